@@ -1,0 +1,34 @@
+"""Shared helpers for the parity tests (oracle side)."""
+import os
+
+import numpy as np
+import torch
+
+from egovlpv2_amd.config import PathConfig
+from egovlpv2_amd.synthetic import make_state_dict, make_batch
+from oracle import ref_model as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load_golden(name):
+    g = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+    depth, n_fuse, img, frames, B, L, wseed, bseed = [int(x) for x in g['meta_cfg']]
+    cfg = PathConfig(depth=depth, n_fuse=n_fuse, img=img, frames=frames)
+    return g, cfg, B, L, wseed, bseed
+
+
+def oracle_setup(cfg, B, L, wseed, bseed, requires_grad=False, tasks='EgoNCE_MLM_ITM'):
+    sd = make_state_dict(cfg, wseed, tasks)
+    if requires_grad:
+        for k, v in sd.items():
+            if v.is_floating_point():
+                v.requires_grad_(True)
+    data, noun, verb = make_batch(cfg, B, L, bseed)
+    return sd, data, noun, verb, O.make_cfg(**cfg.as_dict())
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(np.asarray(a), dtype=torch.float64) if not torch.is_tensor(a) else a.detach().double().cpu()
+    b = torch.as_tensor(np.asarray(b), dtype=torch.float64) if not torch.is_tensor(b) else b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
