@@ -1,0 +1,99 @@
+"""ctypes binding of libegovlp_hip.so (C ABI: include/egovlp_hip.h).
+
+There is no fallback: if the shared library is missing or a symbol is absent, importing the product
+path fails loudly.  ``build()`` in ``__graft_entry__.py`` (or ``egovlpv2_amd/csrc/build.sh``) produces
+the library in-tree.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libegovlp_hip.so')
+
+EGV_F32, EGV_BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+
+
+class AttnDesc(C.Structure):
+    """struct egv_attn_desc (include/egovlp_hip.h) -- field order is the ABI."""
+    _fields_ = [
+        ('Q', vp), ('K', vp), ('V', vp), ('O', vp), ('dO', vp), ('dQ', vp), ('dK', vp), ('dV', vp),
+        ('ldq', i32), ('ldk', i32), ('ldv', i32), ('ldo', i32), ('lddq', i32), ('lddk', i32), ('lddv', i32),
+        ('qoff', i32), ('koff', i32), ('voff', i32), ('ooff', i32), ('dqoff', i32), ('dkoff', i32), ('dvoff', i32),
+        ('lse', vp), ('delta', vp),
+        ('B', i32), ('G', i32), ('H', i32),
+        ('q_bs', i64), ('q_base', i64), ('q_gs', i64), ('q_is', i64), ('q_n', i32),
+        ('k_bs', i64), ('k_base', i64), ('k_gs', i64), ('k_is', i64), ('k_n', i32),
+        ('extra', i32), ('extra_bs', i64), ('extra_row', i64),
+        ('scale', f32),
+        ('mask', vp), ('mask_ld', i32),
+        ('nsplit', i32), ('ws', vp), ('ws_bytes', i64),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/egovlp_hip.h
+PROTOTYPES = {
+    'egv_abi_version': (i32, []),
+    'egv_last_error': (C.c_char_p, []),
+    'egv_gemm': (i32, [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
+    'egv_gemm_wgrad_workspace_bytes': (i64, [i32, i32, i32]),
+    'egv_gemm_wgrad': (i32, [i32, i32, i32, i32, vp, i32, vp, i32, vp, f32, vp, vp, i64, vp]),
+    'egv_layernorm_fwd': (i32, [i32, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
+    'egv_layernorm_bwd_workspace_bytes': (i64, [i32, i32]),
+    'egv_layernorm_bwd': (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
+    'egv_colsum_workspace_bytes': (i64, [i32, i32]),
+    'egv_colsum': (i32, [i32, vp, i32, i32, i32, vp, f32, vp, vp, vp]),
+    'egv_dot': (i32, [i32, vp, vp, i64, vp, f32, vp, vp]),
+    'egv_act_bwd': (i32, [i32, vp, vp, vp, i64, i32, vp]),
+    'egv_cast': (i32, [i32, i32, vp, vp, i64, vp]),
+    'egv_attn_fwd': (i32, [i32, C.POINTER(AttnDesc), vp]),
+    'egv_attn_bwd_dq': (i32, [i32, C.POINTER(AttnDesc), vp]),
+    'egv_attn_bwd_dkv_workspace_bytes': (i64, [i32, i32, i32, i32, i32]),
+    'egv_attn_bwd_dkv': (i32, [i32, C.POINTER(AttnDesc), vp]),
+    'egv_im2col': (i32, [i32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    'egv_assemble_tokens': (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    'egv_assemble_tokens_bwd_workspace_bytes': (i64, [i32, i32, i32]),
+    'egv_assemble_tokens_bwd': (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    'egv_text_embed_fwd': (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    'egv_text_embed_bwd': (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    'egv_ce_fwd': (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i64, vp]),
+    'egv_ce_bwd': (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, vp]),
+    'egv_l2norm_fwd': (i32, [vp, vp, vp, i32, i32, f32, vp]),
+    'egv_l2norm_bwd': (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),
+    'egv_egonce_fwd': (i32, [vp, vp, vp, i32, f32, i32, i32, vp, vp, vp, vp]),
+    'egv_egonce_bwd': (i32, [vp, vp, vp, vp, vp, vp, i32, f32, i32, i32, vp]),
+    'egv_prof_enable': (i32, [i32]),
+    'egv_prof_reset': (i32, []),
+    'egv_prof_collect': (i32, [C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int), i32]),
+}
+
+
+class EgvError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (or egovlpv2_amd/csrc/build.sh). There is no CPU fallback for this path (no CPU fallback).")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError -> loud failure on a stale library
+        fn.restype = res
+        fn.argtypes = args
+    if lib.egv_abi_version() != 1:
+        raise ImportError("libegovlp_hip.so ABI version mismatch")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str = ''):
+    if rc != 0:
+        raise EgvError(f"{what}: rc={rc}: {lib.egv_last_error().decode()}")

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Build libegovlp_hip.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
+set -e
+cd "$(dirname "$0")"
+OUT=../libegovlp_hip.so
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include"
+mkdir -p build
+pids=()
+for f in egv_gemm.hip egv_norm.hip egv_attn.hip egv_misc.hip; do
+  o=build/${f%.hip}.o
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ egv_common.h -nt "$o" ]; then
+    hipcc $FLAGS -c "$f" -o "$o" &
+    pids+=($!)
+  fi
+done
+if [ ! -f build/egv_api.o ] || [ egv_api.cpp -nt build/egv_api.o ]; then
+  hipcc $FLAGS -x hip -c egv_api.cpp -o build/egv_api.o &
+  pids+=($!)
+fi
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT build/egv_gemm.o build/egv_norm.o build/egv_attn.o build/egv_misc.o build/egv_api.o
+echo "built $OUT"

@@ -1,0 +1,488 @@
+// Grouped softmax attention for the EgoVLPv2 hot path, head_dim = 64.
+//
+// All attention variants of the path are "a set of query rows attends to a set of key rows" where both
+// sets are affine row ranges of the (B*S, d) token matrices, optionally with ONE extra row prepended on
+// the other side (the CLS token):
+//   divided space attention : queries = patches of frame f,   keys = [CLS ; patches of frame f]
+//   divided time attention  : queries = patch n of all frames, keys = [CLS ; patch n of all frames]  (row stride N)
+//   CLS query               : query = CLS,                    keys = all S rows
+//   image->text / text->image cross attention, RoBERTa self attention: plain row ranges (+ additive key mask)
+// so the (b h)(f n) d / (b h n) f d permutes, the r-fold repeat of the CLS key/value and the concatenations of
+// video_transformer.py:121-150 are never materialised: kernels gather 128-byte head rows straight from the
+// fused qkv buffer.
+//
+// Backward is split the FlashAttention-1 way into a query-owned kernel (dQ) and a key-owned kernel (dK, dV);
+// with the "extra row" symmetric on both sides every output row is written exactly once (no atomics):
+//   dQ : groups with extra CLS key, CLS query over all keys
+//   dKV: groups with extra CLS query, CLS key over all queries (other side split across workgroups + fp32 reduce)
+//
+// v1 compute mapping (exact fp32 VALU, shared by the f32 and bf16 storage types): lane = key for q.k^T
+// (key row in 64 VGPRs, q broadcast with v_readlane), lane = d for p.V (value column in 64 VGPRs).
+#include "egv_common.h"
+
+namespace egv {
+
+constexpr int HD = 64;          // head dim
+constexpr int TK = 64;          // other-side rows per LDS tile
+constexpr int LDT = 68;         // float pitch of LDS tiles (conflict-free b128 row reads and b32 column reads)
+constexpr int QPW = 8;          // own rows per wave (keeps every kernel under 64 KB of LDS)
+
+struct RowSet {
+    long long bs, base, gs, is;   // row(b,g,i) = b*bs + base + g*gs + i*is
+    int n;
+};
+
+struct AttnArgs {
+    const void* Q; const void* K; const void* V; void* O; const void* dO;
+    void* dQ; void* dK; void* dV;
+    int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
+    int qoff, koff, voff, ooff, dqoff, dkoff, dvoff;
+    float* lse; float* delta; int H;
+    RowSet q, k;
+    int extra; long long extra_bs, extra_row;   // one extra row prepended on the OTHER side of the launched kernel
+    float scale;
+    const float* mask; int mask_ld;             // additive mask over key index: mask[b*mask_ld + i]
+    int G;
+    int nsplit; float* ws;                      // dkv only: split of the query loop + fp32 partial slabs
+};
+
+__device__ __forceinline__ long long rs_row(const RowSet& r, int b, int g, int i) {
+    return (long long)b * r.bs + r.base + (long long)g * r.gs + (long long)i * r.is;
+}
+
+// stage `rows` head rows (64 elements each) of a [.., ld] matrix into an fp32 LDS tile; rows >= nvalid are zero
+template <typename T, int NT>
+__device__ __forceinline__ void stage_tile(float* s, const T* base, int ld, int off, const AttnArgs& a, const RowSet& rs,
+                                           int b, int g, int j0, int ntotal, int tid) {
+    for (int c = tid; c < TK * 16; c += NT) {
+        const int r = c >> 4, v = c & 15;
+        const int j = j0 + r;
+        float x[4] = {0.f, 0.f, 0.f, 0.f};
+        if (j < ntotal) {
+            long long row;
+            if (a.extra) row = (j == 0) ? ((long long)b * a.extra_bs + a.extra_row) : rs_row(rs, b, g, j - 1);
+            else row = rs_row(rs, b, g, j);
+            ld4(base + row * ld + off + v * 4, x);
+        }
+        *reinterpret_cast<f32x4_t*>(s + r * LDT + v * 4) = f32x4_t{x[0], x[1], x[2], x[3]};
+    }
+}
+
+__device__ __forceinline__ void load_row64(const float* s, int r, float (&o)[HD]) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        f32x4_t t = *reinterpret_cast<const f32x4_t*>(s + r * LDT + v * 4);
+        o[v * 4] = t[0]; o[v * 4 + 1] = t[1]; o[v * 4 + 2] = t[2]; o[v * 4 + 3] = t[3];
+    }
+}
+
+__device__ __forceinline__ float dot_bcast(float v, const float (&row)[HD]) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) s = fmaf(readlane_f(v, d), row[d], s);
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward: own = queries
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
+    constexpr int NT = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sK = smem;
+    float* sV = sK + TK * LDT;
+    float* sQ = sV + TK * LDT;                 // [NW][QPW][64]
+    float* sO = sQ + NW * QPW * HD;            // [NW][QPW][64]
+    float* sM = sO + NW * QPW * HD;            // [NW][QPW][2]
+
+    const int tid = threadIdx.x, lane = tid & 63, w = wave_id();
+    const int p = blockIdx.y, b = p / a.G, g = p % a.G, h = blockIdx.z;
+    const int q0 = blockIdx.x * (NW * QPW) + w * QPW;
+    const int nq = min(QPW, a.q.n - q0);       // may be <= 0 for trailing waves
+    const T* Q = reinterpret_cast<const T*>(a.Q);
+    const T* K = reinterpret_cast<const T*>(a.K);
+    const T* V = reinterpret_cast<const T*>(a.V);
+    const int hq = a.qoff + h * HD, hk = a.koff + h * HD, hv = a.voff + h * HD, ho = a.ooff + h * HD;
+
+    for (int i = 0; i < nq; ++i) {
+        const long long row = rs_row(a.q, b, g, q0 + i);
+        sQ[(w * QPW + i) * HD + lane] = Elem<T>::ld(Q + row * a.ldq + hq + lane) * a.scale;
+        sO[(w * QPW + i) * HD + lane] = 0.f;
+        if (lane == 0) {
+            sM[(w * QPW + i) * 2] = -INFINITY;
+            sM[(w * QPW + i) * 2 + 1] = 0.f;
+        }
+    }
+    const int ntot = a.k.n + a.extra;
+    for (int j0 = 0; j0 < ntot; j0 += TK) {
+        __syncthreads();
+        stage_tile<T, NT>(sK, K, a.ldk, hk, a, a.k, b, g, j0, ntot, tid);
+        stage_tile<T, NT>(sV, V, a.ldv, hv, a, a.k, b, g, j0, ntot, tid);
+        __syncthreads();
+        if (nq > 0) {
+            float krow[HD], vcol[HD];
+            load_row64(sK, lane, krow);
+#pragma unroll
+            for (int kk = 0; kk < TK; ++kk) vcol[kk] = sV[kk * LDT + lane];
+            const int j = j0 + lane;
+            const bool valid = j < ntot;
+            float mk = 0.f;
+            if (a.mask && valid && !(a.extra && j == 0)) mk = a.mask[(long long)b * a.mask_ld + (j - a.extra)];
+            for (int i = 0; i < nq; ++i) {
+                const float qv = sQ[(w * QPW + i) * HD + lane];
+                float s = dot_bcast(qv, krow) + mk;
+                s = valid ? s : -INFINITY;
+                const float m_old = sM[(w * QPW + i) * 2], l_old = sM[(w * QPW + i) * 2 + 1];
+                const float m_new = fmaxf(m_old, wave_max(s));
+                const float pj = valid ? __expf(s - m_new) : 0.f;
+                const float corr = __expf(m_old - m_new);
+                const float l_new = l_old * corr + wave_sum(pj);
+                float o = sO[(w * QPW + i) * HD + lane] * corr;
+#pragma unroll
+                for (int kk = 0; kk < TK; ++kk) o = fmaf(readlane_f(pj, kk), vcol[kk], o);
+                sO[(w * QPW + i) * HD + lane] = o;
+                if (lane == 0) {
+                    sM[(w * QPW + i) * 2] = m_new;
+                    sM[(w * QPW + i) * 2 + 1] = l_new;
+                }
+            }
+        }
+    }
+    T* O = reinterpret_cast<T*>(a.O);
+    for (int i = 0; i < nq; ++i) {
+        const long long row = rs_row(a.q, b, g, q0 + i);
+        const float m = sM[(w * QPW + i) * 2], l = sM[(w * QPW + i) * 2 + 1];
+        Elem<T>::st(O + row * a.ldo + ho + lane, sO[(w * QPW + i) * HD + lane] / l);
+        if (a.lse && lane == 0) a.lse[row * a.H + h] = m + __logf(l);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, query-owned: dQ (+ delta = rowsum(dO * O))
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const AttnArgs a) {
+    constexpr int NT = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sK = smem;
+    float* sV = sK + TK * LDT;
+    float* sQ = sV + TK * LDT;                 // [NW][QPW][64] scaled q
+    float* sDO = sQ + NW * QPW * HD;           // [NW][QPW][64]
+    float* sDQ = sDO + NW * QPW * HD;          // [NW][QPW][64]
+    float* sS = sDQ + NW * QPW * HD;           // [NW][QPW][2]: lse, delta
+
+    const int tid = threadIdx.x, lane = tid & 63, w = wave_id();
+    const int p = blockIdx.y, b = p / a.G, g = p % a.G, h = blockIdx.z;
+    const int q0 = blockIdx.x * (NW * QPW) + w * QPW;
+    const int nq = min(QPW, a.q.n - q0);
+    const T* Q = reinterpret_cast<const T*>(a.Q);
+    const T* K = reinterpret_cast<const T*>(a.K);
+    const T* V = reinterpret_cast<const T*>(a.V);
+    const T* O = reinterpret_cast<const T*>(a.O);
+    const T* dO = reinterpret_cast<const T*>(a.dO);
+    const int hq = a.qoff + h * HD, hk = a.koff + h * HD, hv = a.voff + h * HD, ho = a.ooff + h * HD;
+
+    for (int i = 0; i < nq; ++i) {
+        const long long row = rs_row(a.q, b, g, q0 + i);
+        const float dov = Elem<T>::ld(dO + row * a.ldo + ho + lane);
+        const float ov = Elem<T>::ld(O + row * a.ldo + ho + lane);
+        sQ[(w * QPW + i) * HD + lane] = Elem<T>::ld(Q + row * a.ldq + hq + lane) * a.scale;
+        sDO[(w * QPW + i) * HD + lane] = dov;
+        sDQ[(w * QPW + i) * HD + lane] = 0.f;
+        const float dl = wave_sum(dov * ov);
+        if (lane == 0) {
+            sS[(w * QPW + i) * 2] = a.lse[row * a.H + h];
+            sS[(w * QPW + i) * 2 + 1] = dl;
+            a.delta[row * a.H + h] = dl;
+        }
+    }
+    const int ntot = a.k.n + a.extra;
+    for (int j0 = 0; j0 < ntot; j0 += TK) {
+        __syncthreads();
+        stage_tile<T, NT>(sK, K, a.ldk, hk, a, a.k, b, g, j0, ntot, tid);
+        stage_tile<T, NT>(sV, V, a.ldv, hv, a, a.k, b, g, j0, ntot, tid);
+        __syncthreads();
+        if (nq > 0) {
+            float krow[HD], vrow[HD];
+            load_row64(sK, lane, krow);
+            load_row64(sV, lane, vrow);
+            const int j = j0 + lane;
+            const bool valid = j < ntot;
+            float mk = 0.f;
+            if (a.mask && valid && !(a.extra && j == 0)) mk = a.mask[(long long)b * a.mask_ld + (j - a.extra)];
+            for (int i = 0; i < nq; ++i) {
+                const float qv = sQ[(w * QPW + i) * HD + lane];
+                const float dov = sDO[(w * QPW + i) * HD + lane];
+                const float lse = sS[(w * QPW + i) * 2], dl = sS[(w * QPW + i) * 2 + 1];
+                const float s = dot_bcast(qv, krow) + mk;
+                const float pj = valid ? __expf(s - lse) : 0.f;
+                const float dp = dot_bcast(dov, vrow);
+                const float ds = pj * (dp - dl);
+                float acc = sDQ[(w * QPW + i) * HD + lane];
+#pragma unroll
+                for (int kk = 0; kk < TK; ++kk) acc = fmaf(readlane_f(ds, kk), sK[kk * LDT + lane], acc);
+                sDQ[(w * QPW + i) * HD + lane] = acc;
+            }
+        }
+    }
+    T* dQ = reinterpret_cast<T*>(a.dQ);
+    const int hdq = a.dqoff + h * HD;
+    for (int i = 0; i < nq; ++i) {
+        const long long row = rs_row(a.q, b, g, q0 + i);
+        Elem<T>::st(dQ + row * a.lddq + hdq + lane, sDQ[(w * QPW + i) * HD + lane] * a.scale);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, key-owned: dK, dV.  own = keys (one tile of <= 64 keys per workgroup, lane = key),
+// other = queries (optional extra CLS query first), distributed over the waves (and over blockIdx.x % nsplit).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sK = smem;                          // own tile [64][LDT]
+    float* sV = sK + TK * LDT;
+    float* sR = smem;                          // reduction buffer [64][129], aliases sK/sV after the main loop
+    constexpr int LDR = 129;
+    static_assert(2 * TK * LDT >= TK * 129, "reduction buffer must fit in the K/V tiles");
+
+    const int tid = threadIdx.x, lane = tid & 63, w = wave_id();
+    const int p = blockIdx.y, b = p / a.G, g = p % a.G, h = blockIdx.z;
+    const int tile = blockIdx.x / a.nsplit, split = blockIdx.x % a.nsplit;
+    const int k0 = tile * TK;
+    const int nk = min(TK, a.k.n - k0);
+    const T* Q = reinterpret_cast<const T*>(a.Q);
+    const T* K = reinterpret_cast<const T*>(a.K);
+    const T* V = reinterpret_cast<const T*>(a.V);
+    const T* dO = reinterpret_cast<const T*>(a.dO);
+    const int hq = a.qoff + h * HD, hk = a.koff + h * HD, hv = a.voff + h * HD, ho = a.ooff + h * HD;
+
+    // stage own K/V tile (no extra on the own side)
+    for (int c = tid; c < TK * 16; c += 64 * NW) {
+        const int r = c >> 4, v = c & 15;
+        float x[4] = {0.f, 0.f, 0.f, 0.f}, y[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < nk) {
+            const long long row = rs_row(a.k, b, g, k0 + r);
+            ld4(K + row * a.ldk + hk + v * 4, x);
+            ld4(V + row * a.ldv + hv + v * 4, y);
+        }
+        *reinterpret_cast<f32x4_t*>(sK + r * LDT + v * 4) = f32x4_t{x[0], x[1], x[2], x[3]};
+        *reinterpret_cast<f32x4_t*>(sV + r * LDT + v * 4) = f32x4_t{y[0], y[1], y[2], y[3]};
+    }
+    __syncthreads();
+
+    float dk[HD], dv[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) dk[d] = dv[d] = 0.f;
+    const bool valid = lane < nk;
+    float mk = 0.f;
+    if (a.mask && valid) mk = a.mask[(long long)b * a.mask_ld + k0 + lane];
+
+    const int ntot = a.q.n + a.extra;
+    const int per = (ntot + a.nsplit - 1) / a.nsplit;
+    const int i0 = split * per, i1 = min(ntot, i0 + per);
+    for (int i = i0 + w; i < i1; i += NW) {
+        long long row;
+        if (a.extra) row = (i == 0) ? ((long long)b * a.extra_bs + a.extra_row) : rs_row(a.q, b, g, i - 1);
+        else row = rs_row(a.q, b, g, i);
+        const float qv = Elem<T>::ld(Q + row * a.ldq + hq + lane) * a.scale;
+        const float dov = Elem<T>::ld(dO + row * a.ldo + ho + lane);
+        const float lse = a.lse[row * a.H + h], dl = a.delta[row * a.H + h];
+        float s = mk, dp = 0.f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const f32x4_t kx = *reinterpret_cast<const f32x4_t*>(sK + lane * LDT + v * 4);
+            const f32x4_t vx = *reinterpret_cast<const f32x4_t*>(sV + lane * LDT + v * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s = fmaf(readlane_f(qv, v * 4 + e), kx[e], s);
+                dp = fmaf(readlane_f(dov, v * 4 + e), vx[e], dp);
+            }
+        }
+        const float pj = valid ? __expf(s - lse) : 0.f;
+        const float ds = pj * (dp - dl);
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            dv[d] = fmaf(pj, readlane_f(dov, d), dv[d]);
+            dk[d] = fmaf(ds, readlane_f(qv, d), dk[d]);     // qv carries the softmax scale
+        }
+    }
+    // cross-wave reduction through LDS (lane = key writes column d: pitch 129 -> conflict free)
+    __syncthreads();                           // every wave is done reading sK/sV
+    for (int ww = 0; ww < NW; ++ww) {
+        if (w == ww) {
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                if (ww == 0) {
+                    sR[lane * LDR + d] = dk[d];
+                    sR[lane * LDR + HD + d] = dv[d];
+                } else {
+                    sR[lane * LDR + d] += dk[d];
+                    sR[lane * LDR + HD + d] += dv[d];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (a.nsplit == 1) {
+        T* dK = reinterpret_cast<T*>(a.dK);
+        T* dV = reinterpret_cast<T*>(a.dV);
+        const int hdk = a.dkoff + h * HD, hdv = a.dvoff + h * HD;
+        for (int r = w; r < nk; r += NW) {
+            const long long row = rs_row(a.k, b, g, k0 + r);
+            Elem<T>::st(dK + row * a.lddk + hdk + lane, sR[r * LDR + lane]);
+            Elem<T>::st(dV + row * a.lddv + hdv + lane, sR[r * LDR + HD + lane]);
+        }
+    } else {
+        // ws layout: [split][P * k.n own rows][H][2][64] fp32
+        const long long nrows = (long long)gridDim.y * a.k.n;
+        for (int r = w; r < nk; r += NW) {
+            const long long orow = (long long)p * a.k.n + k0 + r;
+            float* dst = a.ws + (((long long)split * nrows + orow) * a.H + h) * 2 * HD;
+            dst[lane] = sR[r * LDR + lane];
+            dst[HD + lane] = sR[r * LDR + HD + lane];
+        }
+    }
+}
+
+template <typename T>
+__global__ void attn_dkv_reduce_kernel(const AttnArgs a, int P) {
+    // one wave per (own row, head)
+    const int lane = threadIdx.x & 63;
+    const long long nrows = (long long)P * a.k.n;
+    const long long idx = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (idx >= nrows * a.H) return;
+    const long long orow = idx / a.H;
+    const int h = (int)(idx % a.H);
+    const int p = (int)(orow / a.k.n), i = (int)(orow % a.k.n);
+    const int b = p / a.G, g = p % a.G;
+    float sk = 0.f, sv = 0.f;
+    for (int s = 0; s < a.nsplit; ++s) {
+        const float* src = a.ws + (((long long)s * nrows + orow) * a.H + h) * 2 * HD;
+        sk += src[lane];
+        sv += src[HD + lane];
+    }
+    const long long row = rs_row(a.k, b, g, i);
+    T* dK = reinterpret_cast<T*>(a.dK);
+    T* dV = reinterpret_cast<T*>(a.dV);
+    Elem<T>::st(dK + row * a.lddk + a.dkoff + h * HD + lane, sk);
+    Elem<T>::st(dV + row * a.lddv + a.dvoff + h * HD + lane, sv);
+}
+
+static inline size_t fwd_smem(int nw) { return (size_t)(2 * TK * LDT + 2 * nw * QPW * HD + nw * QPW * 2) * 4; }
+static inline size_t dq_smem(int nw) { return (size_t)(2 * TK * LDT + 3 * nw * QPW * HD + nw * QPW * 2) * 4; }
+static inline size_t dkv_smem() { return (size_t)(2 * TK * LDT) * 4; }
+
+}  // namespace egv
+using namespace egv;
+
+// Flat C description of one attention launch (see include/egovlp_hip.h).
+struct egv_attn_desc {
+    const void* Q; const void* K; const void* V; void* O; const void* dO; void* dQ; void* dK; void* dV;
+    int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
+    int qoff, koff, voff, ooff, dqoff, dkoff, dvoff;
+    float* lse; float* delta;
+    int B, G, H;
+    long long q_bs, q_base, q_gs, q_is; int q_n;
+    long long k_bs, k_base, k_gs, k_is; int k_n;
+    int extra; long long extra_bs, extra_row;
+    float scale;
+    const float* mask; int mask_ld;
+    int nsplit; float* ws; long long ws_bytes;
+};
+
+static AttnArgs to_args(const egv_attn_desc* d) {
+    AttnArgs a;
+    a.Q = d->Q; a.K = d->K; a.V = d->V; a.O = d->O; a.dO = d->dO; a.dQ = d->dQ; a.dK = d->dK; a.dV = d->dV;
+    a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo; a.lddq = d->lddq; a.lddk = d->lddk; a.lddv = d->lddv;
+    a.qoff = d->qoff; a.koff = d->koff; a.voff = d->voff; a.ooff = d->ooff; a.dqoff = d->dqoff; a.dkoff = d->dkoff; a.dvoff = d->dvoff;
+    a.lse = d->lse; a.delta = d->delta; a.H = d->H;
+    a.q = RowSet{d->q_bs, d->q_base, d->q_gs, d->q_is, d->q_n};
+    a.k = RowSet{d->k_bs, d->k_base, d->k_gs, d->k_is, d->k_n};
+    a.extra = d->extra; a.extra_bs = d->extra_bs; a.extra_row = d->extra_row;
+    a.scale = d->scale; a.mask = d->mask; a.mask_ld = d->mask_ld; a.G = d->G;
+    a.nsplit = d->nsplit > 0 ? d->nsplit : 1; a.ws = d->ws;
+    return a;
+}
+
+static int check_desc(const egv_attn_desc* d, const char* who) {
+    EGV_CHECK(d->B > 0 && d->G > 0 && d->H > 0 && d->q_n > 0 && d->k_n > 0, "%s: bad problem shape", who);
+    EGV_CHECK((d->ldq % 4 == 0) && (d->ldk % 4 == 0) && (d->ldv % 4 == 0) && (d->qoff % 4 == 0) && (d->koff % 4 == 0) &&
+                  (d->voff % 4 == 0), "%s: leading dims / head offsets must be multiples of 4 elements", who);
+    return 0;
+}
+
+#define EGV_ATTN_LAUNCH(KERNEL, NWV, SMEM, GRID)                                                                 \
+    do {                                                                                                         \
+        if (dtype == EGV_BF16) {                                                                                 \
+            if (NWV == 1) hipLaunchKernelGGL((KERNEL<bf16_t, 1>), GRID, dim3(64), SMEM, st, a);                    \
+            else if (NWV == 2) hipLaunchKernelGGL((KERNEL<bf16_t, 2>), GRID, dim3(128), SMEM, st, a);              \
+            else hipLaunchKernelGGL((KERNEL<bf16_t, 4>), GRID, dim3(256), SMEM, st, a);                            \
+        } else {                                                                                                 \
+            if (NWV == 1) hipLaunchKernelGGL((KERNEL<float, 1>), GRID, dim3(64), SMEM, st, a);                     \
+            else if (NWV == 2) hipLaunchKernelGGL((KERNEL<float, 2>), GRID, dim3(128), SMEM, st, a);               \
+            else hipLaunchKernelGGL((KERNEL<float, 4>), GRID, dim3(256), SMEM, st, a);                             \
+        }                                                                                                        \
+    } while (0)
+
+static inline int pick_nw(int n_own) {
+    const int t = (n_own + QPW - 1) / QPW;
+    return t >= 4 ? 4 : (t >= 2 ? 2 : 1);
+}
+
+extern "C" int egv_attn_fwd(int dtype, const egv_attn_desc* d, void* stream) {
+    if (check_desc(d, "egv_attn_fwd")) return -1;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    AttnArgs a = to_args(d);
+    const int nw = pick_nw(d->q_n);
+    dim3 grid((d->q_n + nw * QPW - 1) / (nw * QPW), d->B * d->G, d->H);
+    const size_t sm = fwd_smem(nw);
+    EGV_ATTN_LAUNCH(attn_fwd_kernel, nw, sm, grid);
+    EGV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int egv_attn_bwd_dq(int dtype, const egv_attn_desc* d, void* stream) {
+    if (check_desc(d, "egv_attn_bwd_dq")) return -1;
+    EGV_CHECK(d->lse && d->delta && d->dO && d->dQ, "egv_attn_bwd_dq: missing lse/delta/dO/dQ");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    AttnArgs a = to_args(d);
+    const int nw = pick_nw(d->q_n);
+    dim3 grid((d->q_n + nw * QPW - 1) / (nw * QPW), d->B * d->G, d->H);
+    const size_t sm = dq_smem(nw);
+    EGV_ATTN_LAUNCH(attn_bwd_dq_kernel, nw, sm, grid);
+    EGV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" long long egv_attn_bwd_dkv_workspace_bytes(int B, int G, int H, int k_n, int nsplit) {
+    if (nsplit <= 1) return 0;
+    return (long long)nsplit * B * G * k_n * H * 2 * HD * 4;
+}
+
+extern "C" int egv_attn_bwd_dkv(int dtype, const egv_attn_desc* d, void* stream) {
+    if (check_desc(d, "egv_attn_bwd_dkv")) return -1;
+    EGV_CHECK(d->lse && d->delta && d->dO && d->dK && d->dV, "egv_attn_bwd_dkv: missing lse/delta/dO/dK/dV");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    AttnArgs a = to_args(d);
+    if (a.nsplit > 1)
+        EGV_CHECK(d->ws && d->ws_bytes >= egv_attn_bwd_dkv_workspace_bytes(d->B, d->G, d->H, d->k_n, a.nsplit),
+                  "egv_attn_bwd_dkv: workspace too small");
+    const int ntot = d->q_n + d->extra;
+    const int per = (ntot + a.nsplit - 1) / a.nsplit;
+    const int nw = per >= 4 ? 4 : (per >= 2 ? 2 : 1);
+    const int tiles = (d->k_n + TK - 1) / TK;
+    dim3 grid(tiles * a.nsplit, d->B * d->G, d->H);
+    const size_t sm = dkv_smem();
+    EGV_ATTN_LAUNCH(attn_bwd_dkv_kernel, nw, sm, grid);
+    EGV_LAUNCH_CHECK();
+    if (a.nsplit > 1) {
+        const long long n = (long long)d->B * d->G * d->k_n * d->H;
+        const int blocks = (int)((n + 3) / 4);
+        if (dtype == EGV_BF16) hipLaunchKernelGGL(attn_dkv_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, a, d->B * d->G);
+        else hipLaunchKernelGGL(attn_dkv_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, a, d->B * d->G);
+        EGV_LAUNCH_CHECK();
+    }
+    return 0;
+}

@@ -1,0 +1,113 @@
+// Common device helpers for the gfx950 (MI355X / CDNA4) kernels of the EgoVLPv2 hot path.
+// Wavefront = 64 lanes everywhere; no other architecture is supported (no dual paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define EGV_F32 0
+#define EGV_BF16 1
+
+namespace egv {
+
+struct bf16_t { unsigned short v; };
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
+// round-to-nearest-even, NaN preserved (same rounding torch uses for float -> bfloat16)
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int VEC = 4;   // elements per 16-byte chunk
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int VEC = 8;
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(p->v); }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { p->v = f2bf(v); }
+};
+
+// 4 consecutive elements <-> 4 floats (8 B for bf16, 16 B for f32); p must be aligned to the vector.
+__device__ __forceinline__ void ld4(const float* p, float (&o)[4]) {
+    f32x4_t v = *reinterpret_cast<const f32x4_t*>(p);
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+}
+__device__ __forceinline__ void ld4(const bf16_t* p, float (&o)[4]) {
+    u32x2_t v = *reinterpret_cast<const u32x2_t*>(p);
+    o[0] = __uint_as_float(v[0] << 16); o[1] = __uint_as_float(v[0] & 0xffff0000u);
+    o[2] = __uint_as_float(v[1] << 16); o[3] = __uint_as_float(v[1] & 0xffff0000u);
+}
+__device__ __forceinline__ void st4(float* p, const float (&o)[4]) {
+    f32x4_t v = {o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<f32x4_t*>(p) = v;
+}
+__device__ __forceinline__ void st4(bf16_t* p, const float (&o)[4]) {
+    u32x2_t v;
+    v[0] = (unsigned int)f2bf(o[0]) | ((unsigned int)f2bf(o[1]) << 16);
+    v[1] = (unsigned int)f2bf(o[2]) | ((unsigned int)f2bf(o[3]) << 16);
+    *reinterpret_cast<u32x2_t*>(p) = v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+    // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// bijective XCD-aware remap of a linear workgroup id (cdna_hip_programming.md §5 template):
+// consecutive logical tiles land on the same XCD (= same L2) instead of round-robin over the 8 XCDs.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int nx = 8;
+    const int q = nwg / nx, r = nwg % nx;
+    const int xcd = bid % nx, idx = bid / nx;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+}  // namespace egv
+
+// ---- host side error plumbing shared by the C ABI translation units ----
+extern "C" const char* egv_last_error(void);
+void egv_set_error(const char* fmt, ...);
+#define EGV_CHECK(cond, ...)                      \
+    do {                                          \
+        if (!(cond)) {                            \
+            egv_set_error(__VA_ARGS__);           \
+            return -1;                            \
+        }                                         \
+    } while (0)
+#define EGV_LAUNCH_CHECK()                                                   \
+    do {                                                                     \
+        hipError_t e__ = hipGetLastError();                                  \
+        if (e__ != hipSuccess) {                                             \
+            egv_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__)); \
+            return -2;                                                       \
+        }                                                                    \
+    } while (0)

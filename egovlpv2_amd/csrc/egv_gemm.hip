@@ -1,0 +1,467 @@
+// MFMA GEMM for gfx950 with fused epilogues -- the dominant kernel of the EgoVLPv2 hot path
+// (~97 % of the FLOPs).
+//
+//   C[M,N] = epilogue( sum_k Aop[m,k] * Bop[n,k] )
+//
+// One template covers the three GEMM forms of a Linear layer y = x W^T + b (W stored [N_out, K_in]):
+//   forward   y  = x  W^T : A = x  [M,K]  (AT=0),  B = W  [N,K]       (BT=0)
+//   dgrad     dx = dy W   : A = dy [M,N'] (AT=0),  B = W  [N',K'] read as [red, out] (BT=1)
+//   wgrad     dW = dy^T x : A = dy [M',N] read as [red, out] (AT=1), B = x [M',K] (BT=1)
+// AT/BT = 1 means the operand is stored [reduction, rows] (rows contiguous) and is transposed on the
+// way into LDS by an in-register VEC x VEC block transpose, so the MFMA main loop is identical for
+// all three forms and no transposed copies of weights or activations ever touch HBM.
+//
+// Tiling (v1): 128x128 output tile per 256-thread workgroup (4 waves, 2x2, 64x64 per wave = 4x4
+// MFMA 16x16 tiles), K step = 128 bytes per row (64 bf16 / 32 f32), register-prefetched global
+// loads -> padded LDS (144 B pitch: conflict-free ds_read_b128 fragments) -> MFMA
+// (v_mfma_f32_16x16x32_bf16 / exact-fp32 v_mfma_f32_16x16x4_f32), fp32 accumulation.
+// Operands are swapped in the MFMA (D = W_frag * X_frag^T) so that every lane owns 4 consecutive
+// output columns of one row: bias / residual / aux loads and the store are 8-16 B vectors.
+#include "egv_common.h"
+
+namespace egv {
+
+constexpr int BM = 128, BN = 128;
+constexpr int PITCH = 144;          // bytes per LDS row: 128 B of K + 16 B pad
+constexpr int ROWB = 128;           // payload bytes per LDS row
+
+struct GemmEpi {
+    const float* bias;   // [N] fp32 or null
+    const float* gate;   // device scalar (alpha gate) or null
+    const void* res1;    // [M,N] T or null
+    const void* res2;    // [M,N] T or null
+    void* pre;           // [M,N] T: save (acc + bias) before activation, or null
+    const void* aux;     // [M,N] T: operand of the activation derivative (backward), or null
+    int act;             // 0 none, 1 gelu(erf), 2 relu, 3 tanh
+    int dact;            // 0 none, 1 gelu'(aux = pre-activation), 2 relu'(aux = output), 3 tanh'(aux = output)
+    int ldr;             // leading dim of res1/res2/pre/aux
+    float scale;         // host scalar applied to the accumulator first
+};
+
+struct GemmArgs {
+    const void* A;
+    const void* B;
+    void* C;
+    int M, N, K;
+    int lda, ldb, ldc;
+    int a_vec_ok, b_vec_ok, c_vec_ok;   // 16-byte vector path allowed (pointer + leading dim aligned)
+    int k_per_split;                    // K range per blockIdx.z (== K when not split)
+    long long slab_stride;              // elements between split slabs of C
+    int tiles_m, tiles_n;
+    GemmEpi e;
+};
+
+template <typename T> struct Tile;
+template <> struct Tile<bf16_t> { static constexpr int BK = 64; };
+template <> struct Tile<float> { static constexpr int BK = 32; };
+
+// ---- 16-byte chunk load with zero fill (row-contiguous run of VEC elements starting at p) ----
+template <typename T>
+__device__ __forceinline__ u32x4_t load_chunk(const T* p, int n_valid, bool vec_ok) {
+    constexpr int VEC = Elem<T>::VEC;
+    u32x4_t r = {0u, 0u, 0u, 0u};
+    if (n_valid >= VEC && vec_ok) {
+        r = *reinterpret_cast<const u32x4_t*>(p);
+    } else if (n_valid > 0) {
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e < n_valid) r[e] = reinterpret_cast<const unsigned int*>(p)[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (e < n_valid) r[e >> 1] |= ((unsigned int)reinterpret_cast<const unsigned short*>(p)[e]) << ((e & 1) * 16);
+        }
+    }
+    return r;
+}
+
+// Per-thread staging registers for one operand tile (128 rows x 128 B).
+// Direct: 1024 chunks / 256 threads = 4 chunks.  Transposed: units of VEC chunks (VEC x VEC blocks).
+template <typename T, int TR>
+struct Stager {
+    static constexpr int VEC = Elem<T>::VEC;
+    static constexpr int BK = Tile<T>::BK;
+    static constexpr int NCH = TR ? VEC : 4;
+    u32x4_t r[NCH];
+
+    // op: base pointer; rows: extent of the (non-reduction) row dimension; ld: leading dim;
+    // row0: first tile row; k0: first reduction index of this K step; kend: end of the reduction range.
+    __device__ __forceinline__ void load(const T* op, int rows, int ld, int row0, int k0, int kend, bool vec_ok, int tid) {
+        if constexpr (!TR) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = tid + i * 256;
+                const int row = c >> 3, cc = c & 7;
+                const int grow = row0 + row, gk = k0 + cc * VEC;
+                int nv = kend - gk;
+                if (grow >= rows) nv = 0;
+                r[i] = load_chunk<T>(op + (size_t)grow * ld + gk, nv, vec_ok);
+            }
+        } else {
+            constexpr int RB = 128 / VEC;          // row blocks per tile
+            constexpr int UNITS = 8 * RB;          // 8 k-blocks of VEC
+            if (tid < UNITS) {
+                const int kb = tid / RB, rb = tid % RB;
+                const int grow0 = row0 + rb * VEC;
+                const int nv_rows = rows - grow0;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const int gk = k0 + kb * VEC + j;
+                    const int nv = (gk < kend) ? nv_rows : 0;
+                    r[j] = load_chunk<T>(op + (size_t)gk * ld + grow0, nv, vec_ok);
+                }
+            }
+        }
+    }
+
+    __device__ __forceinline__ void store(unsigned char* s, int tid) const {
+        if constexpr (!TR) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = tid + i * 256;
+                const int row = c >> 3, cc = c & 7;
+                *reinterpret_cast<u32x4_t*>(s + row * PITCH + cc * 16) = r[i];
+            }
+        } else {
+            constexpr int RB = 128 / VEC;
+            constexpr int UNITS = 8 * RB;
+            if (tid < UNITS) {
+                const int kb = tid / RB, rb = tid % RB;
+                if constexpr (sizeof(T) == 4) {
+                    // r[j][e] = X[k = kb*4+j][row = rb*4+e]  ->  out[e][j]
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        u32x4_t o = {r[0][e], r[1][e], r[2][e], r[3][e]};
+                        *reinterpret_cast<u32x4_t*>(s + (rb * 4 + e) * PITCH + kb * 16) = o;
+                    }
+                } else {
+                    // r[j] holds rows rb*8 .. +7 (two per dword) at k = kb*8 + j.
+                    // out[row e].dword[d] = (lo: r[2d] elem e, hi: r[2d+1] elem e)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        u32x4_t o;
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const unsigned int a = r[2 * d][e >> 1], b = r[2 * d + 1][e >> 1];
+                            o[d] = (e & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+                        }
+                        *reinterpret_cast<u32x4_t*>(s + (rb * 8 + e) * PITCH + kb * 16) = o;
+                    }
+                }
+            }
+        }
+    }
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    // one 128-byte LDS row segment = 64 bf16 = 2 MFMA k-steps of 32
+    static __device__ __forceinline__ void run(const unsigned char* sA, const unsigned char* sB, int wm, int wn, int lane,
+                                               f32x4_t (&acc)[4][4]) {
+        const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = *reinterpret_cast<const bf16x8_t*>(sA + (wm * 64 + i * 16 + fr) * PITCH + ks * 64 + fg * 16);
+                b[i] = *reinterpret_cast<const bf16x8_t*>(sB + (wn * 64 + i * 16 + fr) * PITCH + ks * 64 + fg * 16);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni], a[mi], acc[mi][ni], 0, 0, 0);
+        }
+    }
+};
+template <> struct Mma<float> {
+    // 128-byte row = 32 f32 = 2 groups of 16 k; lane group g reads k = ks*16 + g*4 .. +3 (one b128) and
+    // feeds element e to MFMA step e (k order inside the reduction is free as long as A and B agree).
+    static __device__ __forceinline__ void run(const unsigned char* sA, const unsigned char* sB, int wm, int wn, int lane,
+                                               f32x4_t (&acc)[4][4]) {
+        const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f32x4_t a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = *reinterpret_cast<const f32x4_t*>(sA + (wm * 64 + i * 16 + fr) * PITCH + ks * 64 + fg * 16);
+                b[i] = *reinterpret_cast<const f32x4_t*>(sB + (wn * 64 + i * 16 + fr) * PITCH + ks * 64 + fg * 16);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[ni][e], a[mi][e], acc[mi][ni], 0, 0, 0);
+        }
+    }
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == 1) return gelu_f(v);
+    if (act == 2) return fmaxf(v, 0.0f);
+    if (act == 3) return tanhf(v);
+    return v;
+}
+__device__ __forceinline__ float apply_dact(float aux, int dact) {
+    if (dact == 1) return dgelu_f(aux);
+    if (dact == 2) return aux > 0.0f ? 1.0f : 0.0f;
+    if (dact == 3) return 1.0f - aux * aux;
+    return 1.0f;
+}
+
+template <typename T, int AT, int BT, typename OutT>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
+    constexpr int BK = Tile<T>::BK;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 128 * PITCH];
+    unsigned char* sA = smem;
+    unsigned char* sB = smem + 128 * PITCH;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = wave_id();
+    const int wm = wid >> 1, wn = wid & 1;
+
+    const int ntile = g.tiles_m * g.tiles_n;
+    const int t = xcd_remap(blockIdx.x, ntile);
+    const int tm = t / g.tiles_n, tn = t % g.tiles_n;     // N tiles fastest: neighbours share the A panel in L2
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int kbeg = blockIdx.z * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+
+    const T* A = reinterpret_cast<const T*>(g.A);
+    const T* B = reinterpret_cast<const T*>(g.B);
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    Stager<T, AT> stA;
+    Stager<T, BT> stB;
+    // when a transposed bf16 operand only has 128 units, give B's units to threads 128..255
+    const int tidB = (BT && AT) ? ((tid + 128) & 255) : tid;
+
+    stA.load(A, g.M, g.lda, m0, kbeg, kend, g.a_vec_ok != 0, tid);
+    stB.load(B, g.N, g.ldb, n0, kbeg, kend, g.b_vec_ok != 0, tidB);
+
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        stA.store(sA, tid);
+        stB.store(sB, tidB);
+        __syncthreads();
+        if (k0 + BK < kend) {
+            stA.load(A, g.M, g.lda, m0, k0 + BK, kend, g.a_vec_ok != 0, tid);
+            stB.load(B, g.N, g.ldb, n0, k0 + BK, kend, g.b_vec_ok != 0, tidB);
+        }
+        Mma<T>::run(sA, sB, wm, wn, lane, acc);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue ----------------
+    const GemmEpi& e = g.e;
+    OutT* C = reinterpret_cast<OutT*>(g.C) + (size_t)blockIdx.z * g.slab_stride;
+    const T* R1 = reinterpret_cast<const T*>(e.res1);
+    const T* R2 = reinterpret_cast<const T*>(e.res2);
+    const T* AUX = reinterpret_cast<const T*>(e.aux);
+    T* PRE = reinterpret_cast<T*>(e.pre);
+    const float gate = e.gate ? *e.gate : 1.0f;
+    const int fr = lane & 15, fg = lane >> 4;
+    const bool rvec = (e.ldr & 3) == 0;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wm * 64 + mi * 16 + fr;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wn * 64 + ni * 16 + fg * 4;
+            if (n >= g.N) continue;
+            float v[4] = {acc[mi][ni][0] * e.scale, acc[mi][ni][1] * e.scale, acc[mi][ni][2] * e.scale, acc[mi][ni][3] * e.scale};
+            const bool full = (n + 3 < g.N);
+            const size_t ro = (size_t)m * e.ldr + n;
+            if (e.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (full || n + r < g.N) v[r] += e.bias[n + r];
+            }
+            if (PRE) {
+                if (full && rvec) st4(PRE + ro, v);
+                else
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < g.N) Elem<T>::st(PRE + ro + r, v[r]);
+            }
+            if (e.act) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], e.act);
+            }
+            if (e.gate) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= gate;
+            }
+            if (R1) {
+                float x[4] = {0.f, 0.f, 0.f, 0.f};
+                if (full && rvec) ld4(R1 + ro, x);
+                else
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < g.N) x[r] = Elem<T>::ld(R1 + ro + r);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += x[r];
+            }
+            if (R2) {
+                float x[4] = {0.f, 0.f, 0.f, 0.f};
+                if (full && rvec) ld4(R2 + ro, x);
+                else
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < g.N) x[r] = Elem<T>::ld(R2 + ro + r);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += x[r];
+            }
+            if (e.dact) {
+                float x[4] = {0.f, 0.f, 0.f, 0.f};
+                if (full && rvec) ld4(AUX + ro, x);
+                else
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < g.N) x[r] = Elem<T>::ld(AUX + ro + r);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= apply_dact(x[r], e.dact);
+            }
+            const size_t co = (size_t)m * g.ldc + n;
+            if (full && g.c_vec_ok) st4(C + co, v);
+            else
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < g.N) Elem<OutT>::st(C + co + r, v[r]);
+        }
+    }
+}
+
+// sum split-K slabs: out[i] = scale * gate * sum_z slab[z][i]   (fp32, deterministic order)
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out, long long n, int nz,
+                                    long long stride, float scale, const float* gate) {
+    const float gsc = scale * (gate ? *gate : 1.0f);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < nz; ++z) s += slabs[(size_t)z * stride + i];
+        out[i] = s * gsc;
+    }
+}
+
+template <typename T, int AT, int BT, typename OutT>
+static int launch_gemm(const GemmArgs& g, int nz, hipStream_t st) {
+    dim3 grid(g.tiles_m * g.tiles_n, 1, nz);
+    hipLaunchKernelGGL((gemm_kernel<T, AT, BT, OutT>), grid, dim3(256), 0, st, g);
+    return 0;
+}
+
+}  // namespace egv
+
+using namespace egv;
+
+void* egv_prof_begin(void* stream);
+void egv_prof_end(void* handle, void* stream, double flops, int kind);
+
+static inline int vec_ok(const void* p, int ld, int dtype) {
+    const int vec = dtype == EGV_BF16 ? 8 : 4;
+    return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (ld % vec == 0);
+}
+
+// See include/egovlp_hip.h for the contract.
+extern "C" int egv_gemm(int dtype, int a_trans, int b_trans, int M, int N, int K,
+                        const void* A, int lda, const void* B, int ldb, void* C, int ldc, int out_f32,
+                        const float* bias, int act, const float* gate, const void* res1, const void* res2,
+                        void* pre, const void* aux, int dact, int ldr, float scale, void* stream) {
+    EGV_CHECK(dtype == EGV_F32 || dtype == EGV_BF16, "egv_gemm: bad dtype %d", dtype);
+    EGV_CHECK(M > 0 && N > 0 && K > 0, "egv_gemm: bad shape %d %d %d", M, N, K);
+    EGV_CHECK(!(a_trans && !b_trans), "egv_gemm: (a_trans=1,b_trans=0) is not a form this path uses");
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.a_vec_ok = vec_ok(A, lda, dtype);
+    g.b_vec_ok = vec_ok(B, ldb, dtype);
+    g.c_vec_ok = out_f32 ? vec_ok(C, ldc, EGV_F32) : (((reinterpret_cast<uintptr_t>(C) & 15) == 0) && (ldc % 4 == 0));
+    g.k_per_split = K;
+    g.slab_stride = 0;
+    g.tiles_m = (M + BM - 1) / BM;
+    g.tiles_n = (N + BN - 1) / BN;
+    g.e.bias = bias; g.e.gate = gate; g.e.res1 = res1; g.e.res2 = res2; g.e.pre = pre; g.e.aux = aux;
+    g.e.act = act; g.e.dact = dact; g.e.ldr = ldr ? ldr : ldc; g.e.scale = scale;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    void* ph = egv_prof_begin(stream);
+#define EGV_DISPATCH(TT)                                                                   \
+    if (!a_trans && !b_trans) {                                                            \
+        if (out_f32) launch_gemm<TT, 0, 0, float>(g, 1, st); else launch_gemm<TT, 0, 0, TT>(g, 1, st); \
+    } else if (!a_trans && b_trans) {                                                      \
+        if (out_f32) launch_gemm<TT, 0, 1, float>(g, 1, st); else launch_gemm<TT, 0, 1, TT>(g, 1, st); \
+    } else {                                                                               \
+        if (out_f32) launch_gemm<TT, 1, 1, float>(g, 1, st); else launch_gemm<TT, 1, 1, TT>(g, 1, st); \
+    }
+    if (dtype == EGV_BF16) { EGV_DISPATCH(bf16_t) } else { EGV_DISPATCH(float) }
+#undef EGV_DISPATCH
+    egv_prof_end(ph, stream, 2.0 * M * N * K, (dtype == EGV_BF16 ? 0 : 4) + (b_trans ? 1 : 0));
+    EGV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" long long egv_gemm_wgrad_workspace_bytes(int N, int K, int M) {
+    // slabs of fp32 [N,K]; split count chosen by egv_gemm_wgrad
+    const int tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
+    int nz = 1;
+    while (tiles * nz < 512 && nz < 32 && M / (nz * 2) >= 512) nz *= 2;
+    return (long long)nz * N * K * 4;
+}
+
+// dW[N,K] (fp32) = scale * gate * dY[M,N]^T X[M,K], reduction over M split across blockIdx.z.
+extern "C" int egv_gemm_wgrad(int dtype, int M, int N, int K, const void* dY, int ldy, const void* X, int ldx,
+                              float* dW, float scale, const float* gate, void* workspace, long long workspace_bytes,
+                              void* stream) {
+    EGV_CHECK(dtype == EGV_F32 || dtype == EGV_BF16, "egv_gemm_wgrad: bad dtype %d", dtype);
+    EGV_CHECK(M > 0 && N > 0 && K > 0, "egv_gemm_wgrad: bad shape");
+    const int tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
+    int nz = 1;
+    while (tiles * nz < 512 && nz < 32 && M / (nz * 2) >= 512) nz *= 2;
+    const int bk = dtype == EGV_BF16 ? 64 : 32;
+    int kper = (M + nz - 1) / nz;
+    kper = ((kper + bk - 1) / bk) * bk;
+    nz = (M + kper - 1) / kper;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    GemmArgs g;
+    g.A = dY; g.B = X;
+    g.M = N; g.N = K; g.K = M;           // output rows = N (of dY), cols = K (of X), reduction = M
+    g.lda = ldy; g.ldb = ldx; g.ldc = K;
+    g.a_vec_ok = vec_ok(dY, ldy, dtype);
+    g.b_vec_ok = vec_ok(X, ldx, dtype);
+    g.k_per_split = kper;
+    g.tiles_m = (N + BM - 1) / BM;
+    g.tiles_n = (K + BN - 1) / BN;
+    g.e = GemmEpi{};
+    g.e.ldr = K;
+    if (nz == 1) {
+        g.C = dW; g.slab_stride = 0;
+        g.c_vec_ok = vec_ok(dW, K, EGV_F32);
+        g.e.scale = scale; g.e.gate = gate;
+    } else {
+        EGV_CHECK(workspace && workspace_bytes >= (long long)nz * N * K * 4, "egv_gemm_wgrad: workspace too small");
+        g.C = workspace; g.slab_stride = (long long)N * K;
+        g.c_vec_ok = vec_ok(workspace, K, EGV_F32) && (((long long)N * K) % 4 == 0);
+        g.e.scale = 1.0f;
+    }
+    void* ph = egv_prof_begin(stream);
+    if (dtype == EGV_BF16) launch_gemm<bf16_t, 1, 1, float>(g, nz, st);
+    else launch_gemm<float, 1, 1, float>(g, nz, st);
+    egv_prof_end(ph, stream, 2.0 * M * N * K, (dtype == EGV_BF16 ? 0 : 4) + 2);
+    EGV_LAUNCH_CHECK();
+    if (nz > 1) {
+        const long long n = (long long)N * K;
+        int blocks = (int)((n + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dW, n, nz,
+                           (long long)N * K, scale, gate);
+        EGV_LAUNCH_CHECK();
+    }
+    return 0;
+}

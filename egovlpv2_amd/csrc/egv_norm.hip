@@ -1,0 +1,338 @@
+// HBM-bound row kernels of the EgoVLPv2 hot path: LayerNorm fwd/bwd (SURVEY.md K2/K7/K8 prologues),
+// column sums (bias gradients), dot reductions (gate gradients), dtype casts.
+// One 64-lane wavefront per token row, 8-16 B vector accesses, fp32 statistics.
+#include "egv_common.h"
+
+namespace egv {
+
+constexpr int LN_MAXV = 4;   // up to 4 vectors of 4 elements per lane -> D <= 1024
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ stats, int M, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave_id();
+    if (row >= M) return;
+    const T* xr = x + (size_t)row * D;
+    float v[LN_MAXV][4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int c = (j * 64 + lane) * 4;
+        if (c < D) {
+            ld4(xr + c, v[j]);
+            s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+        } else {
+            v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int c = (j * 64 + lane) * 4;
+        if (c < D) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[j][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float var = wave_sum(q) / (float)D;
+    const float rstd = rsqrtf(var + eps);
+    if (stats && lane == 0) {
+        stats[2 * (size_t)row] = mean;
+        stats[2 * (size_t)row + 1] = rstd;
+    }
+    T* yr = y + (size_t)row * D;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int c = (j * 64 + lane) * 4;
+        if (c < D) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * gamma[c + e] + beta[c + e];
+            st4(yr + c, o);
+        }
+    }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  partial dgamma/dbeta per workgroup.
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                            const T* __restrict__ add, T* __restrict__ dx,
+                                                            float* __restrict__ partial, int M, int D, int rows_per_block) {
+    __shared__ float red[4][2][LN_MAXV * 256];
+    const int lane = threadIdx.x & 63;
+    const int w = wave_id();
+    float dg[LN_MAXV][4], db[LN_MAXV][4], gm[LN_MAXV][4];
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int c = (j * 64 + lane) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dg[j][e] = 0.f;
+            db[j][e] = 0.f;
+            gm[j][e] = (c < D) ? gamma[c + e] : 0.f;
+        }
+    }
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    for (int row = r0 + w; row < r1; row += 4) {
+        const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
+        float xh[LN_MAXV][4], g[LN_MAXV][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const int c = (j * 64 + lane) * 4;
+            if (c < D) {
+                float xv[4], dv[4];
+                ld4(x + (size_t)row * D + c, xv);
+                ld4(dy + (size_t)row * D + c, dv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[j][e] = (xv[e] - mean) * rstd;
+                    g[j][e] = dv[e] * gm[j][e];
+                    s1 += g[j][e];
+                    s2 += g[j][e] * xh[j][e];
+                    dg[j][e] += dv[e] * xh[j][e];
+                    db[j][e] += dv[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xh[j][e] = g[j][e] = 0.f;
+            }
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const int c = (j * 64 + lane) * 4;
+            if (c < D) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rstd * (g[j][e] - s1 - xh[j][e] * s2);
+                if (add) {
+                    float a[4];
+                    ld4(add + (size_t)row * D + c, a);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += a[e];
+                }
+                st4(dx + (size_t)row * D + c, o);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[w][0][(j * 64 + lane) * 4 + e] = dg[j][e];
+            red[w][1][(j * 64 + lane) * 4 + e] = db[j][e];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            a += red[ww][0][c];
+            b += red[ww][1][c];
+        }
+        partial[(size_t)blockIdx.x * 2 * D + c] = a;
+        partial[(size_t)blockIdx.x * 2 * D + D + c] = b;
+    }
+}
+
+// out[c] = scale * gate * sum_p partial[p][c]   (deterministic order)
+__global__ void colsum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int P, int ncol,
+                                       int stride, float scale, const float* gate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncol) return;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += partial[(size_t)p * stride + c];
+    out[c] = s * scale * (gate ? *gate : 1.0f);
+}
+
+// partial column sums of X[M,N]: grid (ceil(N/256), chunks); each lane owns 4 columns, waves split rows.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, float* __restrict__ partial, int M, int N, int ld,
+                                                     int rows_per_block) {
+    __shared__ float red[4][256];
+    const int lane = threadIdx.x & 63, w = wave_id();
+    const int c = blockIdx.x * 256 + lane * 4;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool vec = ((ld & 3) == 0) && (c + 3 < N);
+    for (int r = r0 + w; r < r1; r += 4) {
+        if (vec) {
+            float v[4];
+            ld4(X + (size_t)r * ld + c, v);
+            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < N) s[e] += Elem<T>::ld(X + (size_t)r * ld + c + e);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[w][lane * 4 + e] = s[e];
+    __syncthreads();
+    const int cc = blockIdx.x * 256 + threadIdx.x;
+    if (cc < N) partial[(size_t)blockIdx.y * N + cc] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dot_partial_kernel(const T* __restrict__ a, const T* __restrict__ b, float* __restrict__ partial,
+                                                          long long n) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const long long nv = n / 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
+        float x[4], y[4];
+        ld4(a + i * 4, x);
+        ld4(b + i * 4, y);
+        s += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long long i = nv * 4 + threadIdx.x;
+        s += Elem<T>::ld(a + i) * Elem<T>::ld(b + i);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[wave_id()] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void sum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int P, float scale) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < P; i += 256) s += partial[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[wave_id()] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (red[0] + red[1] + red[2] + red[3]) * scale;
+}
+
+template <typename S, typename D>
+__global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, long long n) {
+    const long long nv = n / 4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+        float v[4];
+        ld4(src + i * 4, v);
+        st4(dst + i * 4, v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long long i = nv * 4 + threadIdx.x;
+        Elem<D>::st(dst + i, Elem<S>::ld(src + i));
+    }
+}
+
+}  // namespace egv
+using namespace egv;
+
+extern "C" int egv_layernorm_fwd(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* stats,
+                                 int M, int D, float eps, void* stream) {
+    EGV_CHECK(D % 4 == 0 && D <= LN_MAXV * 256, "egv_layernorm_fwd: D=%d unsupported", D);
+    EGV_CHECK(M > 0, "egv_layernorm_fwd: M=%d", M);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((M + 3) / 4);
+    if (dtype == EGV_BF16)
+        hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, gamma, beta, stats, M, D, eps);
+    else
+        hipLaunchKernelGGL(layernorm_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (float*)y, gamma, beta, stats, M, D, eps);
+    EGV_LAUNCH_CHECK();
+    return 0;
+}
+
+static inline int ln_bwd_blocks(int M) {
+    int nb = (M + 3) / 4;
+    return nb > 1024 ? 1024 : nb;
+}
+
+extern "C" long long egv_layernorm_bwd_workspace_bytes(int M, int D) { return (long long)ln_bwd_blocks(M) * 2 * D * 4; }
+
+extern "C" int egv_layernorm_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma,
+                                 const void* add, void* dx, float* dgamma, float* dbeta, int M, int D, void* workspace,
+                                 void* stream) {
+    EGV_CHECK(D % 4 == 0 && D <= LN_MAXV * 256, "egv_layernorm_bwd: D=%d unsupported", D);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int nb = ln_bwd_blocks(M);
+    const int rpb = (M + nb - 1) / nb;
+    const int nb2 = (M + rpb - 1) / rpb;
+    float* partial = (float*)workspace;
+    if (dtype == EGV_BF16)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(nb2), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, stats, gamma,
+                           (const bf16_t*)add, (bf16_t*)dx, partial, M, D, rpb);
+    else
+        hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(nb2), dim3(256), 0, st, (const float*)dy, (const float*)x, stats, gamma,
+                           (const float*)add, (float*)dx, partial, M, D, rpb);
+    EGV_LAUNCH_CHECK();
+    // partial layout [nb2][2][D]: columns 0..D-1 = dgamma, D..2D-1 = dbeta
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 255) / 256), dim3(256), 0, st, (const float*)partial, dgamma, nb2, D,
+                       2 * D, 1.0f, (const float*)nullptr);
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 255) / 256), dim3(256), 0, st, (const float*)partial + D, dbeta, nb2, D,
+                       2 * D, 1.0f, (const float*)nullptr);
+    EGV_LAUNCH_CHECK();
+    return 0;
+}
+
+static inline int colsum_chunks(int M) {
+    int c = (M + 255) / 256;
+    return c > 128 ? 128 : (c < 1 ? 1 : c);
+}
+extern "C" long long egv_colsum_workspace_bytes(int M, int N) { return (long long)colsum_chunks(M) * N * 4; }
+
+// out[n] (fp32) = scale * gate * sum_m X[m,n]
+extern "C" int egv_colsum(int dtype, const void* X, int M, int N, int ld, float* out, float scale, const float* gate,
+                          void* workspace, void* stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int ch = colsum_chunks(M);
+    const int rpb = (M + ch - 1) / ch;
+    const int ch2 = (M + rpb - 1) / rpb;
+    dim3 grid((N + 255) / 256, ch2);
+    if (dtype == EGV_BF16)
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)X, (float*)workspace, M, N, ld, rpb);
+    else
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)X, (float*)workspace, M, N, ld, rpb);
+    EGV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, st, (const float*)workspace, out, ch2, N, N, scale, gate);
+    EGV_LAUNCH_CHECK();
+    return 0;
+}
+
+// out[0] (fp32) = scale * sum_i a[i] * b[i];  workspace >= 1024 floats
+extern "C" int egv_dot(int dtype, const void* a, const void* b, long long n, float* out, float scale, void* workspace,
+                       void* stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    long long nb = (n / 4 + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    if (dtype == EGV_BF16)
+        hipLaunchKernelGGL(dot_partial_kernel<bf16_t>, dim3((int)nb), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (float*)workspace, n);
+    else
+        hipLaunchKernelGGL(dot_partial_kernel<float>, dim3((int)nb), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)workspace, n);
+    EGV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, out, (int)nb, scale);
+    EGV_LAUNCH_CHECK();
+    return 0;
+}
+
+// dst (dtype_dst) = cast(src (dtype_src)); pointers 16-byte aligned
+extern "C" int egv_cast(int dtype_src, int dtype_dst, const void* src, void* dst, long long n, void* stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    long long nb = (n / 4 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    if (dtype_src == EGV_F32 && dtype_dst == EGV_BF16)
+        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3((int)nb), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, n);
+    else if (dtype_src == EGV_BF16 && dtype_dst == EGV_F32)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3((int)nb), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, n);
+    else if (dtype_src == EGV_F32 && dtype_dst == EGV_F32)
+        hipLaunchKernelGGL((cast_kernel<float, float>), dim3((int)nb), dim3(256), 0, st, (const float*)src, (float*)dst, n);
+    else
+        hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3((int)nb), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
+    EGV_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,678 @@
+"""torch.autograd plumbing over the HIP C ABI (include/egovlp_hip.h).
+
+PyTorch is used here for device memory, streams and the autograd graph only: every forward and
+backward computation below is a call into ``libegovlp_hip.so``.  There is no CPU or ATen fallback;
+tensors must live on a ROCm device.
+
+Activations are stored in the model's compute dtype (torch.float32 -> EGV_F32, torch.bfloat16 ->
+EGV_BF16); parameters and their gradients are fp32.  In bf16 mode weights are cast once per parameter
+version (``compute_weight``) -- the cast kernel is part of the timed step.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+from ._lib import lib, check, AttnDesc
+
+ACT = {'none': L.ACT_NONE, 'gelu': L.ACT_GELU, 'relu': L.ACT_RELU, 'tanh': L.ACT_TANH}
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return L.EGV_BF16
+    if t.dtype == torch.float32:
+        return L.EGV_F32
+    raise TypeError(f"unsupported activation dtype {t.dtype}")
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("egovlpv2_amd: the hot path runs only on a ROCm device through libegovlp_hip.so "
+                           "(no CPU fallback); got a CPU tensor")
+
+
+# ---- scratch space (stream-ordered reuse on the current stream) ---------------------------------------
+_ws = {}
+
+
+def workspace(nbytes: int, device, slot: int = 0) -> torch.Tensor:
+    key = (device, slot)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+# ---- compute-dtype copies of fp32 master weights -------------------------------------------------------
+_wcache = {}
+
+
+def compute_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """fp32 parameter -> tensor in the compute dtype (cached per parameter version)."""
+    if dtype == torch.float32:
+        return w
+    key = id(w)
+    ent = _wcache.get(key)
+    if ent is not None and ent[0] == w._version and ent[1].device == w.device and ent[2] is w:
+        return ent[1]
+    out = torch.empty(w.shape, dtype=dtype, device=w.device)
+    src = w.detach()
+    if not src.is_contiguous():
+        src = src.contiguous()
+    check(lib.egv_cast(L.EGV_F32, _dt(out), _p(src), _p(out), src.numel(), _st()), 'egv_cast')
+    _wcache[key] = (w._version, out, w)
+    return out
+
+
+def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    if x.dtype == dtype:
+        return x
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    check(lib.egv_cast(_dt(x), _dt(out), _p(x), _p(out), x.numel(), _st()), 'egv_cast')
+    return out
+
+
+class CastFn(Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return cast(x, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return cast(g, ctx.src), None
+
+
+# ---- raw launch helpers ------------------------------------------------------------------------------
+def gemm(x, w, out, *, a_trans=0, b_trans=0, M, N, K, lda, ldb, ldc, bias=None, act=0, gate=None, res1=None,
+         res2=None, pre=None, aux=None, dact=0, scale=1.0, out_f32=0):
+    check(lib.egv_gemm(_dt(x), a_trans, b_trans, M, N, K, _p(x), lda, _p(w), ldb, _p(out), ldc, out_f32, _p(bias), act,
+                       _p(gate), _p(res1), _p(res2), _p(pre), _p(aux), dact, ldc, float(scale), _st()), 'egv_gemm')
+
+
+def wgrad(dy, x, M, N, K, gate=None, scale=1.0, ldy=None):
+    """dW[N,K] fp32 = scale*gate * dy[M,N]^T x[M,K]"""
+    dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+    nb = lib.egv_gemm_wgrad_workspace_bytes(N, K, M)
+    ws = workspace(nb, dy.device)
+    check(lib.egv_gemm_wgrad(_dt(dy), M, N, K, _p(dy), N if ldy is None else ldy, _p(x), K, _p(dw), float(scale), _p(gate),
+                             _p(ws), nb, _st()), 'egv_gemm_wgrad')
+    return dw
+
+
+def colsum(dy, M, N, gate=None, scale=1.0, ld=None):
+    out = torch.empty(N, dtype=torch.float32, device=dy.device)
+    ws = workspace(lib.egv_colsum_workspace_bytes(M, N), dy.device)
+    check(lib.egv_colsum(_dt(dy), _p(dy), M, N, N if ld is None else ld, _p(out), float(scale), _p(gate), _p(ws), _st()),
+          'egv_colsum')
+    return out
+
+
+def dot(a, b):
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    ws = workspace(4096, a.device)
+    check(lib.egv_dot(_dt(a), _p(a), _p(b), a.numel(), _p(out), 1.0, _p(ws), _st()), 'egv_dot')
+    return out
+
+
+# ---- Linear (+bias, activation, gate, residuals) --------------------------------------------------------
+class LinearFn(Function):
+    """y = gate * act(x W^T + b) + res1 + res2   (gate requires act == none; its pre-gate value is saved)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gate, res1, res2, act):
+        _need_gpu(x)
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M, K = x2.shape
+        N = weight.shape[0]
+        w = compute_weight(weight, x.dtype)
+        y = torch.empty(M, N, dtype=x.dtype, device=x.device)
+        pre = torch.empty_like(y) if (gate is not None or act == L.ACT_GELU) else None
+        assert not (gate is not None and act != L.ACT_NONE), "gate requires act == none"
+        r1 = res1.reshape(M, N).contiguous() if res1 is not None else None
+        r2 = res2.reshape(M, N).contiguous() if res2 is not None else None
+        gemm(x2, w, y, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, act=act, gate=gate, res1=r1, res2=r2, pre=pre)
+        ctx.act = act
+        ctx.dims = (M, N, K)
+        ctx.xshape = shp
+        ctx.has = (bias is not None, gate is not None, res1 is not None, res2 is not None)
+        ctx.save_for_backward(x2, weight, gate, pre, y if act in (L.ACT_RELU, L.ACT_TANH) else None)
+        return y.reshape(*shp[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, gate, pre, yact = ctx.saved_tensors
+        M, N, K = ctx.dims
+        has_b, has_g, has_r1, has_r2 = ctx.has
+        dy2 = dy.reshape(M, N)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dz = dy2
+        if ctx.act in (L.ACT_RELU, L.ACT_TANH):
+            dz = torch.empty_like(dy2)
+            check(lib.egv_act_bwd(_dt(dy2), _p(dy2), _p(yact), _p(dz), dy2.numel(), ctx.act, _st()), 'egv_act_bwd')
+        elif ctx.act == L.ACT_GELU:
+            dz = torch.empty_like(dy2)
+            check(lib.egv_act_bwd(_dt(dy2), _p(dy2), _p(pre), _p(dz), dy2.numel(), L.ACT_GELU, _st()), 'egv_act_bwd')
+        dx = dw = db = dg = None
+        w = compute_weight(weight, dy2.dtype)
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, dtype=dy2.dtype, device=dy2.device)
+            gemm(dz, w, dx, a_trans=0, b_trans=1, M=M, N=K, K=N, lda=N, ldb=K, ldc=K, gate=gate)
+            dx = dx.reshape(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dw = wgrad(dz, x2, M, N, K, gate=gate)
+        if has_b and ctx.needs_input_grad[2]:
+            db = colsum(dz, M, N, gate=gate)
+        if has_g and ctx.needs_input_grad[3]:
+            dg = dot(dy2, pre)
+        dr1 = dy if has_r1 and ctx.needs_input_grad[4] else None
+        dr2 = dy if has_r2 and ctx.needs_input_grad[5] else None
+        return dx, dw, db, dg, dr1, dr2, None
+
+
+def linear(x, weight, bias=None, act='none', gate=None, res1=None, res2=None):
+    return LinearFn.apply(x, weight, bias, gate, res1, res2, ACT[act])
+
+
+class MlpFn(Function):
+    """y = res + W2 gelu(W1 x + b1) + b2  -- Mlp / intermediate+output of video_transformer.py:42-58, roberta.py:397-426.
+    GELU' is fused into the fc2 dgrad epilogue; pre-activation and activation are saved."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, res):
+        _need_gpu(x)
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M, K = x2.shape
+        Hd = w1.shape[0]
+        N = w2.shape[0]
+        c1, c2 = compute_weight(w1, x.dtype), compute_weight(w2, x.dtype)
+        pre = torch.empty(M, Hd, dtype=x.dtype, device=x.device)
+        h = torch.empty_like(pre)
+        gemm(x2, c1, h, M=M, N=Hd, K=K, lda=K, ldb=K, ldc=Hd, bias=b1, act=L.ACT_GELU, pre=pre)
+        y = torch.empty(M, N, dtype=x.dtype, device=x.device)
+        r = res.reshape(M, N).contiguous() if res is not None else None
+        gemm(h, c2, y, M=M, N=N, K=Hd, lda=Hd, ldb=Hd, ldc=N, bias=b2, res1=r)
+        ctx.dims = (M, K, Hd, N)
+        ctx.xshape = shp
+        ctx.has_res = res is not None
+        ctx.save_for_backward(x2, w1, w2, pre, h)
+        return y.reshape(*shp[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w2, pre, h = ctx.saved_tensors
+        M, K, Hd, N = ctx.dims
+        dy2 = dy.reshape(M, N)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        c1, c2 = compute_weight(w1, dy2.dtype), compute_weight(w2, dy2.dtype)
+        dpre = torch.empty(M, Hd, dtype=dy2.dtype, device=dy2.device)
+        gemm(dy2, c2, dpre, a_trans=0, b_trans=1, M=M, N=Hd, K=N, lda=N, ldb=Hd, ldc=Hd, aux=pre, dact=L.ACT_GELU)
+        dw2 = wgrad(dy2, h, M, N, Hd)
+        db2 = colsum(dy2, M, N)
+        dw1 = wgrad(dpre, x2, M, Hd, K)
+        db1 = colsum(dpre, M, Hd)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, dtype=dy2.dtype, device=dy2.device)
+            gemm(dpre, c1, dx, a_trans=0, b_trans=1, M=M, N=K, K=Hd, lda=Hd, ldb=K, ldc=K)
+            dx = dx.reshape(ctx.xshape)
+        return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None)
+
+
+def mlp(x, w1, b1, w2, b2, res=None):
+    return MlpFn.apply(x, w1, b1, w2, b2, res)
+
+
+class VocabLinearFn(Function):
+    """MLM decoder (heads.py:44-50): logits = x W^T + bias with the vocabulary axis padded to a multiple of 128
+    columns (row pitch stays 16-byte aligned; columns >= V are never read and get zero gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, V):
+        _need_gpu(x)
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        M, K = x2.shape
+        Vp = (V + 127) // 128 * 128
+        w = compute_weight(weight, x.dtype)
+        y = torch.empty(M, Vp, dtype=x.dtype, device=x.device)
+        gemm(x2, w, y, M=M, N=V, K=K, lda=K, ldb=K, ldc=Vp, bias=bias)
+        ctx.dims = (M, K, V, Vp)
+        ctx.xshape = x.shape
+        ctx.save_for_backward(x2, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        M, K, V, Vp = ctx.dims
+        dy = dy.contiguous()
+        w = compute_weight(weight, dy.dtype)
+        dx = torch.empty(M, K, dtype=dy.dtype, device=dy.device)
+        gemm(dy, w, dx, a_trans=0, b_trans=1, M=M, N=K, K=V, lda=Vp, ldb=K, ldc=K)
+        dw = wgrad(dy, x2, M, V, K, ldy=Vp)
+        db = colsum(dy, M, V, ld=Vp)
+        return dx.reshape(ctx.xshape), dw, db, None
+
+
+def vocab_linear(x, weight, bias, V):
+    return VocabLinearFn.apply(x, weight, bias, V)
+
+
+# ---- LayerNorm ---------------------------------------------------------------------------------------
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _need_gpu(x)
+        shp = x.shape
+        D = shp[-1]
+        x2 = x.reshape(-1, D)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M = x2.shape[0]
+        y = torch.empty_like(x2)
+        stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+        check(lib.egv_layernorm_fwd(_dt(x2), _p(x2), _p(y), _p(gamma), _p(beta), _p(stats), M, D, float(eps), _st()),
+              'egv_layernorm_fwd')
+        ctx.save_for_backward(x2, gamma, stats)
+        ctx.xshape = shp
+        return y.reshape(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, gamma, stats = ctx.saved_tensors
+        M, D = x2.shape
+        dy2 = dy.reshape(M, D)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dx = torch.empty_like(x2)
+        dg = torch.empty(D, dtype=torch.float32, device=x2.device)
+        db = torch.empty(D, dtype=torch.float32, device=x2.device)
+        ws = workspace(lib.egv_layernorm_bwd_workspace_bytes(M, D), x2.device)
+        check(lib.egv_layernorm_bwd(_dt(x2), _p(dy2), _p(x2), _p(stats), _p(gamma), None, _p(dx), _p(dg), _p(db), M, D,
+                                    _p(ws), _st()), 'egv_layernorm_bwd')
+        return dx.reshape(ctx.xshape), dg, db, None
+
+
+def layernorm(x, gamma, beta, eps):
+    return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+# ---- attention ---------------------------------------------------------------------------------------
+def _rowset(bs, base, gs, istride, n):
+    return (int(bs), int(base), int(gs), int(istride), int(n))
+
+
+def _mk_desc(Q, K, V, O, lse, B, G, H, qset, kset, extra, scale, mask=None, dO=None, dQ=None, dK=None, dV=None, delta=None,
+             nsplit=1, ws=None, ws_bytes=0):
+    d = AttnDesc()
+    d.Q, d.K, d.V, d.O = _p(Q), _p(K), _p(V), _p(O)
+    d.dO, d.dQ, d.dK, d.dV = _p(dO), _p(dQ), _p(dK), _p(dV)
+    d.ldq, d.ldk, d.ldv, d.ldo = Q.stride(0), K.stride(0), V.stride(0), O.stride(0)
+    d.lddq = dQ.stride(0) if dQ is not None else 0
+    d.lddk = dK.stride(0) if dK is not None else 0
+    d.lddv = dV.stride(0) if dV is not None else 0
+    d.qoff = d.koff = d.voff = d.ooff = d.dqoff = d.dkoff = d.dvoff = 0
+    d.lse, d.delta = _p(lse), _p(delta)
+    d.B, d.G, d.H = B, G, H
+    d.q_bs, d.q_base, d.q_gs, d.q_is, d.q_n = qset
+    d.k_bs, d.k_base, d.k_gs, d.k_is, d.k_n = kset
+    if extra is None:
+        d.extra, d.extra_bs, d.extra_row = 0, 0, 0
+    else:
+        d.extra, d.extra_bs, d.extra_row = 1, int(extra[0]), int(extra[1])
+    d.scale = float(scale)
+    d.mask = _p(mask)
+    d.mask_ld = mask.stride(0) if mask is not None else 0
+    d.nsplit = nsplit
+    d.ws = _p(ws)
+    d.ws_bytes = ws_bytes
+    return d
+
+
+def _dkv_ws(B, G, H, k_n, nsplit, device):
+    nb = lib.egv_attn_bwd_dkv_workspace_bytes(B, G, H, k_n, nsplit)
+    return (workspace(nb, device, slot=1), nb) if nb else (None, 0)
+
+
+class DividedAttnFn(Function):
+    """Divided space / time attention core of VarAttention (video_transformer.py:121-150) on the fused qkv buffer
+    [B*S, 3*D]: CLS query over all S keys, patch queries over [CLS ; own frame | own patch column]."""
+
+    @staticmethod
+    def forward(ctx, qkv, B, Fr, N, H, mode):
+        _need_gpu(qkv)
+        S = 1 + Fr * N
+        D = H * 64
+        M = B * S
+        assert qkv.shape == (M, 3 * D) and qkv.is_contiguous()
+        Q, K, V = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        O = torch.empty(M, D, dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty(M, H, dtype=torch.float32, device=qkv.device)
+        scale = 64 ** -0.5
+        if mode == 'space':
+            G, gset = Fr, _rowset(S, 1, N, 1, N)
+        else:
+            G, gset = N, _rowset(S, 1, 1, N, Fr)
+        dt = _dt(qkv)
+        d1 = _mk_desc(Q, K, V, O, lse, B, G, H, gset, gset, (S, 0), scale)
+        check(lib.egv_attn_fwd(dt, C.byref(d1), _st()), 'egv_attn_fwd(groups)')
+        d2 = _mk_desc(Q, K, V, O, lse, B, 1, H, _rowset(S, 0, 0, 1, 1), _rowset(S, 0, 0, 1, S), None, scale)
+        check(lib.egv_attn_fwd(dt, C.byref(d2), _st()), 'egv_attn_fwd(cls)')
+        ctx.cfg = (B, Fr, N, H, mode)
+        ctx.save_for_backward(qkv, O, lse)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        qkv, O, lse = ctx.saved_tensors
+        B, Fr, N, H, mode = ctx.cfg
+        S = 1 + Fr * N
+        D = H * 64
+        M = B * S
+        dO = dO.contiguous()
+        Q, K, V = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        dqkv = torch.empty_like(qkv)
+        dQ, dK, dV = dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:]
+        delta = torch.empty(M, H, dtype=torch.float32, device=qkv.device)
+        scale = 64 ** -0.5
+        if mode == 'space':
+            G, gset = Fr, _rowset(S, 1, N, 1, N)
+        else:
+            G, gset = N, _rowset(S, 1, 1, N, Fr)
+        cls1, allS = _rowset(S, 0, 0, 1, 1), _rowset(S, 0, 0, 1, S)
+        dt = _dt(qkv)
+        kw = dict(dO=dO, dQ=dQ, dK=dK, dV=dV, delta=delta)
+        d1 = _mk_desc(Q, K, V, O, lse, B, G, H, gset, gset, (S, 0), scale, **kw)
+        check(lib.egv_attn_bwd_dq(dt, C.byref(d1), _st()), 'egv_attn_bwd_dq(groups)')
+        d2 = _mk_desc(Q, K, V, O, lse, B, 1, H, cls1, allS, None, scale, **kw)
+        check(lib.egv_attn_bwd_dq(dt, C.byref(d2), _st()), 'egv_attn_bwd_dq(cls)')
+        # key-owned: group keys <- [CLS query ; group queries];  CLS key <- all S queries (split + reduce)
+        d3 = _mk_desc(Q, K, V, O, lse, B, G, H, gset, gset, (S, 0), scale, **kw)
+        check(lib.egv_attn_bwd_dkv(dt, C.byref(d3), _st()), 'egv_attn_bwd_dkv(groups)')
+        nsplit = max(1, min(32, S // 64))
+        ws, nb = _dkv_ws(B, 1, H, 1, nsplit, qkv.device)
+        d4 = _mk_desc(Q, K, V, O, lse, B, 1, H, allS, cls1, None, scale, nsplit=nsplit, ws=ws, ws_bytes=nb, **kw)
+        check(lib.egv_attn_bwd_dkv(dt, C.byref(d4), _st()), 'egv_attn_bwd_dkv(cls)')
+        return dqkv, None, None, None, None, None
+
+
+def divided_attention(qkv, B, Fr, N, H, mode):
+    return DividedAttnFn.apply(qkv, B, Fr, N, H, mode)
+
+
+class PlainAttnFn(Function):
+    """softmax(scale * q k^T + mask) v per (batch, head): RoBERTa self attention (roberta.py:257-327), text->image
+    cross attention (same class, keys = video tokens, no mask) and image->text cross attention
+    (video_transformer.py:159-182).  q [B*nq, D], k/v [B*nk, D] may be column slices (stride(1) == 1)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, B, H, nq, nk, scale, mask, dkv_nsplit):
+        _need_gpu(q)
+        D = H * 64
+        for t in (q, k, v):
+            assert t.dim() == 2 and t.stride(1) == 1 and t.shape[1] == D
+        O = torch.empty(B * nq, D, dtype=q.dtype, device=q.device)
+        lse = torch.empty(B * nq, H, dtype=torch.float32, device=q.device)
+        d = _mk_desc(q, k, v, O, lse, B, 1, H, _rowset(nq, 0, 0, 1, nq), _rowset(nk, 0, 0, 1, nk), None, scale, mask=mask)
+        check(lib.egv_attn_fwd(_dt(q), C.byref(d), _st()), 'egv_attn_fwd')
+        ctx.cfg = (B, H, nq, nk, scale, dkv_nsplit)
+        ctx.save_for_backward(q, k, v, O, lse, mask)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        q, k, v, O, lse, mask = ctx.saved_tensors
+        B, H, nq, nk, scale, nsplit = ctx.cfg
+        D = H * 64
+        dO = dO.contiguous()
+        dq = torch.empty(B * nq, D, dtype=q.dtype, device=q.device)
+        dk = torch.empty(B * nk, D, dtype=q.dtype, device=q.device)
+        dv = torch.empty(B * nk, D, dtype=q.dtype, device=q.device)
+        delta = torch.empty(B * nq, H, dtype=torch.float32, device=q.device)
+        qs, ks = _rowset(nq, 0, 0, 1, nq), _rowset(nk, 0, 0, 1, nk)
+        ws, nb = _dkv_ws(B, 1, H, nk, nsplit, q.device)
+        d = _mk_desc(q, k, v, O, lse, B, 1, H, qs, ks, None, scale, mask=mask, dO=dO, dQ=dq, dK=dk, dV=dv, delta=delta,
+                     nsplit=nsplit, ws=ws, ws_bytes=nb)
+        check(lib.egv_attn_bwd_dq(_dt(q), C.byref(d), _st()), 'egv_attn_bwd_dq')
+        check(lib.egv_attn_bwd_dkv(_dt(q), C.byref(d), _st()), 'egv_attn_bwd_dkv')
+        return dq, dk, dv, None, None, None, None, None, None, None
+
+
+def plain_attention(q, k, v, B, H, nq, nk, scale, mask=None, dkv_nsplit=1):
+    return PlainAttnFn.apply(q, k, v, B, H, nq, nk, scale, mask, dkv_nsplit)
+
+
+# ---- patch embedding + CLS + positional / temporal embedding ------------------------------------------------
+class PatchTokensFn(Function):
+    """video (B,F,3,H,W) fp32 -> tokens (B, 1+F*N, D): Conv2d(k=s=P) as im2col + MFMA GEMM (+bias), then CLS concat
+    and pos/temporal embedding (video_transformer.py:78-83,356-371)."""
+
+    @staticmethod
+    def forward(ctx, video, conv_w, conv_b, cls, pos, temporal, dtype):
+        _need_gpu(video)
+        B, Fr, Cc, Hh, Ww = video.shape
+        D = conv_w.shape[0]
+        P = conv_w.shape[-1]
+        N = (Hh // P) * (Ww // P)
+        Kp = Cc * P * P
+        video = video.contiguous().float()
+        dt = L.EGV_BF16 if dtype == torch.bfloat16 else L.EGV_F32
+        patches = torch.empty(B * Fr * N, Kp, dtype=dtype, device=video.device)
+        check(lib.egv_im2col(dt, _p(video), _p(patches), B * Fr, Cc, Hh, Ww, P, _st()), 'egv_im2col')
+        w = compute_weight(conv_w, dtype).reshape(D, Kp)
+        emb = torch.empty(B * Fr * N, D, dtype=dtype, device=video.device)
+        gemm(patches, w, emb, M=B * Fr * N, N=D, K=Kp, lda=Kp, ldb=Kp, ldc=D, bias=conv_b)
+        out = torch.empty(B, 1 + Fr * N, D, dtype=dtype, device=video.device)
+        check(lib.egv_assemble_tokens(dt, _p(emb), _p(cls), _p(pos), _p(temporal), _p(out), B, Fr, N, D, _st()),
+              'egv_assemble_tokens')
+        ctx.cfg = (B, Fr, N, D, Kp, dt)
+        ctx.shapes = (conv_w.shape, cls.shape, pos.shape, temporal.shape)
+        ctx.save_for_backward(patches)
+        return out
+
+    @staticmethod
+    def backward(ctx, dX):
+        (patches,) = ctx.saved_tensors
+        B, Fr, N, D, Kp, dt = ctx.cfg
+        wshape, cshape, pshape, tshape = ctx.shapes
+        dX = dX.contiguous()
+        dev = dX.device
+        dpatch = torch.empty(B * Fr * N, D, dtype=dX.dtype, device=dev)
+        dcls = torch.empty(D, dtype=torch.float32, device=dev)
+        dpos = torch.empty(1 + N, D, dtype=torch.float32, device=dev)
+        dtem = torch.empty(Fr, D, dtype=torch.float32, device=dev)
+        ws = workspace(lib.egv_assemble_tokens_bwd_workspace_bytes(Fr, N, D), dev, slot=1)
+        check(lib.egv_assemble_tokens_bwd(dt, _p(dX), _p(dpatch), _p(dcls), _p(dpos), _p(dtem), B, Fr, N, D, _p(ws), _st()),
+              'egv_assemble_tokens_bwd')
+        M = B * Fr * N
+        dw = wgrad(dpatch, patches, M, D, Kp).reshape(wshape)
+        db = colsum(dpatch, M, D)
+        return None, dw, db, dcls.reshape(cshape), dpos.reshape(pshape), dtem.reshape(tshape), None
+
+
+def patch_tokens(video, conv_w, conv_b, cls, pos, temporal, dtype):
+    return PatchTokensFn.apply(video, conv_w, conv_b, cls, pos, temporal, dtype)
+
+
+# ---- RoBERTa embeddings --------------------------------------------------------------------------------
+class TextEmbedFn(Function):
+    @staticmethod
+    def forward(ctx, ids, word, pos, typ, pad_id, dtype):
+        _need_gpu(ids)
+        B, Lt = ids.shape
+        D = word.shape[1]
+        ids = ids.contiguous()
+        out = torch.empty(B * Lt, D, dtype=dtype, device=ids.device)
+        dt = L.EGV_BF16 if dtype == torch.bfloat16 else L.EGV_F32
+        check(lib.egv_text_embed_fwd(dt, _p(ids), _p(word), _p(pos), _p(typ), _p(out), B, Lt, D, pad_id, _st()),
+              'egv_text_embed_fwd')
+        ctx.cfg = (B, Lt, D, pad_id, dt, word.shape, pos.shape, typ.shape)
+        ctx.save_for_backward(ids)
+        return out
+
+    @staticmethod
+    def backward(ctx, de):
+        (ids,) = ctx.saved_tensors
+        B, Lt, D, pad_id, dt, wshape, pshape, tshape = ctx.cfg
+        de = de.contiguous()
+        dword = torch.zeros(wshape, dtype=torch.float32, device=de.device)
+        dpos = torch.zeros(pshape, dtype=torch.float32, device=de.device)
+        check(lib.egv_text_embed_bwd(dt, _p(ids), _p(de), _p(dword), _p(dpos), B, Lt, D, pad_id, _st()), 'egv_text_embed_bwd')
+        dtyp = colsum(de, B * Lt, D).reshape(tshape)
+        return None, dword, dpos, dtyp, None, None
+
+
+def text_embed(ids, word, pos, typ, pad_id, dtype):
+    return TextEmbedFn.apply(ids, word, pos, typ, pad_id, dtype)
+
+
+# ---- losses ------------------------------------------------------------------------------------------------
+class CrossEntropySumFn(Function):
+    """sum over rows of CE(logits[r, :V], labels[r]) with ignore_index; logits may be column-padded (ld > V)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, V, ignore_index):
+        _need_gpu(logits)
+        R, ld = logits.shape
+        assert logits.is_contiguous()
+        labels = labels.contiguous()
+        lse = torch.empty(R, dtype=torch.float32, device=logits.device)
+        row = torch.empty(R, dtype=torch.float32, device=logits.device)
+        check(lib.egv_ce_fwd(_dt(logits), _p(logits), _p(labels), _p(lse), _p(row), R, V, ld, ignore_index, _st()), 'egv_ce_fwd')
+        ones = torch.ones(R, dtype=torch.float32, device=logits.device)
+        total = dot(row, ones).reshape(())
+        ctx.cfg = (R, V, ld, ignore_index)
+        ctx.save_for_backward(logits, labels, lse)
+        return total
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, lse = ctx.saved_tensors
+        R, V, ld, ignore_index = ctx.cfg
+        coef = g.reshape(1).float().contiguous()
+        dl = torch.empty_like(logits)
+        check(lib.egv_ce_bwd(_dt(logits), _p(logits), _p(labels), _p(lse), _p(coef), _p(dl), R, V, ld, ld, ignore_index, _st()),
+              'egv_ce_bwd')
+        return dl, None, None, None
+
+
+def cross_entropy_sum(logits, labels, V, ignore_index=-100):
+    return CrossEntropySumFn.apply(logits, labels, V, ignore_index)
+
+
+class SimMatrixFn(Function):
+    """sim_matrix (model.py:576-584) in fp32: a/max(|a|,eps) @ (b/max(|b|,eps))^T."""
+
+    @staticmethod
+    def forward(ctx, a, b, eps):
+        _need_gpu(a)
+        a = a.contiguous()
+        b = b.contiguous()
+        n, d = a.shape
+        m = b.shape[0]
+        an, bn = torch.empty_like(a), torch.empty_like(b)
+        na = torch.empty(n, dtype=torch.float32, device=a.device)
+        nb = torch.empty(m, dtype=torch.float32, device=a.device)
+        check(lib.egv_l2norm_fwd(_p(a), _p(an), _p(na), n, d, eps, _st()), 'egv_l2norm_fwd')
+        check(lib.egv_l2norm_fwd(_p(b), _p(bn), _p(nb), m, d, eps, _st()), 'egv_l2norm_fwd')
+        sim = torch.empty(n, m, dtype=torch.float32, device=a.device)
+        gemm(an, bn, sim, M=n, N=m, K=d, lda=d, ldb=d, ldc=m)
+        ctx.eps = eps
+        ctx.save_for_backward(an, bn, na, nb)
+        return sim
+
+    @staticmethod
+    def backward(ctx, ds):
+        an, bn, na, nb = ctx.saved_tensors
+        n, d = an.shape
+        m = bn.shape[0]
+        ds = ds.contiguous()
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            dan = torch.empty_like(an)
+            gemm(ds, bn, dan, a_trans=0, b_trans=1, M=n, N=d, K=m, lda=m, ldb=d, ldc=d)
+            da = torch.empty_like(an)
+            check(lib.egv_l2norm_bwd(_p(dan), _p(an), _p(na), _p(da), n, d, ctx.eps, _st()), 'egv_l2norm_bwd')
+        if ctx.needs_input_grad[1]:
+            dbn = torch.empty_like(bn)
+            gemm(ds, an, dbn, a_trans=1, b_trans=1, M=m, N=d, K=n, lda=m, ldb=d, ldc=d)
+            db = torch.empty_like(bn)
+            check(lib.egv_l2norm_bwd(_p(dbn), _p(bn), _p(nb), _p(db), m, d, ctx.eps, _st()), 'egv_l2norm_bwd')
+        return da, db, None
+
+
+def sim_matrix_f32(a, b, eps=1e-8):
+    return SimMatrixFn.apply(a, b, eps)
+
+
+class EgoNCEFn(Function):
+    """EgoNCE.forward (loss.py:40-61): returns (loss, mask_bool)."""
+
+    @staticmethod
+    def forward(ctx, x, sim_v, sim_n, temperature, noun, verb):
+        _need_gpu(x)
+        x, sim_v, sim_n = x.contiguous(), sim_v.contiguous(), sim_n.contiguous()
+        n = x.shape[0]
+        stats = torch.empty(2 * n, 4, dtype=torch.float32, device=x.device)
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        mask = torch.empty(n, n, dtype=torch.uint8, device=x.device)
+        check(lib.egv_egonce_fwd(_p(x), _p(sim_v), _p(sim_n), n, temperature, int(noun), int(verb), _p(stats), _p(loss), _p(mask),
+                                 _st()), 'egv_egonce_fwd')
+        ctx.cfg = (n, temperature, int(noun), int(verb))
+        ctx.save_for_backward(x, sim_v, sim_n, stats)
+        mb = mask.bool()
+        ctx.mark_non_differentiable(mb)
+        return loss.reshape(()), mb
+
+    @staticmethod
+    def backward(ctx, g, _gm):
+        x, sim_v, sim_n, stats = ctx.saved_tensors
+        n, temperature, noun, verb = ctx.cfg
+        g = g.reshape(1).float().contiguous()
+        dx = torch.empty_like(x)
+        check(lib.egv_egonce_bwd(_p(x), _p(sim_v), _p(sim_n), _p(stats), _p(g), _p(dx), n, temperature, noun, verb, _st()),
+              'egv_egonce_bwd')
+        return dx, None, None, None, None, None
+
+
+def egonce(x, sim_v, sim_n, temperature=0.05, noun=True, verb=True):
+    return EgoNCEFn.apply(x, sim_v, sim_n, temperature, noun, verb)
+
+
+# ---- GEMM instrumentation (bench.py roofline) -------------------------------------------------------------
+def prof_enable(on: bool):
+    lib.egv_prof_enable(1 if on else 0)
+
+
+def prof_reset():
+    lib.egv_prof_reset()
+
+
+def prof_collect(max_records: int = 1 << 16):
+    fl = (C.c_double * max_records)()
+    ms = (C.c_float * max_records)()
+    kd = (C.c_int * max_records)()
+    n = lib.egv_prof_collect(fl, ms, kd, max_records)
+    return [(fl[i], ms[i], kd[i]) for i in range(n)]

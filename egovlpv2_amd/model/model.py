@@ -1,0 +1,443 @@
+"""FrozenInTime on MI355X: the reference model API (model/model.py:46-595) over hand-written HIP kernels.
+
+Drop-in surface: ``FrozenInTime(video_params, text_params, projection_dim, load_checkpoint,
+projection, load_temporal_fix, config, task_names, norm_layer, embed_dim)``, ``forward(data, n_embeds, v_embeds,
+allgather, n_gpu, args, config, loss_egonce, gpu, return_embeds, task_names)``, ``infer``, ``compute_text``,
+``compute_video``, module-level ``sim_matrix`` / ``sim_matrix_batch_val`` and identical state-dict names.
+
+Not a port: the module tree only holds the parameters (under the reference's names); the computation is a
+sequence of fused HIP ops (egovlpv2_amd/hipops.py -> libegovlp_hip.so):
+  * one token matrix (B*S, d) per modality, never permuted: divided space/time attention, the CLS splice and
+    both cross-attentions index it in place (csrc/egv_attn.hip);
+  * every Linear is an MFMA GEMM with bias / GELU / gate / residual epilogues (csrc/egv_gemm.hip);
+  * MLM logits are never all-gathered: per-rank CE partial sums are exchanged instead (same loss, same grads).
+Extra keyword arguments (``compute_dtype``, ``path_config``) are extensions; defaults reproduce the reference
+architecture (ViT-B/16 TimeSformer + RoBERTa-base, 6 fused layers).
+"""
+from __future__ import annotations
+
+import copy
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.distributed as dist
+
+from .. import hipops as ops
+from ..config import PathConfig
+from ..synthetic import param_shapes
+from ..utils.util import state_dict_data_parallel_fix
+
+# EgoNCE_MLM_ITM_Config.yml of the reference (read there from cwd at import time; here a plain default)
+DEFAULT_YML = dict(input_image_embed_size=768, vocab_size=50265, mlm_prob=0.15, input_text_embed_size=768,
+                   hidden_size=768, num_heads=12, num_layers=12, mlp_ratio=4, drop_rate=0.1, num_fuse_block=6,
+                   use_checkpoint=True, decay_power='cosine', end_lr=1e-7, warmup_steps=0.1)
+config = dict(DEFAULT_YML)
+
+F32_MIN = torch.finfo(torch.float32).min
+
+
+class _Node(nn.Module):
+    """Bare container: the module tree exists only to give parameters the reference's dotted names."""
+
+
+def _register(root: nn.Module, dotted: str, tensor: torch.Tensor, buffer: bool = False):
+    parts = dotted.split('.')
+    mod = root
+    for p in parts[:-1]:
+        nxt = mod._modules.get(p)
+        if nxt is None:
+            nxt = _Node()
+            mod.add_module(p, nxt)
+        mod = nxt
+    if buffer:
+        mod.register_buffer(parts[-1], tensor)
+    else:
+        mod.register_parameter(parts[-1], nn.Parameter(tensor))
+
+
+def _init_tensor(name: str, shape, gen: torch.Generator, cfg: PathConfig) -> torch.Tensor:
+    """Reference initialisation rules: RoBERTa normal(0,0.02) with zero biases / unit LayerNorm (HF _init_weights,
+    roberta.py:737); TimeSformer Linear defaults, time attention qkv = 0 and proj.weight = 1
+    (video_transformer.py:96-102), alpha gates 0 (:114, roberta.py:440), model cls_token / temporal_embed 0
+    (model.py:150, video_transformer.py:293), pos_embed / video cls_token trunc_normal(0.02) (:319-320), heads
+    normal(0, 0.02) (model.py:35-43)."""
+    last = name.rsplit('.', 1)[-1]
+    if 'alpha_' in name or name in ('cls_token', 'video_model.temporal_embed'):
+        return torch.zeros(shape)
+    if '.timeattn.' in name:
+        if name.endswith('proj.weight'):
+            return torch.ones(shape)
+        return torch.zeros(shape)
+    if last == 'bias' or name == 'mlm_score.bias':
+        return torch.zeros(shape)
+    if len(shape) == 1:                        # LayerNorm weights
+        return torch.ones(shape)
+    if name in ('video_model.pos_embed', 'video_model.cls_token'):
+        return torch.nn.init.trunc_normal_(torch.empty(shape), std=0.02, generator=gen)
+    if name.startswith('video_model.') or name.startswith('txt_proj') or name.startswith('vid_proj'):
+        fan_in = int(np.prod(shape[1:]))       # nn.Linear / nn.Conv2d default: kaiming_uniform(a=sqrt(5))
+        bound = 1.0 / math.sqrt(fan_in)
+        return (torch.rand(shape, generator=gen) * 2 - 1) * bound
+    t = torch.randn(shape, generator=gen) * 0.02
+    if name.endswith('word_embeddings.weight') or name.endswith('position_embeddings.weight'):
+        t[cfg.pad_id].zero_()                  # nn.Embedding(padding_idx=1)
+    return t
+
+
+class FrozenInTime(nn.Module):
+    def __init__(self, video_params, text_params, projection_dim=4096, load_checkpoint=None, projection='minimal',
+                 load_temporal_fix='bilinear', config=config, task_names='EgoNCE_ITM_MLM', norm_layer=None, embed_dim=768,
+                 compute_dtype=torch.bfloat16, path_config: PathConfig | None = None, init_seed: int = 0):
+        super().__init__()
+        self.video_params = video_params
+        self.text_params = text_params
+        self.load_temporal_fix = load_temporal_fix
+        self.config = dict(DEFAULT_YML, **(config or {}))
+        self.task_names = task_names
+        if not text_params['pretrained']:
+            raise NotImplementedError("Huggingface text models require pretrained init.")       # model.py:65-66
+        if not text_params['model'].startswith('roberta'):
+            raise NotImplementedError(f"{text_params['model']} not implemented")
+        if video_params['model'] != 'SpaceTimeTransformer':
+            raise NotImplementedError(f"{video_params['model']} not implemented")                # model.py:97
+        if projection not in ('minimal',):
+            raise NotImplementedError(f"projection={projection!r}")
+        if compute_dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError("compute_dtype must be torch.bfloat16 or torch.float32")
+        if path_config is None:
+            path_config = PathConfig(depth=self.config['num_layers'], n_fuse=self.config['num_fuse_block'],
+                                     frames=video_params['num_frames'], dim=embed_dim, heads=self.config['num_heads'],
+                                     mlp_ratio=self.config['mlp_ratio'], vocab=self.config['vocab_size'],
+                                     proj_dim=projection_dim, img=video_params.get('img_size', 224))
+        self.cfg = path_config
+        if self.cfg.head_dim != 64:
+            raise NotImplementedError("attention kernels are built for head_dim 64")
+        self.num_frames = self.cfg.frames
+        self.num_fuse_block = self.cfg.n_fuse
+        self.num_text_layer = self.cfg.depth
+        self.compute_dtype = compute_dtype
+        self.patches_per_frame = self.cfg.n_patches
+
+        gen = torch.Generator().manual_seed(init_seed)
+        for name, shape in param_shapes(self.cfg, task_names).items():
+            if name.endswith('position_ids'):
+                _register(self, name, torch.arange(self.cfg.max_pos).expand(1, -1).clone(), buffer=True)
+            else:
+                _register(self, name, _init_tensor(name, shape, gen, self.cfg))
+        self._P = None
+
+        if load_checkpoint not in ["", None]:
+            checkpoint = torch.load(load_checkpoint, map_location='cpu')
+            state_dict = checkpoint['state_dict']
+            new_state_dict = state_dict_data_parallel_fix(state_dict, self.state_dict())
+            new_state_dict = self._inflate_positional_embeds(new_state_dict)
+            self.load_state_dict(new_state_dict, strict=False)
+
+    # ------------------------------------------------------------------ plumbing
+    def set_device(self, device):
+        self.device = device
+
+    def p(self, name: str) -> torch.Tensor:
+        if self._P is None:
+            self._P = dict(self.named_parameters())
+        return self._P[name]
+
+    def _lin(self, x, prefix, act='none', gate=None, res1=None, res2=None, bias=True):
+        return ops.linear(x, self.p(prefix + '.weight'), self.p(prefix + '.bias') if bias else None, act=act, gate=gate,
+                          res1=res1, res2=res2)
+
+    def _ln(self, x, prefix, eps):
+        return ops.layernorm(x, self.p(prefix + '.weight'), self.p(prefix + '.bias'), eps)
+
+    # ------------------------------------------------------------------ video side
+    def _patch_tokens(self, video, cls_name):
+        """video_transformer.py:353-372 / model.py:211-232: patch embed, CLS concat, pos + temporal embedding."""
+        B, Fr = video.shape[0], video.shape[1]
+        assert Fr == self.num_frames, (Fr, self.num_frames)                  # video_transformer.py:80
+        x = ops.patch_tokens(video, self.p('video_model.patch_embed.proj.weight'), self.p('video_model.patch_embed.proj.bias'),
+                             self.p(cls_name), self.p('video_model.pos_embed'), self.p('video_model.temporal_embed'),
+                             self.compute_dtype)
+        return x.reshape(B * self.cfg.seq, self.cfg.dim)
+
+    def _video_block(self, x, i, B, y=None, y_mask=None, L=0):
+        """SpaceTimeBlock.forward (video_transformer.py:214-228) on the flat (B*S, d) token matrix."""
+        c = self.cfg
+        pfx = f'video_model.blocks.{i}'
+        Fr, N, H = c.frames, c.n_patches, c.heads
+        qkv = self._lin(self._ln(x, pfx + '.norm3', c.eps_video), pfx + '.timeattn.qkv')
+        t_ctx = ops.divided_attention(qkv, B, Fr, N, H, 'time')
+        tr = self._lin(t_ctx, pfx + '.timeattn.proj', res1=x)                        # time_residual = x + t   (:218)
+        qkv = self._lin(self._ln(tr, pfx + '.norm1', c.eps_video), pfx + '.attn.qkv')
+        s_ctx = ops.divided_attention(qkv, B, Fr, N, H, 'space')
+        if y is None:
+            sr = self._lin(s_ctx, pfx + '.attn.proj', res1=x)                        # space_residual = x + s  (:222)
+        else:
+            a = pfx + '.attn'
+            s = self._lin(s_ctx, a + '.proj')
+            kv = self._lin(y, a + '.qkv_text_i2t')                                    # (B*L, 2D) = [k | v]   (:159-164)
+            q = self._lin(self._ln(s, a + '.norm_i2t_i', c.eps_video), a + '.qkv_i2t')
+            o = ops.plain_attention(q, kv[:, :c.dim], kv[:, c.dim:], B, H, c.seq, L, c.head_dim ** -0.5, mask=y_mask,
+                                    dkv_nsplit=max(1, min(32, c.seq // 64)))
+            # x + (s + alpha * proj_i2t(o))   (:185, :222)
+            sr = self._lin(o, a + '.proj_i2t', gate=self.p(a + '.alpha_i2t'), res1=s, res2=x)
+        return ops.mlp(self._ln(sr, pfx + '.norm2', c.eps_video), self.p(pfx + '.mlp.fc1.weight'), self.p(pfx + '.mlp.fc1.bias'),
+                       self.p(pfx + '.mlp.fc2.weight'), self.p(pfx + '.mlp.fc2.bias'), res=sr)
+
+    def _cls_rows(self, x, B, rows_per_sample):
+        return x.reshape(B, rows_per_sample, -1)[:, 0].contiguous()
+
+    def _proj_mlp(self, x, prefix):
+        x = ops.linear(x, self.p(prefix + '.0.weight'), None, act='relu')
+        x = self._lin(x, prefix + '.2', act='relu')
+        return self._lin(x, prefix + '.4')
+
+    # ------------------------------------------------------------------ text side
+    def _text_embeddings(self, input_ids):
+        e = ops.text_embed(input_ids, self.p('text_model.embeddings.word_embeddings.weight'),
+                           self.p('text_model.embeddings.position_embeddings.weight'),
+                           self.p('text_model.embeddings.token_type_embeddings.weight'), self.cfg.pad_id, self.compute_dtype)
+        return self._ln(e, 'text_model.embeddings.LayerNorm', self.cfg.eps_text)
+
+    @staticmethod
+    def _key_mask(attention_mask):
+        """additive (B, L) fp32 key mask: (1 - m) * finfo(fp32).min (get_extended_attention_mask, roberta.py:826)."""
+        return ((1.0 - attention_mask.to(torch.float32)) * F32_MIN).contiguous()
+
+    def _text_layer(self, hid, mask, i, B, L, enc=None):
+        """RobertaLayer.forward (roberta.py:444-505); enc = video tokens (B*S, d) for the fused layers."""
+        c = self.cfg
+        pfx = f'text_model.encoder.layer.{i}'
+        sa = pfx + '.attention.self'
+        q, k, v = self._lin(hid, sa + '.query'), self._lin(hid, sa + '.key'), self._lin(hid, sa + '.value')
+        ctx = ops.plain_attention(q, k, v, B, c.heads, L, L, 1.0 / math.sqrt(c.head_dim), mask=mask)
+        if enc is None:
+            a = self._lin(ctx, pfx + '.attention.output.dense', res1=hid)           # dense(ctx) + hidden  (:488)
+        else:
+            a0 = self._lin(ctx, pfx + '.attention.output.dense')
+            ca = pfx + '.crossattention_t2i'
+            cq = self._lin(a0, ca + '.self.query')
+            ck, cv = self._lin(enc, ca + '.self.key'), self._lin(enc, ca + '.self.value')
+            cctx = ops.plain_attention(cq, ck, cv, B, c.heads, L, c.seq, 1.0 / math.sqrt(c.head_dim), mask=None)
+            # alpha_t2i * dense(cctx) + a0 + hidden   (:486-488)
+            a = self._lin(cctx, ca + '.output.dense', gate=self.p(pfx + '.alpha_t2i'), res1=a0, res2=hid)
+        a = self._ln(a, pfx + '.attention.output.LayerNorm', c.eps_text)
+        f = ops.mlp(a, self.p(pfx + '.intermediate.dense.weight'), self.p(pfx + '.intermediate.dense.bias'),
+                    self.p(pfx + '.output.dense.weight'), self.p(pfx + '.output.dense.bias'), res=a)
+        return self._ln(f, pfx + '.output.LayerNorm', c.eps_text)
+
+    # ------------------------------------------------------------------ reference API
+    def compute_text(self, text_data):
+        """model.py:491-505: RoBERTa last_hidden_state[:, 0] -> txt_proj."""
+        ids, am = text_data['input_ids'], text_data['attention_mask']
+        B, L = ids.shape
+        hid = self._text_embeddings(ids)
+        mask = self._key_mask(am)
+        for i in range(self.cfg.depth):
+            hid = self._text_layer(hid, mask, i, B, L)
+        return self._proj_mlp(self._cls_rows(hid, B, L), 'txt_proj')
+
+    def compute_text_tokens(self, text_data):
+        """model.py:507-522: all token states -> txt_proj."""
+        ids, am = text_data['input_ids'], text_data['attention_mask']
+        B, L = ids.shape
+        hid = self._text_embeddings(ids)
+        mask = self._key_mask(am)
+        for i in range(self.cfg.depth):
+            hid = self._text_layer(hid, mask, i, B, L)
+        return self._proj_mlp(hid, 'txt_proj').reshape(B, L, -1)
+
+    def _video_features(self, video_data):
+        B = video_data.shape[0]
+        x = self._patch_tokens(video_data, 'video_model.cls_token')
+        for i in range(self.cfg.depth):
+            x = self._video_block(x, i, B)
+        return self._ln(self._cls_rows(x, B, self.cfg.seq), 'video_model.norm', self.cfg.eps_video)
+
+    def compute_video(self, video_data):
+        """model.py:524-530: SpaceTimeTransformer.forward_features (video_model.cls_token / video_model.norm) -> vid_proj."""
+        return self._proj_mlp(self._video_features(video_data), 'vid_proj')
+
+    def _fused_stack(self, video, input_ids, attention_mask, need_video_out=True):
+        """model.py:211-271 / :295-357: model-level cls_token, unfused prefix, then fused steps where both sides read the
+        other modality's state from BEFORE the step.  With need_video_out=False (MLM branch) the last video block, whose
+        output the reference computes and discards, is skipped."""
+        c = self.cfg
+        B, L = input_ids.shape
+        v = self._patch_tokens(video, 'cls_token')
+        t = self._text_embeddings(input_ids)
+        mask = self._key_mask(attention_mask)
+        n_plain = c.depth - c.n_fuse
+        for i in range(n_plain):
+            v = self._video_block(v, i, B)
+        for i in range(n_plain):
+            t = self._text_layer(t, mask, i, B, L)
+        for i in range(n_plain, c.depth):
+            last = i == c.depth - 1
+            v_new = None if (last and not need_video_out) else self._video_block(v, i, B, y=t, y_mask=mask, L=L)
+            t = self._text_layer(t, mask, i, B, L, enc=v)
+            v = v_new
+        return v, t
+
+    def infer(self, data, video_only=False, return_embeds=True, task_names=None, ret=None):
+        """model.py:189-367.  (The reference's mutable default ``ret={}`` is replaced by a fresh dict.)"""
+        ret = {} if ret is None else ret
+        text_data, video_data = data['text'], data['video']
+        if task_names is not None:
+            self.task_names = task_names
+        c = self.cfg
+        if 'EgoNCE' in self.task_names:
+            text_embeddings = self.compute_text(text_data)
+            video_embeddings = self.compute_video(video_data)
+            if return_embeds:
+                ret.update({'text_embeds': text_embeddings, 'video_embeds': video_embeddings})
+        if 'ITM' in self.task_names:
+            B, L = text_data['input_ids'].shape
+            v, t = self._fused_stack(video_data, text_data['input_ids'], text_data['attention_mask'])
+            vf = self._ln(self._cls_rows(v, B, c.seq), 'norm', c.eps_model_norm)            # self.norm(v)[:, 0]  (:275)
+            tf = self._lin(self._cls_rows(t, B, L), 'cross_modal_text_transform')
+            vf = self._lin(vf, 'cross_modal_video_transform')
+            ct = self._lin(tf, 'cross_modal_text_pooler.dense', act='tanh')
+            cv = self._lin(vf, 'cross_modal_video_pooler.dense', act='tanh')
+            ret.update({'cross_attn_itm_logits': self._lin(torch.cat([ct, cv], dim=-1), 'itm_score.fc')})
+        if 'MLM' in self.task_names:
+            B, L = data['text_mlm_ids'].shape
+            logits = self._mlm_logits_padded(video_data, data['text_mlm_ids'], text_data['attention_mask'])
+            ret.update({'cross_attn_mlm_logits': logits.reshape(B, L, -1)[..., :c.vocab]})
+            ret['_mlm_logits_padded'] = logits
+        return ret
+
+    def _mlm_logits_padded(self, video, mlm_ids, attention_mask):
+        """MLM tail (model.py:360-365, heads.py:38-50); the vocabulary axis is padded to a multiple of 128 so that the
+        logits rows stay 16-byte aligned (padded columns are excluded from the CE and get zero gradient)."""
+        c = self.cfg
+        _, t = self._fused_stack(video, mlm_ids, attention_mask, need_video_out=False)
+        t = self._lin(t, 'cross_modal_text_transform')
+        t = self._lin(t, 'mlm_score.transform.dense', act='gelu')
+        t = self._ln(t, 'mlm_score.transform.LayerNorm', c.eps_mlm)
+        return ops.vocab_linear(t, self.p('mlm_score.decoder.weight'), self.p('mlm_score.bias'), c.vocab)
+
+    def forward(self, data, n_embeds, v_embeds, allgather, n_gpu, args, config, loss_egonce, gpu, return_embeds=True,
+                task_names='EgoNCE_ITM_MLM'):
+        """model.py:370-487.  Returns (loss, loss_dict, ret)."""
+        ret, loss_dict = {}, {}
+        if 'Feature_Extraction' in task_names:                                                   # :375-377
+            return self.compute_video(data['video'])
+        world = getattr(args, 'world_size', 1)
+        gather = (lambda t: allgather(t, n_gpu, args))
+        c = self.cfg
+        if 'EgoNCE' in task_names:                                                               # :380-400
+            ret = self.infer(data, task_names='EgoNCE')
+            video_embeds = gather(ops.CastFn.apply(ret['video_embeds'], torch.float32))
+            text_embeds = gather(ops.CastFn.apply(ret['text_embeds'], torch.float32))
+            n_all, v_all = gather(n_embeds.float()), gather(v_embeds.float())
+            output = sim_matrix(text_embeds, video_embeds)
+            if config['loss']['type'] == 'EgoNCE':
+                sim_v = sim_matrix(v_all, v_all)
+                sim_n = sim_matrix(n_all, n_all)
+                loss, mask_bool, temp = loss_egonce(output, sim_v, sim_n)
+            else:
+                loss, mask_bool, temp = loss_egonce(output)
+            ret.update({'sim_v2t': output, 'sim_t2v': output.t()})
+            loss_dict.update({'EgoNCE': loss})
+
+        if 'MLM' in task_names:                                                                  # :404-422
+            ret = self.infer(data, task_names='MLM', ret=ret)
+            logits = ret.pop('_mlm_logits_padded')
+            labels = data['text_mlm_labels'].reshape(-1)
+            ce_sum = ops.cross_entropy_sum(logits, labels, c.vocab, -100)
+            cnt = (labels != -100).sum().to(torch.float32)
+            # the reference all-gathers the (B*L, 50265) logits (412 MB at W=8) and takes the global mean; gathering the
+            # two per-rank scalars gives the identical loss and, through AllGather_multi.backward, identical gradients.
+            tot = gather(torch.stack([ce_sum, cnt]).reshape(1, 2))
+            loss_mlm = tot[:, 0].sum() / tot[:, 1].sum()
+            loss = loss + loss_mlm
+            loss_dict.update({'loss_mlm': loss_mlm})
+
+        if 'ITM' in task_names:                                                                  # :426-483
+            rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else getattr(args, 'rank', 0)
+            all_video = gather(data['video'])
+            all_text_ids = gather(data['text']['input_ids'])
+            all_text_masks = gather(data['text']['attention_mask'])
+            bsz = data['video'].size(0)
+            pos_len = bsz // 2
+            itm_labels = torch.cat([torch.ones(pos_len), torch.zeros(bsz - pos_len)])
+            itm_labels = itm_labels[torch.randperm(itm_labels.size(0))]
+            with torch.no_grad():
+                sl = slice(bsz * rank, bsz * (rank + 1))
+                w_v2t = F.softmax(ret['sim_v2t'][sl] / temp, dim=1).masked_fill(mask_bool[sl], 0)
+                w_t2v = F.softmax(ret['sim_t2v'][sl] / temp, dim=1).masked_fill(mask_bool[sl], 0)
+                # ONE device->host copy; negatives are drawn on the host with the reference's RNG consumption order
+                # (np.random.rand then torch.multinomial per negative, model.py:459-468) instead of one sync per sample.
+                w_cpu = torch.stack([w_v2t, w_t2v]).float().cpu()
+            vid_idx = torch.arange(bsz) + rank * bsz
+            txt_idx = vid_idx.clone()
+            neg_log = []
+            for idx in range(bsz):
+                if itm_labels[idx] == 1:
+                    continue
+                if np.random.rand() > 0.5:
+                    j = torch.multinomial(w_cpu[1, idx] + 1e-9, 1).item()
+                    vid_idx[idx] = j
+                    neg_log.append((idx, 'video', j))
+                else:
+                    j = torch.multinomial(w_cpu[0, idx] + 1e-9, 1).item()
+                    txt_idx[idx] = j
+                    neg_log.append((idx, 'text', j))
+            dev = data['video'].device
+            vid_idx, txt_idx = vid_idx.to(dev), txt_idx.to(dev)
+            data_itm = {'video': all_video.index_select(0, vid_idx),
+                        'text': {'input_ids': all_text_ids.index_select(0, txt_idx),
+                                 'attention_mask': all_text_masks.index_select(0, txt_idx)}}
+            ret = self.infer(data_itm, task_names='ITM', ret=ret)
+            itm_logits = ret['cross_attn_itm_logits']
+            labels_dev = itm_labels.to(dev)
+            ce_sum = ops.cross_entropy_sum(ops.CastFn.apply(itm_logits, torch.float32).contiguous(), labels_dev.long(), 2, -100)
+            tot = gather(torch.stack([ce_sum, torch.full_like(ce_sum, float(bsz))]).reshape(1, 2))
+            loss_itm = tot[:, 0].sum() / tot[:, 1].sum()
+            loss = loss + 2 * loss_itm
+            loss_dict.update({'loss_itm': loss_itm})
+            ret['_itm_labels'] = itm_labels
+            ret['_itm_neg_log'] = neg_log
+
+        loss_dict.update({'loss_total': loss})
+        return loss, loss_dict, ret
+
+    # ------------------------------------------------------------------ checkpoint helpers
+    def _inflate_positional_embeds(self, new_state_dict):
+        """model.py:532-574: adapt temporal_embed when the checkpoint has a different number of frames."""
+        curr_keys = list(self.state_dict().keys())
+        k = 'video_model.temporal_embed'
+        if k in new_state_dict and k in curr_keys:
+            load = new_state_dict[k]
+            load_f, curr_f, dim = load.shape[1], self.video_params['num_frames'], load.shape[2]
+            if load_f != curr_f:
+                if load_f > curr_f:
+                    new = load[:, :curr_f, :]
+                elif self.load_temporal_fix == 'zeros':
+                    new = torch.zeros([load.shape[0], curr_f, dim])
+                    new[:, :load_f] = load
+                elif self.load_temporal_fix in ['interp', 'bilinear']:
+                    mode = 'bilinear' if self.load_temporal_fix == 'bilinear' else 'nearest'
+                    kw = dict(align_corners=True) if mode == 'bilinear' else {}
+                    new = F.interpolate(load.unsqueeze(0), (curr_f, dim), mode=mode, **kw).squeeze(0)
+                else:
+                    raise NotImplementedError
+                new_state_dict[k] = new
+        k = 'video_model.pos_embed'
+        if k in new_state_dict and k in curr_keys:
+            if new_state_dict[k].shape[1] != self.state_dict()[k].shape[1]:
+                raise NotImplementedError('Loading models with different spatial resolution / patch number not yet implemented, sorry.')
+        return new_state_dict
+
+
+def sim_matrix(a, b, eps=1e-8):
+    """model.py:576-584 (fp32 HIP kernels: row normalisation + MFMA GEMM)."""
+    return ops.sim_matrix_f32(a.float(), b.float(), eps)
+
+
+def sim_matrix_batch_val(a, b, eps=1e-8):
+    """model.py:587-595: batched cosine similarity (validation only)."""
+    return torch.stack([sim_matrix(a[i], b[i], eps) for i in range(a.shape[0])])

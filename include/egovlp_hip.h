@@ -1,0 +1,148 @@
+/* libegovlp_hip.so -- C ABI of the MI355X (gfx950) kernels behind the EgoVLPv2 pre-training hot path.
+ *
+ * The reference (facebookresearch/EgoVLPv2) has no FFI: its hot path is a composition of stock ATen ops
+ * inside Python nn.Modules.  Each entry point below replaces one such
+ * composition; the reference lines it replaces are cited per function (paths relative to
+ * EgoVLPv2/ in the reference tree).  The Python host code in egovlpv2_amd/ binds these with ctypes
+ * (egovlpv2_amd/_lib.py) and mirrors the reference module API (FrozenInTime.forward()/infer(),
+ * sim_matrix, EgoNCE, AllGather_multi) on top of them.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless stated otherwise; the caller owns all memory, outputs and
+ *    workspaces are caller-allocated (sizes from the *_workspace_bytes queries), nothing is allocated,
+ *    freed or synchronised inside the library;
+ *  - `stream` is a hipStream_t (as void*); all work is enqueued on it, stream-ordered;
+ *  - `dtype` selects the STORAGE type of activations: EGV_F32 (exact fp32 MFMA path, used for the 1e-3
+ *    parity gate) or EGV_BF16 (bf16 MFMA path, the throughput configuration); arithmetic accumulates in
+ *    fp32 in both; parameters, biases, gates, LayerNorm affine terms, statistics and parameter gradients
+ *    are always fp32;
+ *  - matrices are row-major with an explicit leading dimension in ELEMENTS; activation pointers must be
+ *    16-byte aligned and leading dims multiples of 4 elements for the vector paths (scalar fallbacks
+ *    exist in the GEMM for ragged shapes);
+ *  - return value: 0 on success, negative on error, message via egv_last_error(); errors are argument
+ *    errors detected on the host or launch failures -- there is no CPU fallback of any kind.
+ */
+#ifndef EGOVLP_HIP_H
+#define EGOVLP_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EGV_F32 0
+#define EGV_BF16 1
+
+#define EGV_ACT_NONE 0
+#define EGV_ACT_GELU 1 /* exact erf GELU: nn.GELU video_transformer.py:43, ACT2FN["gelu"] roberta.py:402 */
+#define EGV_ACT_RELU 2 /* txt_proj / vid_proj, model.py:105-115 */
+#define EGV_ACT_TANH 3 /* heads.Pooler, heads.py:15-25 */
+
+int egv_abi_version(void);
+const char* egv_last_error(void);
+
+/* ---- GEMM with fused epilogue: every nn.Linear / Conv2d(k=s=16) on the path ------------------------
+ * C[M,N] = epi( sum_k Aop[m,k] * Bop[n,k] ),  Aop = A[M,K] (a_trans=0) or A[K,M] (a_trans=1), same for B.
+ *   forward  x W^T + b : a_trans=0, b_trans=0        (video_transformer.py:53,56,120,152,160,166,183;
+ *                                                       roberta.py:257-270,341,404,423; model.py:105-115,279-290;
+ *                                                       heads.py:23,34,48-49; patch embed :82 after egv_im2col)
+ *   dgrad    dy W      : a_trans=0, b_trans=1        (autograd of the same lines)
+ * epi: v = scale*acc + bias[n]; pre[m,n] = v (optional save); v = act(v); v *= *gate (optional device
+ * scalar: alpha_i2t / alpha_t2i, video_transformer.py:185, roberta.py:486); v += res1[m,n] + res2[m,n]
+ * (residual adds video_transformer.py:218,222,226; roberta.py:424,488); v *= act'(aux[m,n]) (backward,
+ * dact = EGV_ACT_*: aux is the saved pre-activation for GELU, the forward output for RELU/TANH).
+ * C is dtype unless out_f32.  res1/res2/pre/aux share leading dim ldr (0 -> ldc). */
+int egv_gemm(int dtype, int a_trans, int b_trans, int M, int N, int K,
+             const void* A, int lda, const void* B, int ldb, void* C, int ldc, int out_f32,
+             const float* bias, int act, const float* gate, const void* res1, const void* res2,
+             void* pre, const void* aux, int dact, int ldr, float scale, void* stream);
+
+/* wgrad: dW[N,K] (fp32) = scale * (*gate) * dY[M,N]^T X[M,K]; reduction over the M tokens is split across
+ * workgroups into fp32 slabs in `workspace` and summed in a fixed order (deterministic). */
+long long egv_gemm_wgrad_workspace_bytes(int N, int K, int M);
+int egv_gemm_wgrad(int dtype, int M, int N, int K, const void* dY, int ldy, const void* X, int ldx,
+                   float* dW, float scale, const float* gate, void* workspace, long long workspace_bytes, void* stream);
+
+/* ---- LayerNorm (video_transformer.py:196,207,210,304,115; roberta.py:160,336,417; model.py:155;
+ * BertPredictionHeadTransform.LayerNorm heads.py:41).  stats = [M][2] fp32 {mean, rstd} (may be NULL in
+ * inference).  bwd: dx = LN'(dy) (+ add if not NULL); dgamma/dbeta fp32 [D]. */
+int egv_layernorm_fwd(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* stats,
+                      int M, int D, float eps, void* stream);
+long long egv_layernorm_bwd_workspace_bytes(int M, int D);
+int egv_layernorm_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma,
+                      const void* add, void* dx, float* dgamma, float* dbeta, int M, int D, void* workspace, void* stream);
+
+/* out[n] (fp32) = scale * (*gate) * sum_m X[m,n]  -- bias gradients */
+long long egv_colsum_workspace_bytes(int M, int N);
+int egv_colsum(int dtype, const void* X, int M, int N, int ld, float* out, float scale, const float* gate,
+               void* workspace, void* stream);
+/* out[0] (fp32) = scale * sum_i a[i]*b[i]  -- gradients of the scalar gates; workspace >= 4 KiB */
+int egv_dot(int dtype, const void* a, const void* b, long long n, float* out, float scale, void* workspace, void* stream);
+/* out = dy * act'(aux)  (kind = EGV_ACT_*; aux = forward output for RELU/TANH, pre-activation for GELU) */
+int egv_act_bwd(int dtype, const void* dy, const void* aux, void* out, long long n, int kind, void* stream);
+int egv_cast(int dtype_src, int dtype_dst, const void* src, void* dst, long long n, void* stream);
+
+/* ---- grouped attention, head_dim 64 (video_transformer.py:35-39,117-150,155-182; roberta.py:257-327) ----
+ * Query rows and key rows are affine row sets of token matrices:
+ *     row(b, g, i) = b*bs + base + g*gs + i*is,   b < B, g < G, i < n
+ * and `extra` prepends one row (b*extra_bs + extra_row: the CLS token) on the OTHER side of the launched
+ * kernel: the key side for egv_attn_fwd / egv_attn_bwd_dq, the query side for egv_attn_bwd_dkv.
+ * Q/K/V/O (and gradients) are [rows, ld] matrices; head h lives in columns off + 64*h .. +63.
+ * lse/delta: fp32 [query rows of the whole tensor][H].  mask: additive fp32 over the key index
+ * (mask[b*mask_ld + i]), applies to non-extra keys.  scale multiplies q (video_transformer.py:123,171-172;
+ * roberta.py:303).  egv_attn_bwd_dq must run before egv_attn_bwd_dkv (it produces delta). */
+typedef struct egv_attn_desc {
+    const void* Q; const void* K; const void* V; void* O; const void* dO; void* dQ; void* dK; void* dV;
+    int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
+    int qoff, koff, voff, ooff, dqoff, dkoff, dvoff;
+    float* lse; float* delta;
+    int B, G, H;
+    long long q_bs, q_base, q_gs, q_is; int q_n;
+    long long k_bs, k_base, k_gs, k_is; int k_n;
+    int extra; long long extra_bs, extra_row;
+    float scale;
+    const float* mask; int mask_ld;
+    int nsplit; float* ws; long long ws_bytes;   /* dkv only: split of the query loop, fp32 partial slabs */
+} egv_attn_desc;
+int egv_attn_fwd(int dtype, const egv_attn_desc* d, void* stream);
+int egv_attn_bwd_dq(int dtype, const egv_attn_desc* d, void* stream);
+long long egv_attn_bwd_dkv_workspace_bytes(int B, int G, int H, int k_n, int nsplit);
+int egv_attn_bwd_dkv(int dtype, const egv_attn_desc* d, void* stream);
+
+/* ---- patch embedding pre/post (video_transformer.py:78-83,356-371; model.py:212-231,296-317) ---- */
+int egv_im2col(int dtype, const float* video, void* out, int BF, int C, int H, int W, int P, void* stream);
+int egv_assemble_tokens(int dtype, const void* patch, const float* cls, const float* pos, const float* temporal,
+                        void* out, int B, int F, int N, int D, void* stream);
+long long egv_assemble_tokens_bwd_workspace_bytes(int F, int N, int D);
+int egv_assemble_tokens_bwd(int dtype, const void* dX, void* dpatch, float* dcls, float* dpos, float* dtemporal,
+                            int B, int F, int N, int D, void* workspace, void* stream);
+
+/* ---- RoBERTa embeddings (roberta.py:174-204,881-892): out = word[id] + type[0] + position[posid] ---- */
+int egv_text_embed_fwd(int dtype, const long long* ids, const float* word, const float* pos, const float* type,
+                       void* out, int B, int L, int D, int pad_id, void* stream);
+int egv_text_embed_bwd(int dtype, const long long* ids, const void* de, float* dword, float* dpos, int B, int L, int D,
+                       int pad_id, void* stream);
+
+/* ---- cross entropy (model.py:414-418,478): lse/row_loss fp32 [R]; bwd writes coef*(softmax-onehot),
+ * zero for ignored rows and for padded columns [V, Vpad) ---- */
+int egv_ce_fwd(int dtype, const void* logits, const long long* labels, float* lse, float* row_loss, int R, int V, int ld,
+               long long ignore_index, void* stream);
+int egv_ce_bwd(int dtype, const void* logits, const long long* labels, const float* lse, const float* coef, void* dlogits,
+               int R, int V, int Vpad, int ld, long long ignore_index, void* stream);
+
+/* ---- sim_matrix + EgoNCE (model.py:576-584; loss.py:40-61), fp32 ---- */
+int egv_l2norm_fwd(const float* x, float* y, float* nrm, int n, int d, float eps, void* stream);
+int egv_l2norm_bwd(const float* dy, const float* y, const float* nrm, float* dx, int n, int d, float eps, void* stream);
+int egv_egonce_fwd(const float* x, const float* sim_v, const float* sim_n, int n, float temperature, int noun, int verb,
+                   float* stats /* [2n][4] */, float* loss, unsigned char* mask_bool /* [n][n] or NULL */, void* stream);
+int egv_egonce_bwd(const float* x, const float* sim_v, const float* sim_n, const float* stats, const float* gout, float* dx,
+                   int n, float temperature, int noun, int verb, void* stream);
+
+/* ---- instrumentation: HIP-event timing of the GEMM launches on their own stream (bench.py roofline) ---- */
+int egv_prof_enable(int on);
+int egv_prof_reset(void);
+/* synchronises the recorded events; returns the number of (flops, ms) records copied to the HOST arrays */
+int egv_prof_collect(double* flops, float* ms, int* kind, int max_records);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

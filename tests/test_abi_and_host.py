@@ -1,0 +1,114 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/egovlp_hip.h declares, the ctypes mirror of
+egv_attn_desc has the C layout, the host model has the reference's state-dict surface, and the product path refuses to
+run without a GPU (no silent fallback)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(REPO, 'include', 'egovlp_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(egv_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from egovlpv2_amd import _lib
+    syms = _declared_symbols()
+    assert len(syms) >= 30
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), s
+        assert s in _lib.PROTOTYPES, f"{s} declared in the header but not bound in _lib.py"
+    assert _lib.lib.egv_abi_version() == 1
+
+
+def test_attn_desc_layout_matches_c(tmp_path):
+    """compile a tiny C program against the public header and compare sizeof/offsetof with ctypes"""
+    from egovlpv2_amd._lib import AttnDesc
+    src = tmp_path / 't.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "egovlp_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n",'
+                   'sizeof(egv_attn_desc), offsetof(egv_attn_desc, lse), offsetof(egv_attn_desc, q_bs), offsetof(egv_attn_desc, scale),'
+                   'offsetof(egv_attn_desc, ws_bytes));return 0;}\n')
+    exe = tmp_path / 't'
+    subprocess.check_call(['gcc', '-I', os.path.join(REPO, 'include'), str(src), '-o', str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [ctypes.sizeof(AttnDesc), AttnDesc.lse.offset, AttnDesc.q_bs.offset, AttnDesc.scale.offset, AttnDesc.ws_bytes.offset]
+    assert got == want
+
+
+def test_state_dict_surface_matches_reference():
+    from egovlpv2_amd.model.model import FrozenInTime
+    from egovlpv2_amd.config import tiny_config
+    g = np.load(os.path.join(REPO, 'tests', 'golden', 'tiny.npz'))
+    m = FrozenInTime({'model': 'SpaceTimeTransformer', 'num_frames': 4, 'pretrained': True},
+                     {'model': 'roberta-base', 'pretrained': True, 'input': 'text'}, path_config=tiny_config(),
+                     task_names='EgoNCE_MLM_ITM')
+    assert sorted(k for k, _ in m.named_parameters()) == sorted(str(x) for x in g['param_names'])
+    assert 'text_model.embeddings.position_ids' in m.state_dict()
+    # reference zero / one initialisation (video_transformer.py:96-102,114; roberta.py:440; model.py:150)
+    sd = m.state_dict()
+    assert float(sd['video_model.blocks.1.attn.alpha_i2t']) == 0 and float(sd['text_model.encoder.layer.1.alpha_t2i']) == 0
+    assert sd['video_model.blocks.0.timeattn.qkv.weight'].abs().sum() == 0
+    assert (sd['video_model.blocks.0.timeattn.proj.weight'] == 1).all()
+    assert sd['cls_token'].abs().sum() == 0
+
+
+def test_full_size_parameter_count():
+    """381.6 M parameters / 557 tensors for the reference architecture."""
+    from egovlpv2_amd.synthetic import param_shapes
+    from egovlpv2_amd.config import PathConfig
+    shapes = {k: v for k, v in param_shapes(PathConfig(frames=4)).items() if not k.endswith('position_ids')}
+    assert len(shapes) == 557
+    assert abs(sum(int(np.prod(s)) for s in shapes.values()) / 1e6 - 381.6) < 0.1
+
+
+def test_product_path_refuses_cpu():
+    from egovlpv2_amd.model.model import FrozenInTime
+    from egovlpv2_amd.config import tiny_config
+    from egovlpv2_amd.synthetic import make_batch
+    cfg = tiny_config()
+    m = FrozenInTime({'model': 'SpaceTimeTransformer', 'num_frames': 4, 'pretrained': True},
+                     {'model': 'roberta-base', 'pretrained': True, 'input': 'text'}, path_config=cfg)
+    data, _, _ = make_batch(cfg, 2, 16)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m.compute_video(data['video'])
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    code = ("import sys, importlib.util as u\n"
+            f"sys.path.insert(0, {REPO!r})\n"
+            "import egovlpv2_amd._lib as L\n")
+    # simulate a tree without the .so by pointing the loader at an empty directory
+    env = dict(os.environ)
+    pkg = tmp_path / 'egovlpv2_amd'
+    pkg.mkdir()
+    for f in ('__init__.py', '_lib.py'):
+        (pkg / f).write_text(open(os.path.join(REPO, 'egovlpv2_amd', f)).read())
+    r = subprocess.run([sys.executable, '-c', "import egovlpv2_amd._lib"], cwd=str(tmp_path), env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and 'no CPU fallback' in r.stderr
+
+
+def test_data_parallel_fix_and_inflate():
+    from egovlpv2_amd.utils.util import state_dict_data_parallel_fix
+    a = {'module.x': 1, 'module.y': 2}
+    assert list(state_dict_data_parallel_fix(a, {'x': 0, 'y': 0})) == ['x', 'y']
+    assert list(state_dict_data_parallel_fix({'x': 1}, {'module.x': 0})) == ['module.x']
+    from egovlpv2_amd.model.model import FrozenInTime
+    from egovlpv2_amd.config import tiny_config
+    from egovlpv2_amd.synthetic import make_state_dict
+    g = np.load(os.path.join(REPO, 'tests', 'golden', 'tiny.npz'))
+    cfg = tiny_config(frames=int(g['inflate_frames']))
+    m = FrozenInTime({'model': 'SpaceTimeTransformer', 'num_frames': cfg.frames, 'pretrained': True},
+                     {'model': 'roberta-base', 'pretrained': True, 'input': 'text'}, path_config=cfg)
+    sd = make_state_dict(tiny_config(), 0)
+    out = m._inflate_positional_embeds({'video_model.temporal_embed': sd['video_model.temporal_embed'].clone()})
+    assert np.allclose(out['video_model.temporal_embed'][0, :, :8].numpy(), g['inflate_slice'], atol=1e-6)

@@ -1,0 +1,60 @@
+"""world_size-2 gloo tests (CPU) of the multi-rank plumbing of the path: AllGather_multi forward/backward semantics
+(reference trainer/trainer_egoclip.py:25-41) and the scalar-gather form of the MLM/ITM loss reductions, which must give
+the same loss and the same local gradients as gathering the logits (reference model.py:411-418)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import types
+    from egovlpv2_amd.trainer.trainer_egoclip import AllGather_multi
+    args = types.SimpleNamespace(world_size=world, rank=rank)
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(3, 5, generator=g, requires_grad=True)
+    y = AllGather_multi.apply(x, world, args)
+    ok = y.shape == (3 * world, 5) and torch.equal(y[3 * rank:3 * rank + 3], x.detach())
+    w = torch.arange(3 * world * 5, dtype=torch.float32).reshape(3 * world, 5)
+    (y * w).sum().backward()
+    ok = ok and torch.equal(x.grad, w[3 * rank:3 * rank + 3])       # local slice only, no reduction
+
+    # scalar-gather CE == logits-gather CE (loss value and local gradient)
+    V = 11
+    logits = torch.randn(4, V, generator=g, requires_grad=True)
+    labels = torch.randint(0, V, (4,), generator=g)
+    labels[rank] = -100
+    lg_all = AllGather_multi.apply(logits, world, args)
+    lb_all = AllGather_multi.apply(labels, world, args)
+    ref = torch.nn.functional.cross_entropy(lg_all, lb_all, ignore_index=-100)
+    (g_ref,) = torch.autograd.grad(ref, logits)
+    s = torch.nn.functional.cross_entropy(logits, labels, ignore_index=-100, reduction='sum')
+    cnt = (labels != -100).sum().float()
+    tot = AllGather_multi.apply(torch.stack([s, cnt]).reshape(1, 2), world, args)
+    mine = tot[:, 0].sum() / tot[:, 1].sum()
+    (g_mine,) = torch.autograd.grad(mine, logits)
+    ok = ok and torch.allclose(ref, mine, atol=1e-6) and torch.allclose(g_ref, g_mine, atol=1e-7)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_allgather_and_loss_reduction_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 300)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]

@@ -1,0 +1,333 @@
+"""Op-level parity of every HIP entry point (through the C ABI via egovlpv2_amd.hipops) against plain
+torch fp64 math on the same (dtype-rounded) inputs.  Tolerances (relative L2):
+  fp32 storage: 2e-5 forward / 1e-4 backward (exact-fp32 MFMA, fp32 accumulation order differs from torch)
+  bf16 storage: 6e-3 forward / 2e-2 backward (inputs are pre-rounded to bf16, so the error budget is the
+                bf16 rounding of intermediates/outputs, 2^-9 per element)
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _tol(dtype, bwd=False):
+    if dtype == torch.float32:
+        return 1e-4 if bwd else 2e-5
+    return 2e-2 if bwd else 6e-3
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _rnd(shape, dtype, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    t = (torch.randn(shape, generator=g) * scale).to(dtype)
+    return t
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from egovlpv2_amd import hipops
+    return hipops
+
+
+def gelu64(x):
+    return 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(300, 200, 768), (128, 128, 64), (25, 2, 1536), (130, 1000, 264), (8, 4096, 768)])
+def test_linear_forms(ops, dtype, shape):
+    M, N, K = shape
+    x = _rnd((M, K), dtype, 1.0, 1).cuda().requires_grad_(True)
+    w = _rnd((N, K), torch.float32, 0.05, 2).cuda().requires_grad_(True)
+    b = _rnd((N,), torch.float32, 0.5, 3).cuda().requires_grad_(True)
+    r = _rnd((M, N), dtype, 1.0, 4).cuda().requires_grad_(True)
+    y = ops.linear(x, w, b, res1=r)
+    wq = w.detach().to(dtype).double().cpu()
+    x64, r64 = x.detach().double().cpu().requires_grad_(True), r.detach().double().cpu().requires_grad_(True)
+    w64, b64 = wq.clone().requires_grad_(True), b.detach().double().cpu().requires_grad_(True)
+    y64 = x64 @ w64.t() + b64 + r64
+    assert _rel(y, y64) < _tol(dtype)
+    dy = _rnd((M, N), dtype, 1.0, 5)
+    y.backward(dy.cuda())
+    y64.backward(dy.double())
+    assert _rel(x.grad, x64.grad) < _tol(dtype, True)
+    assert _rel(w.grad, w64.grad) < _tol(dtype, True)
+    assert _rel(b.grad, b64.grad) < _tol(dtype, True)
+    assert _rel(r.grad, r64.grad) < 1e-6
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('act', ['relu', 'tanh', 'gelu'])
+def test_linear_act(ops, dtype, act):
+    M, N, K = 70, 96, 128
+    x = _rnd((M, K), dtype, 1.0, 1).cuda().requires_grad_(True)
+    w = _rnd((N, K), torch.float32, 0.1, 2).cuda().requires_grad_(True)
+    b = _rnd((N,), torch.float32, 0.5, 3).cuda().requires_grad_(True)
+    y = ops.linear(x, w, b, act=act)
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    w64 = w.detach().to(dtype).double().cpu().requires_grad_(True)
+    b64 = b.detach().double().cpu().requires_grad_(True)
+    z = x64 @ w64.t() + b64
+    y64 = {'relu': torch.relu, 'tanh': torch.tanh, 'gelu': gelu64}[act](z)
+    assert _rel(y, y64) < _tol(dtype)
+    dy = _rnd((M, N), dtype, 1.0, 5)
+    y.backward(dy.cuda())
+    y64.backward(dy.double())
+    assert _rel(x.grad, x64.grad) < _tol(dtype, True) * 1.5
+    assert _rel(w.grad, w64.grad) < _tol(dtype, True) * 1.5
+    assert _rel(b.grad, b64.grad) < _tol(dtype, True) * 1.5
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_linear_gate_two_residuals(ops, dtype):
+    M, N, K = 200, 768, 768
+    x = _rnd((M, K), dtype, 1.0, 1).cuda().requires_grad_(True)
+    w = _rnd((N, K), torch.float32, 0.05, 2).cuda().requires_grad_(True)
+    b = _rnd((N,), torch.float32, 0.5, 3).cuda().requires_grad_(True)
+    r1 = _rnd((M, N), dtype, 1.0, 4).cuda().requires_grad_(True)
+    r2 = _rnd((M, N), dtype, 1.0, 6).cuda().requires_grad_(True)
+    alpha = torch.tensor([0.37], device='cuda', requires_grad=True)
+    y = ops.linear(x, w, b, gate=alpha, res1=r1, res2=r2)
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    w64 = w.detach().to(dtype).double().cpu().requires_grad_(True)
+    b64 = b.detach().double().cpu().requires_grad_(True)
+    a64 = alpha.detach().double().cpu().requires_grad_(True)
+    y64 = a64 * (x64 @ w64.t() + b64) + r1.detach().double().cpu() + r2.detach().double().cpu()
+    assert _rel(y, y64) < _tol(dtype)
+    dy = _rnd((M, N), dtype, 1.0, 5)
+    y.backward(dy.cuda())
+    y64.backward(dy.double())
+    assert _rel(x.grad, x64.grad) < _tol(dtype, True)
+    assert _rel(w.grad, w64.grad) < _tol(dtype, True)
+    assert _rel(b.grad, b64.grad) < _tol(dtype, True)
+    assert _rel(alpha.grad, a64.grad) < _tol(dtype, True)
+    assert _rel(r1.grad, dy) < 1e-6 and _rel(r2.grad, dy) < 1e-6
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_mlp(ops, dtype):
+    M, D, H = 333, 768, 3072
+    x = _rnd((M, D), dtype, 1.0, 1).cuda().requires_grad_(True)
+    w1 = _rnd((H, D), torch.float32, 0.04, 2).cuda().requires_grad_(True)
+    b1 = _rnd((H,), torch.float32, 0.2, 3).cuda().requires_grad_(True)
+    w2 = _rnd((D, H), torch.float32, 0.02, 4).cuda().requires_grad_(True)
+    b2 = _rnd((D,), torch.float32, 0.2, 5).cuda().requires_grad_(True)
+    y = ops.mlp(x, w1, b1, w2, b2, res=x)
+    p64 = [t.detach().double().cpu().requires_grad_(True) for t in (x, w1.detach().to(dtype), b1, w2.detach().to(dtype), b2)]
+    x64, w164, b164, w264, b264 = p64
+    h = gelu64(x64 @ w164.t() + b164)
+    if dtype == torch.bfloat16:
+        h = h + (h.detach().to(torch.bfloat16).double() - h.detach())      # the stored activation is bf16
+    y64 = h @ w264.t() + b264 + x64
+    assert _rel(y, y64) < _tol(dtype)
+    dy = _rnd((M, D), dtype, 1.0, 6)
+    y.backward(dy.cuda())
+    y64.backward(dy.double())
+    for a, bb in zip((x, w1, b1, w2, b2), p64):
+        assert _rel(a.grad, bb.grad) < _tol(dtype, True) * 1.5
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('D', [768, 1024])
+def test_layernorm(ops, dtype, D):
+    M = 517
+    x = _rnd((M, D), dtype, 2.0, 1).cuda().requires_grad_(True)
+    g = (1 + _rnd((D,), torch.float32, 0.1, 2)).cuda().requires_grad_(True)
+    b = _rnd((D,), torch.float32, 0.1, 3).cuda().requires_grad_(True)
+    y = ops.layernorm(x, g, b, 1e-5)
+    x64, g64, b64 = [t.detach().double().cpu().requires_grad_(True) for t in (x, g, b)]
+    y64 = torch.nn.functional.layer_norm(x64, (D,), g64, b64, 1e-5)
+    assert _rel(y, y64) < _tol(dtype)
+    dy = _rnd((M, D), dtype, 1.0, 5)
+    y.backward(dy.cuda())
+    y64.backward(dy.double())
+    assert _rel(x.grad, x64.grad) < _tol(dtype, True)
+    assert _rel(g.grad, g64.grad) < _tol(dtype, True)
+    assert _rel(b.grad, b64.grad) < _tol(dtype, True)
+
+
+def _divided_ref(qkv, B, Fr, N, H, mode):
+    """fp64 restatement of VarAttention's attention core (video_transformer.py:121-150)."""
+    S = 1 + Fr * N
+    dh = 64
+    q, k, v = qkv.reshape(B, S, 3, H, dh).permute(2, 0, 3, 1, 4)
+    q = q * dh ** -0.5
+    cls = torch.softmax(q[:, :, :1] @ k.transpose(-1, -2), -1) @ v
+
+    def grp(t):
+        t = t[:, :, 1:].reshape(B, H, Fr, N, dh)
+        return t if mode == 'space' else t.transpose(2, 3)
+    qg, kg, vg = grp(q), grp(k), grp(v)
+    G = qg.shape[2]
+    kc = k[:, :, :1].unsqueeze(2).expand(B, H, G, 1, dh)
+    vc = v[:, :, :1].unsqueeze(2).expand(B, H, G, 1, dh)
+    kk, vv = torch.cat([kc, kg], 3), torch.cat([vc, vg], 3)
+    og = torch.softmax(qg @ kk.transpose(-1, -2), -1) @ vv
+    if mode != 'space':
+        og = og.transpose(2, 3)
+    out = torch.cat([cls, og.reshape(B, H, Fr * N, dh)], 2)
+    return out.permute(0, 2, 1, 3).reshape(B * S, H * dh)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('mode,Fr,N', [('space', 3, 70), ('time', 5, 9), ('space', 2, 196), ('time', 16, 4)])
+def test_divided_attention(ops, dtype, mode, Fr, N):
+    B, H = 2, 3
+    S = 1 + Fr * N
+    qkv = _rnd((B * S, 3 * H * 64), dtype, 1.5, 7).cuda().requires_grad_(True)
+    o = ops.divided_attention(qkv, B, Fr, N, H, mode)
+    q64 = qkv.detach().double().cpu().requires_grad_(True)
+    o64 = _divided_ref(q64, B, Fr, N, H, mode)
+    assert _rel(o, o64) < _tol(dtype)
+    do = _rnd((B * S, H * 64), dtype, 1.0, 8)
+    o.backward(do.cuda())
+    o64.backward(do.double())
+    assert _rel(qkv.grad, q64.grad) < _tol(dtype, True)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('nq,nk,masked,nsplit', [(16, 16, True, 1), (32, 197, False, 1), (300, 32, True, 4), (5, 70, False, 1)])
+def test_plain_attention(ops, dtype, nq, nk, masked, nsplit):
+    B, H = 2, 3
+    D = H * 64
+    q = _rnd((B * nq, D), dtype, 1.0, 1).cuda().requires_grad_(True)
+    kv = _rnd((B * nk, 2 * D), dtype, 1.0, 2).cuda().requires_grad_(True)
+    mask = None
+    if masked:
+        m = torch.ones(B, nk)
+        m[0, nk // 2:] = 0
+        m[1, -1] = 0
+        mask = ((1 - m) * torch.finfo(torch.float32).min).cuda()
+    scale = 0.125
+    o = ops.plain_attention(q, kv[:, :D], kv[:, D:], B, H, nq, nk, scale, mask=mask, dkv_nsplit=nsplit)
+    q64 = q.detach().double().cpu().requires_grad_(True)
+    kv64 = kv.detach().double().cpu().requires_grad_(True)
+    qh = q64.reshape(B, nq, H, 64).transpose(1, 2)
+    kh = kv64[:, :D].reshape(B, nk, H, 64).transpose(1, 2)
+    vh = kv64[:, D:].reshape(B, nk, H, 64).transpose(1, 2)
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    if masked:
+        s = s + mask.double().cpu().view(B, 1, 1, nk)
+    o64 = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B * nq, D)
+    assert _rel(o, o64) < _tol(dtype)
+    do = _rnd((B * nq, D), dtype, 1.0, 3)
+    o.backward(do.cuda())
+    o64.backward(do.double())
+    assert _rel(q.grad, q64.grad) < _tol(dtype, True)
+    assert _rel(kv.grad, kv64.grad) < _tol(dtype, True)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_patch_tokens(ops, dtype):
+    B, Fr, R, P, D = 2, 3, 64, 16, 128
+    N = (R // P) ** 2
+    video = _rnd((B, Fr, 3, R, R), torch.float32, 1.0, 1).cuda()
+    w = _rnd((D, 3, P, P), torch.float32, 0.05, 2).cuda().requires_grad_(True)
+    b = _rnd((D,), torch.float32, 0.1, 3).cuda().requires_grad_(True)
+    cls = _rnd((1, 1, D), torch.float32, 0.5, 4).cuda().requires_grad_(True)
+    pos = _rnd((1, 1 + N, D), torch.float32, 0.5, 5).cuda().requires_grad_(True)
+    tem = _rnd((1, Fr, D), torch.float32, 0.5, 6).cuda().requires_grad_(True)
+    y = ops.patch_tokens(video, w, b, cls, pos, tem, dtype)
+    v64 = video.to(dtype).double().cpu()
+    w64 = w.detach().to(dtype).double().cpu().requires_grad_(True)
+    b64, c64, p64, t64 = [t.detach().double().cpu().requires_grad_(True) for t in (b, cls, pos, tem)]
+    e = torch.nn.functional.conv2d(v64.reshape(B * Fr, 3, R, R), w64, b64, stride=P).flatten(2).transpose(2, 1).reshape(B, Fr * N, D)
+    body = p64[:, 1:].unsqueeze(1) + t64.unsqueeze(2)
+    y64 = torch.cat([(c64 + p64[:, :1]).expand(B, 1, D), e + body.reshape(1, Fr * N, D)], 1)
+    assert _rel(y, y64) < _tol(dtype)
+    dy = _rnd((B, 1 + Fr * N, D), dtype, 1.0, 7)
+    y.backward(dy.cuda())
+    y64.backward(dy.double())
+    for a, bb in ((w, w64), (b, b64), (cls, c64), (pos, p64), (tem, t64)):
+        assert _rel(a.grad, bb.grad) < _tol(dtype, True)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_text_embed(ops, dtype):
+    B, L, D, V = 3, 12, 128, 500
+    ids = torch.randint(3, V, (B, L), generator=torch.Generator().manual_seed(1))
+    ids[:, 0] = 0
+    ids[0, 7:] = 1
+    ids[1, 10:] = 1
+    word = _rnd((V, D), torch.float32, 1.0, 2).cuda().requires_grad_(True)
+    pos = _rnd((40, D), torch.float32, 1.0, 3).cuda().requires_grad_(True)
+    typ = _rnd((1, D), torch.float32, 1.0, 4).cuda().requires_grad_(True)
+    y = ops.text_embed(ids.cuda(), word, pos, typ, 1, dtype)
+    m = ids.ne(1).long()
+    pid = torch.cumsum(m, 1) * m + 1
+    w64, p64, t64 = [t.detach().double().cpu().requires_grad_(True) for t in (word, pos, typ)]
+    y64 = (torch.nn.functional.embedding(ids, w64, padding_idx=1) + t64[0] + torch.nn.functional.embedding(pid, p64, padding_idx=1)).reshape(B * L, D)
+    assert _rel(y, y64) < _tol(dtype)
+    dy = _rnd((B * L, D), dtype, 1.0, 5)
+    y.backward(dy.cuda())
+    y64.backward(dy.double())
+    assert _rel(word.grad, w64.grad) < 1e-5
+    assert _rel(pos.grad, p64.grad) < 1e-5
+    assert _rel(typ.grad, t64.grad) < 1e-5
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_vocab_linear_and_ce(ops, dtype):
+    R, K, V = 40, 128, 1003
+    x = _rnd((R, K), dtype, 1.0, 1).cuda().requires_grad_(True)
+    w = _rnd((V, K), torch.float32, 0.2, 2).cuda().requires_grad_(True)
+    b = _rnd((V,), torch.float32, 0.5, 3).cuda().requires_grad_(True)
+    labels = torch.randint(0, V, (R,), generator=torch.Generator().manual_seed(4))
+    labels[::3] = -100
+    logits = ops.vocab_linear(x, w, b, V)
+    assert logits.shape[1] % 128 == 0
+    total = ops.cross_entropy_sum(logits, labels.cuda(), V, -100)
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    w64 = w.detach().to(dtype).double().cpu().requires_grad_(True)
+    b64 = b.detach().double().cpu().requires_grad_(True)
+    lg = x64 @ w64.t() + b64
+    if dtype == torch.bfloat16:
+        lg = lg + (lg.detach().to(torch.bfloat16).double() - lg.detach())
+    t64 = torch.nn.functional.cross_entropy(lg, labels, ignore_index=-100, reduction='sum')
+    assert abs(total.item() - t64.item()) < (2e-5 if dtype == torch.float32 else 4e-3) * abs(t64.item())
+    (total * 0.5).backward()
+    (t64 * 0.5).backward()
+    assert _rel(x.grad, x64.grad) < _tol(dtype, True)
+    assert _rel(w.grad, w64.grad) < _tol(dtype, True)
+    assert _rel(b.grad, b64.grad) < _tol(dtype, True)
+
+
+def test_sim_matrix_and_egonce(ops):
+    n, d = 24, 512
+    a = _rnd((n, d), torch.float32, 1.0, 1).cuda().requires_grad_(True)
+    b = _rnd((n, d), torch.float32, 1.0, 2).cuda().requires_grad_(True)
+    nv = (torch.rand(n, 30, generator=torch.Generator().manual_seed(3)) < 0.2).float()
+    vv = (torch.rand(n, 20, generator=torch.Generator().manual_seed(4)) < 0.2).float()
+    sim = ops.sim_matrix_f32(a, b)
+    sv = ops.sim_matrix_f32(vv.cuda(), vv.cuda())
+    sn = ops.sim_matrix_f32(nv.cuda(), nv.cuda())
+    loss, mb = ops.egonce(sim, sv, sn, 0.05, True, True)
+
+    def sm(x, y, eps=1e-8):
+        return (x / x.norm(dim=1, keepdim=True).clamp_min(eps)) @ (y / y.norm(dim=1, keepdim=True).clamp_min(eps)).t()
+    a64, b64 = a.detach().double().cpu().requires_grad_(True), b.detach().double().cpu().requires_grad_(True)
+    s64 = sm(a64, b64)
+    sv64, sn64 = sm(vv.double(), vv.double()), sm(nv.double(), nv.double())
+    mask = (sv64 * sn64 + torch.eye(n, dtype=torch.float64)) > 0
+    i_sm, j_sm = torch.softmax(s64 / 0.05, 1), torch.softmax(s64.t() / 0.05, 1)
+    l64 = -torch.log((i_sm * mask).sum(1)).mean() - torch.log((j_sm * mask).sum(1)).mean()
+    assert _rel(sim, s64) < 2e-5
+    assert torch.equal(mb.cpu(), mask)
+    assert abs(loss.item() - l64.item()) < 2e-5 * abs(l64.item())
+    loss.backward()
+    l64.backward()
+    assert _rel(a.grad, a64.grad) < 2e-4
+    assert _rel(b.grad, b64.grad) < 2e-4
+
+
+def test_cpu_tensor_is_refused(ops):
+    with pytest.raises(RuntimeError):
+        ops.linear(torch.randn(4, 8), torch.randn(8, 8))
