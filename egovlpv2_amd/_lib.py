@@ -9,6 +9,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- must be imported first: the HIP runtime torch bundles has to be the one in the process
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libegovlp_hip.so')
 
