@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""bench.py -- EgoVLPv2 pre-training hot path on MI355X: video-text pairs/s for FrozenInTime forward+backward.
+
+  python bench.py --gpus 1 --steps K --warmup W                       (one rank)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = zero_grad + forward (EgoNCE + MLM + ITM, three backbone passes) + backward over one synthetic batch of B
+pairs per GPU at 16 x 224^2 frames / 32 tokens (BASELINE.json configs[2]; `--workload dual` = configs[1], EgoNCE only),
+bf16 storage / fp32 accumulation, weights cast from the fp32 masters inside every timed step, DDP gradient all-reduce
+over RCCL for N > 1.  Prints ONE JSON line (rank 0) with the contract fields + `roofline` (dominant kernel: the MFMA GEMM,
+timed with HIP events on its own stream inside the timed region) + `cpu_baseline` (the CPU oracle timed on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: ~2.5 PF dense)
+
+
+def flops_per_pair(cfg, L, workload):
+    """Algorithmic matmul FLOPs per video-text pair, forward (SURVEY.md §8d formulas); fwd+bwd = 3x."""
+    d, F, N, S, P = cfg.dim, cfg.frames, cfg.n_patches, cfg.seq, cfg.proj_dim
+    patch = 2 * F * N * d * (3 * cfg.patch ** 2)
+    vblock = 2 * (2 * S * d * 3 * d + 2 * S * d * d) + 4 * d * (F * N * (1 + F) + S) + 4 * d * (F * N * (1 + N) + S) + 4 * S * d * 4 * d
+    i2t = 4 * S * d * d + 2 * L * d * 2 * d + 4 * S * L * d
+    tlayer = 8 * L * d * d + 4 * L * L * d + 16 * L * d * d
+    t2i = 4 * L * d * d + 4 * S * d * d + 4 * L * S * d
+    proj = 2 * (2 * d * P + 4 * P * P)
+    dual = patch + cfg.depth * vblock + cfg.depth * tlayer + proj
+    fused = patch + cfg.depth * vblock + cfg.depth * tlayer + cfg.n_fuse * (i2t + t2i)
+    heads = 2 * L * d * d + 2 * L * d * cfg.vocab + 2 * L * d * d + 6 * d * d
+    return dual if workload == 'dual' else dual + 2 * fused + heads
+
+
+def cpu_baseline(cfg, L, workload, budget_s):
+    """The CPU oracle (oracle/ref_model.py, kind 'port') timed on this box's host cores on a bounded sample of the same
+    workload: the same shapes at B=1, one fwd+bwd step (after a tiny warm-up to page the libraries in)."""
+    from oracle import ref_model as O
+    from egovlpv2_amd.synthetic import make_state_dict, make_batch
+    from egovlpv2_amd.config import tiny_config
+    tasks = 'EgoNCE' if workload == 'dual' else 'EgoNCE_MLM_ITM'
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+
+    def one(c, B, Lx):
+        sd = make_state_dict(c, 0)
+        for v in sd.values():
+            if v.is_floating_point():
+                v.requires_grad_(True)
+        data, noun, verb = make_batch(c, B, Lx, 99)
+        t0 = time.time()
+        loss, _, _ = O.forward_losses(sd, data, noun, verb, O.make_cfg(**c.as_dict()), tasks)
+        loss.backward()
+        return time.time() - t0
+    one(tiny_config(), 2, 16)
+    frames = cfg.frames
+    dt = one(cfg, 1, L)
+    sample = f"oracle fp32, B=1, {frames}x{cfg.img}^2 frames, {L} tokens, tasks={tasks}, 1 fwd+bwd step"
+    return {"value": round(1.0 / dt, 5), "unit": "pairs/s", "cores": cores, "kind": "port", "sample": sample,
+            "seconds": round(dt, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='full', choices=['full', 'dual'])
+    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--frames', type=int, default=16)
+    ap.add_argument('--text-len', type=int, default=32)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-gemm-events', action='store_true')
+    a = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from egovlpv2_amd import hipops as ops
+    from egovlpv2_amd.config import PathConfig
+    from egovlpv2_amd.synthetic import make_state_dict, make_batch
+    from egovlpv2_amd.model.model import FrozenInTime
+    from egovlpv2_amd.model.loss import EgoNCE
+    from egovlpv2_amd.trainer.trainer_egoclip import AllGather_multi
+
+    cfg = PathConfig(frames=a.frames)
+    tasks = 'EgoNCE' if a.workload == 'dual' else 'EgoNCE_MLM_ITM'
+    dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
+    model = FrozenInTime({'model': 'SpaceTimeTransformer', 'num_frames': cfg.frames, 'pretrained': True},
+                         {'model': 'roberta-base', 'pretrained': True, 'input': 'text'}, path_config=cfg,
+                         task_names='EgoNCE_MLM_ITM', compute_dtype=dtype)
+    model.load_state_dict(make_state_dict(cfg, 0), strict=True)          # same random-init weights on every rank
+    model = model.to(dev)
+    net = model
+    if world > 1:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        net = DDP(model, device_ids=[local], static_graph=True, gradient_as_bucket_view=True,
+                  find_unused_parameters=False, bucket_cap_mb=64)
+    data, noun, verb = make_batch(cfg, a.batch, a.text_len, 1234 + rank)
+    data = {'video': data['video'].to(dev), 'text': {k: v.to(dev) for k, v in data['text'].items()},
+            'text_mlm_ids': data['text_mlm_ids'].to(dev), 'text_mlm_labels': data['text_mlm_labels'].to(dev)}
+    noun, verb = noun.to(dev), verb.to(dev)
+    args = types.SimpleNamespace(world_size=world, rank=rank)
+    loss_fn = EgoNCE()
+    conf = {'loss': {'type': 'EgoNCE'}}
+    np.random.seed(1 + rank)
+    torch.manual_seed(1 + rank)
+
+    def step():
+        ops.invalidate_weight_cache()            # weights are re-cast from the fp32 masters every step, as in training
+        for p in model.parameters():
+            p.grad = None
+        loss, ld, _ = net(data, noun, verb, AllGather_multi.apply, world, args, conf, loss_fn, local, task_names=tasks)
+        loss.backward()
+        return ld
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        ld = step()
+    sync()
+    use_events = not a.no_gemm_events
+    if use_events:
+        ops.prof_reset()
+        ops.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ld = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if use_events:
+        ops.prof_enable(False)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    losses = {k: round(float(v.detach()), 5) for k, v in ld.items()}
+
+    roof = None
+    if use_events and rank == 0:
+        recs = ops.prof_collect()
+        kinds = {0: 'gemm_nt_fwd', 1: 'gemm_nn_dgrad', 2: 'gemm_tn_wgrad', 4: 'gemm_nt_fwd_f32', 5: 'gemm_nn_dgrad_f32', 6: 'gemm_tn_wgrad_f32'}
+        agg = {}
+        for fl, ms, kd in recs:
+            e = agg.setdefault(kd, [0.0, 0.0, 0])
+            e[0] += fl
+            e[1] += ms
+            e[2] += 1
+        tot_ms = sum(e[1] for e in agg.values())
+        dom = max(agg, key=lambda k: agg[k][1])
+        fl, ms, n = agg[dom]
+        ach = fl / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "kernel": kinds.get(dom, str(dom)), "launches": n, "avg_launch_ms": round(ms / n, 4),
+                "all_gemm": {kinds.get(k, str(k)): {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1), "ms_per_step": round(v[1] / a.steps, 2),
+                                                    "launches_per_step": v[2] // a.steps} for k, v in agg.items()},
+                "gemm_ms_per_step": round(tot_ms / a.steps, 2)}
+
+    if rank == 0:
+        pairs = world * a.batch * a.steps
+        value = pairs / dt
+        fpp = 3.0 * flops_per_pair(cfg, a.text_len, a.workload)
+        out = {"metric": "video-text pairs/sec/node (EgoClip fwd+bwd, 16x224^2, 32 tok)", "value": round(value, 3),
+               "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": a.dtype, "data": "synthetic",
+               "config": {"workload": ("configs[2] full fusion EgoNCE+MLM+ITM" if a.workload == 'full' else "configs[1] dual encoder EgoNCE")
+                          + f", ViT-B/16 TimeSformer + RoBERTa-base, B={a.batch}/GPU, {a.frames}x224^2, {a.text_len} tok",
+                          "global_batch": world * a.batch, "parallelism": f"dp{world}", "timed": "zero_grad + fwd + bwd (+DDP all-reduce), weight cast included"},
+               "model_tflops": round(value * fpp / 1e12, 1), "mfma_frac_of_peak": round(value * fpp / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
+               "losses": losses, "roofline": roof}
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, a.text_len, a.workload, 30)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

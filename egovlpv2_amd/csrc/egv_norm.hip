@@ -280,7 +280,7 @@ extern "C" int egv_layernorm_bwd(int dtype, const void* dy, const void* x, const
 
 static inline int colsum_chunks(int M) {
     int c = (M + 255) / 256;
-    return c > 128 ? 128 : (c < 1 ? 1 : c);
+    return c > 32 ? 32 : (c < 1 ? 1 : c);
 }
 extern "C" long long egv_colsum_workspace_bytes(int M, int N) { return (long long)colsum_chunks(M) * N * 4; }
 

@@ -676,3 +676,8 @@ def prof_collect(max_records: int = 1 << 16):
     kd = (C.c_int * max_records)()
     n = lib.egv_prof_collect(fl, ms, kd, max_records)
     return [(fl[i], ms[i], kd[i]) for i in range(n)]
+
+
+def invalidate_weight_cache():
+    """Drop the compute-dtype weight copies (call once per optimisation step: the fp32 masters changed)."""
+    _wcache.clear()
