@@ -1,0 +1,71 @@
+// Shared declarations of the attention kernels (VALU reference-precision path: egv_attn.hip; MFMA bf16 path:
+// egv_attn_mfma.hip).
+#pragma once
+#include "egv_common.h"
+
+namespace egv {
+
+constexpr int HD = 64;          // head dim
+constexpr int TK = 64;          // other-side rows per LDS tile
+constexpr int LDT = 68;         // float pitch of LDS tiles (conflict-free b128 row reads and b32 column reads)
+constexpr int QPW = 8;          // own rows per wave (keeps every kernel under 64 KB of LDS)
+
+struct RowSet {
+    long long bs, base, gs, is;   // row(b,g,i) = b*bs + base + g*gs + i*is
+    int n;
+};
+
+struct AttnArgs {
+    const void* Q; const void* K; const void* V; void* O; const void* dO;
+    void* dQ; void* dK; void* dV;
+    int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
+    int qoff, koff, voff, ooff, dqoff, dkoff, dvoff;
+    float* lse; float* delta; int H;
+    RowSet q, k;
+    int extra; long long extra_bs, extra_row;   // one extra row prepended on the OTHER side of the launched kernel
+    float scale;
+    const float* mask; int mask_ld;             // additive mask over key index: mask[b*mask_ld + i]
+    int G;
+    int nsplit; float* ws;                      // dkv only: split of the query loop + fp32 partial slabs
+};
+
+__device__ __forceinline__ long long rs_row(const RowSet& r, int b, int g, int i) {
+    return (long long)b * r.bs + r.base + (long long)g * r.gs + (long long)i * r.is;
+}
+
+}  // namespace egv
+
+// Flat C description of one attention launch (see include/egovlp_hip.h).
+struct egv_attn_desc {
+    const void* Q; const void* K; const void* V; void* O; const void* dO; void* dQ; void* dK; void* dV;
+    int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
+    int qoff, koff, voff, ooff, dqoff, dkoff, dvoff;
+    float* lse; float* delta;
+    int B, G, H;
+    long long q_bs, q_base, q_gs, q_is; int q_n;
+    long long k_bs, k_base, k_gs, k_is; int k_n;
+    int extra; long long extra_bs, extra_row;
+    float scale;
+    const float* mask; int mask_ld;
+    int nsplit; float* ws; long long ws_bytes;
+};
+
+static inline egv::AttnArgs to_args(const egv_attn_desc* d) {
+    egv::AttnArgs a;
+    a.Q = d->Q; a.K = d->K; a.V = d->V; a.O = d->O; a.dO = d->dO; a.dQ = d->dQ; a.dK = d->dK; a.dV = d->dV;
+    a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo; a.lddq = d->lddq; a.lddk = d->lddk; a.lddv = d->lddv;
+    a.qoff = d->qoff; a.koff = d->koff; a.voff = d->voff; a.ooff = d->ooff; a.dqoff = d->dqoff; a.dkoff = d->dkoff; a.dvoff = d->dvoff;
+    a.lse = d->lse; a.delta = d->delta; a.H = d->H;
+    a.q = egv::RowSet{d->q_bs, d->q_base, d->q_gs, d->q_is, d->q_n};
+    a.k = egv::RowSet{d->k_bs, d->k_base, d->k_gs, d->k_is, d->k_n};
+    a.extra = d->extra; a.extra_bs = d->extra_bs; a.extra_row = d->extra_row;
+    a.scale = d->scale; a.mask = d->mask; a.mask_ld = d->mask_ld; a.G = d->G;
+    a.nsplit = d->nsplit > 0 ? d->nsplit : 1; a.ws = d->ws;
+    return a;
+}
+
+
+// MFMA launchers (egv_attn_mfma.hip): return 1 if the problem shape is covered (and the kernel was enqueued), else 0.
+int egv_attn_fwd_mfma(const egv::AttnArgs& a, int B, hipStream_t st);
+int egv_attn_dq_mfma(const egv::AttnArgs& a, int B, hipStream_t st);
+int egv_attn_dkv_mfma(const egv::AttnArgs& a, int B, hipStream_t st);

@@ -18,37 +18,9 @@
 //
 // v1 compute mapping (exact fp32 VALU, shared by the f32 and bf16 storage types): lane = key for q.k^T
 // (key row in 64 VGPRs, q broadcast with v_readlane), lane = d for p.V (value column in 64 VGPRs).
-#include "egv_common.h"
+#include "egv_attn.h"
 
 namespace egv {
-
-constexpr int HD = 64;          // head dim
-constexpr int TK = 64;          // other-side rows per LDS tile
-constexpr int LDT = 68;         // float pitch of LDS tiles (conflict-free b128 row reads and b32 column reads)
-constexpr int QPW = 8;          // own rows per wave (keeps every kernel under 64 KB of LDS)
-
-struct RowSet {
-    long long bs, base, gs, is;   // row(b,g,i) = b*bs + base + g*gs + i*is
-    int n;
-};
-
-struct AttnArgs {
-    const void* Q; const void* K; const void* V; void* O; const void* dO;
-    void* dQ; void* dK; void* dV;
-    int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
-    int qoff, koff, voff, ooff, dqoff, dkoff, dvoff;
-    float* lse; float* delta; int H;
-    RowSet q, k;
-    int extra; long long extra_bs, extra_row;   // one extra row prepended on the OTHER side of the launched kernel
-    float scale;
-    const float* mask; int mask_ld;             // additive mask over key index: mask[b*mask_ld + i]
-    int G;
-    int nsplit; float* ws;                      // dkv only: split of the query loop + fp32 partial slabs
-};
-
-__device__ __forceinline__ long long rs_row(const RowSet& r, int b, int g, int i) {
-    return (long long)b * r.bs + r.base + (long long)g * r.gs + (long long)i * r.is;
-}
 
 // stage `rows` head rows (64 elements each) of a [.., ld] matrix into an fp32 LDS tile; rows >= nvalid are zero
 template <typename T, int NT>
@@ -98,7 +70,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, w = wave_id();
     const int p = blockIdx.y, b = p / a.G, g = p % a.G, h = blockIdx.z;
-    const int q0 = blockIdx.x * (NW * QPW) + w * QPW;
+    const int split = blockIdx.x % a.nsplit;
+    const int q0 = (blockIdx.x / a.nsplit) * (NW * QPW) + w * QPW;
     const int nq = min(QPW, a.q.n - q0);       // may be <= 0 for trailing waves
     const T* Q = reinterpret_cast<const T*>(a.Q);
     const T* K = reinterpret_cast<const T*>(a.K);
@@ -115,10 +88,12 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
         }
     }
     const int ntot = a.k.n + a.extra;
-    for (int j0 = 0; j0 < ntot; j0 += TK) {
+    const int per = (((ntot + TK - 1) / TK + a.nsplit - 1) / a.nsplit) * TK;      // key range of this split (tile aligned)
+    const int jbeg = split * per, jend = min(ntot, jbeg + per);
+    for (int j0 = jbeg; j0 < jend; j0 += TK) {
         __syncthreads();
-        stage_tile<T, NT>(sK, K, a.ldk, hk, a, a.k, b, g, j0, ntot, tid);
-        stage_tile<T, NT>(sV, V, a.ldv, hv, a, a.k, b, g, j0, ntot, tid);
+        stage_tile<T, NT>(sK, K, a.ldk, hk, a, a.k, b, g, j0, jend, tid);
+        stage_tile<T, NT>(sV, V, a.ldv, hv, a, a.k, b, g, j0, jend, tid);
         __syncthreads();
         if (nq > 0) {
             float krow[HD], vcol[HD];
@@ -126,7 +101,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
             for (int kk = 0; kk < TK; ++kk) vcol[kk] = sV[kk * LDT + lane];
             const int j = j0 + lane;
-            const bool valid = j < ntot;
+            const bool valid = j < jend;
             float mk = 0.f;
             if (a.mask && valid && !(a.extra && j == 0)) mk = a.mask[(long long)b * a.mask_ld + (j - a.extra)];
             for (int i = 0; i < nq; ++i) {
@@ -153,9 +128,43 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
     for (int i = 0; i < nq; ++i) {
         const long long row = rs_row(a.q, b, g, q0 + i);
         const float m = sM[(w * QPW + i) * 2], l = sM[(w * QPW + i) * 2 + 1];
-        Elem<T>::st(O + row * a.ldo + ho + lane, sO[(w * QPW + i) * HD + lane] / l);
-        if (a.lse && lane == 0) a.lse[row * a.H + h] = m + __logf(l);
+        if (a.nsplit == 1) {
+            Elem<T>::st(O + row * a.ldo + ho + lane, sO[(w * QPW + i) * HD + lane] / l);
+            if (a.lse && lane == 0) a.lse[row * a.H + h] = m + __logf(l);
+        } else {
+            // partial (m, l, o[64]) per split: ws[split][P * q.n own rows][H][66]
+            const long long nrows = (long long)gridDim.y * a.q.n;
+            const long long orow = (long long)p * a.q.n + q0 + i;
+            float* dst = a.ws + (((long long)split * nrows + orow) * a.H + h) * 66;
+            dst[2 + lane] = sO[(w * QPW + i) * HD + lane];
+            if (lane == 0) { dst[0] = m; dst[1] = l; }
+        }
     }
+}
+
+// combine the per-split partial softmax states of attn_fwd_kernel (one wave per (own row, head))
+template <typename T>
+__global__ void attn_fwd_combine_kernel(const AttnArgs a, int P) {
+    const int lane = threadIdx.x & 63;
+    const long long nrows = (long long)P * a.q.n;
+    const long long idx = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (idx >= nrows * a.H) return;
+    const long long orow = idx / a.H;
+    const int h = (int)(idx % a.H);
+    const int p = (int)(orow / a.q.n), i = (int)(orow % a.q.n);
+    const int b = p / a.G, g = p % a.G;
+    float M = -INFINITY;
+    for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, a.ws[(((long long)s * nrows + orow) * a.H + h) * 66]);
+    float Lsum = 0.f, o = 0.f;
+    for (int s = 0; s < a.nsplit; ++s) {
+        const float* src = a.ws + (((long long)s * nrows + orow) * a.H + h) * 66;
+        const float c = __expf(src[0] - M);
+        Lsum += src[1] * c;
+        o += src[2 + lane] * c;
+    }
+    const long long row = rs_row(a.q, b, g, i);
+    Elem<T>::st(reinterpret_cast<T*>(a.O) + row * a.ldo + a.ooff + h * HD + lane, o / Lsum);
+    if (a.lse && lane == 0) a.lse[row * a.H + h] = M + __logf(Lsum);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -174,7 +183,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const AttnArgs a) 
 
     const int tid = threadIdx.x, lane = tid & 63, w = wave_id();
     const int p = blockIdx.y, b = p / a.G, g = p % a.G, h = blockIdx.z;
-    const int q0 = blockIdx.x * (NW * QPW) + w * QPW;
+    const int split = blockIdx.x % a.nsplit;
+    const int q0 = (blockIdx.x / a.nsplit) * (NW * QPW) + w * QPW;
     const int nq = min(QPW, a.q.n - q0);
     const T* Q = reinterpret_cast<const T*>(a.Q);
     const T* K = reinterpret_cast<const T*>(a.K);
@@ -194,21 +204,23 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const AttnArgs a) 
         if (lane == 0) {
             sS[(w * QPW + i) * 2] = a.lse[row * a.H + h];
             sS[(w * QPW + i) * 2 + 1] = dl;
-            a.delta[row * a.H + h] = dl;
+            if (split == 0) a.delta[row * a.H + h] = dl;
         }
     }
     const int ntot = a.k.n + a.extra;
-    for (int j0 = 0; j0 < ntot; j0 += TK) {
+    const int per = (((ntot + TK - 1) / TK + a.nsplit - 1) / a.nsplit) * TK;
+    const int jbeg = split * per, jend = min(ntot, jbeg + per);
+    for (int j0 = jbeg; j0 < jend; j0 += TK) {
         __syncthreads();
-        stage_tile<T, NT>(sK, K, a.ldk, hk, a, a.k, b, g, j0, ntot, tid);
-        stage_tile<T, NT>(sV, V, a.ldv, hv, a, a.k, b, g, j0, ntot, tid);
+        stage_tile<T, NT>(sK, K, a.ldk, hk, a, a.k, b, g, j0, jend, tid);
+        stage_tile<T, NT>(sV, V, a.ldv, hv, a, a.k, b, g, j0, jend, tid);
         __syncthreads();
         if (nq > 0) {
             float krow[HD], vrow[HD];
             load_row64(sK, lane, krow);
             load_row64(sV, lane, vrow);
             const int j = j0 + lane;
-            const bool valid = j < ntot;
+            const bool valid = j < jend;
             float mk = 0.f;
             if (a.mask && valid && !(a.extra && j == 0)) mk = a.mask[(long long)b * a.mask_ld + (j - a.extra)];
             for (int i = 0; i < nq; ++i) {
@@ -230,8 +242,30 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const AttnArgs a) 
     const int hdq = a.dqoff + h * HD;
     for (int i = 0; i < nq; ++i) {
         const long long row = rs_row(a.q, b, g, q0 + i);
-        Elem<T>::st(dQ + row * a.lddq + hdq + lane, sDQ[(w * QPW + i) * HD + lane] * a.scale);
+        if (a.nsplit == 1) {
+            Elem<T>::st(dQ + row * a.lddq + hdq + lane, sDQ[(w * QPW + i) * HD + lane] * a.scale);
+        } else {
+            const long long nrows = (long long)gridDim.y * a.q.n;
+            const long long orow = (long long)p * a.q.n + q0 + i;
+            a.ws[(((long long)split * nrows + orow) * a.H + h) * HD + lane] = sDQ[(w * QPW + i) * HD + lane] * a.scale;
+        }
     }
+}
+
+template <typename T>
+__global__ void attn_dq_combine_kernel(const AttnArgs a, int P) {
+    const int lane = threadIdx.x & 63;
+    const long long nrows = (long long)P * a.q.n;
+    const long long idx = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (idx >= nrows * a.H) return;
+    const long long orow = idx / a.H;
+    const int h = (int)(idx % a.H);
+    const int p = (int)(orow / a.q.n), i = (int)(orow % a.q.n);
+    const int b = p / a.G, g = p % a.G;
+    float acc = 0.f;
+    for (int s = 0; s < a.nsplit; ++s) acc += a.ws[(((long long)s * nrows + orow) * a.H + h) * HD + lane];
+    const long long row = rs_row(a.q, b, g, i);
+    Elem<T>::st(reinterpret_cast<T*>(a.dQ) + row * a.lddq + a.dqoff + h * HD + lane, acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -377,35 +411,6 @@ static inline size_t dkv_smem() { return (size_t)(2 * TK * LDT) * 4; }
 }  // namespace egv
 using namespace egv;
 
-// Flat C description of one attention launch (see include/egovlp_hip.h).
-struct egv_attn_desc {
-    const void* Q; const void* K; const void* V; void* O; const void* dO; void* dQ; void* dK; void* dV;
-    int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
-    int qoff, koff, voff, ooff, dqoff, dkoff, dvoff;
-    float* lse; float* delta;
-    int B, G, H;
-    long long q_bs, q_base, q_gs, q_is; int q_n;
-    long long k_bs, k_base, k_gs, k_is; int k_n;
-    int extra; long long extra_bs, extra_row;
-    float scale;
-    const float* mask; int mask_ld;
-    int nsplit; float* ws; long long ws_bytes;
-};
-
-static AttnArgs to_args(const egv_attn_desc* d) {
-    AttnArgs a;
-    a.Q = d->Q; a.K = d->K; a.V = d->V; a.O = d->O; a.dO = d->dO; a.dQ = d->dQ; a.dK = d->dK; a.dV = d->dV;
-    a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo; a.lddq = d->lddq; a.lddk = d->lddk; a.lddv = d->lddv;
-    a.qoff = d->qoff; a.koff = d->koff; a.voff = d->voff; a.ooff = d->ooff; a.dqoff = d->dqoff; a.dkoff = d->dkoff; a.dvoff = d->dvoff;
-    a.lse = d->lse; a.delta = d->delta; a.H = d->H;
-    a.q = RowSet{d->q_bs, d->q_base, d->q_gs, d->q_is, d->q_n};
-    a.k = RowSet{d->k_bs, d->k_base, d->k_gs, d->k_is, d->k_n};
-    a.extra = d->extra; a.extra_bs = d->extra_bs; a.extra_row = d->extra_row;
-    a.scale = d->scale; a.mask = d->mask; a.mask_ld = d->mask_ld; a.G = d->G;
-    a.nsplit = d->nsplit > 0 ? d->nsplit : 1; a.ws = d->ws;
-    return a;
-}
-
 static int check_desc(const egv_attn_desc* d, const char* who) {
     EGV_CHECK(d->B > 0 && d->G > 0 && d->H > 0 && d->q_n > 0 && d->k_n > 0, "%s: bad problem shape", who);
     EGV_CHECK((d->ldq % 4 == 0) && (d->ldk % 4 == 0) && (d->ldv % 4 == 0) && (d->qoff % 4 == 0) && (d->koff % 4 == 0) &&
@@ -431,15 +436,36 @@ static inline int pick_nw(int n_own) {
     return t >= 4 ? 4 : (t >= 2 ? 2 : 1);
 }
 
+// fp32 workspace for a split launch: which = 0 fwd (own = queries), 1 dq (own = queries), 2 dkv (own = keys)
+extern "C" long long egv_attn_split_workspace_bytes(int which, int B, int G, int H, int n_own, int nsplit) {
+    if (nsplit <= 1) return 0;
+    const long long per = which == 0 ? 66 : (which == 1 ? HD : 2 * HD);
+    return (long long)nsplit * B * G * n_own * H * per * 4;
+}
+
 extern "C" int egv_attn_fwd(int dtype, const egv_attn_desc* d, void* stream) {
     if (check_desc(d, "egv_attn_fwd")) return -1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     AttnArgs a = to_args(d);
+    if (dtype == EGV_BF16 && a.nsplit == 1 && egv_attn_fwd_mfma(a, d->B, st)) {
+        EGV_LAUNCH_CHECK();
+        return 0;
+    }
+    if (a.nsplit > 1)
+        EGV_CHECK(d->ws && d->ws_bytes >= egv_attn_split_workspace_bytes(0, d->B, d->G, d->H, d->q_n, a.nsplit),
+                  "egv_attn_fwd: workspace too small");
     const int nw = pick_nw(d->q_n);
-    dim3 grid((d->q_n + nw * QPW - 1) / (nw * QPW), d->B * d->G, d->H);
+    dim3 grid(((d->q_n + nw * QPW - 1) / (nw * QPW)) * a.nsplit, d->B * d->G, d->H);
     const size_t sm = fwd_smem(nw);
     EGV_ATTN_LAUNCH(attn_fwd_kernel, nw, sm, grid);
     EGV_LAUNCH_CHECK();
+    if (a.nsplit > 1) {
+        const long long n = (long long)d->B * d->G * d->q_n * d->H;
+        const int blocks = (int)((n + 3) / 4);
+        if (dtype == EGV_BF16) hipLaunchKernelGGL(attn_fwd_combine_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, a, d->B * d->G);
+        else hipLaunchKernelGGL(attn_fwd_combine_kernel<float>, dim3(blocks), dim3(256), 0, st, a, d->B * d->G);
+        EGV_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -448,11 +474,25 @@ extern "C" int egv_attn_bwd_dq(int dtype, const egv_attn_desc* d, void* stream) 
     EGV_CHECK(d->lse && d->delta && d->dO && d->dQ, "egv_attn_bwd_dq: missing lse/delta/dO/dQ");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     AttnArgs a = to_args(d);
+    if (dtype == EGV_BF16 && a.nsplit == 1 && egv_attn_dq_mfma(a, d->B, st)) {
+        EGV_LAUNCH_CHECK();
+        return 0;
+    }
+    if (a.nsplit > 1)
+        EGV_CHECK(d->ws && d->ws_bytes >= egv_attn_split_workspace_bytes(1, d->B, d->G, d->H, d->q_n, a.nsplit),
+                  "egv_attn_bwd_dq: workspace too small");
     const int nw = pick_nw(d->q_n);
-    dim3 grid((d->q_n + nw * QPW - 1) / (nw * QPW), d->B * d->G, d->H);
+    dim3 grid(((d->q_n + nw * QPW - 1) / (nw * QPW)) * a.nsplit, d->B * d->G, d->H);
     const size_t sm = dq_smem(nw);
     EGV_ATTN_LAUNCH(attn_bwd_dq_kernel, nw, sm, grid);
     EGV_LAUNCH_CHECK();
+    if (a.nsplit > 1) {
+        const long long n = (long long)d->B * d->G * d->q_n * d->H;
+        const int blocks = (int)((n + 3) / 4);
+        if (dtype == EGV_BF16) hipLaunchKernelGGL(attn_dq_combine_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, a, d->B * d->G);
+        else hipLaunchKernelGGL(attn_dq_combine_kernel<float>, dim3(blocks), dim3(256), 0, st, a, d->B * d->G);
+        EGV_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -466,6 +506,10 @@ extern "C" int egv_attn_bwd_dkv(int dtype, const egv_attn_desc* d, void* stream)
     EGV_CHECK(d->lse && d->delta && d->dO && d->dK && d->dV, "egv_attn_bwd_dkv: missing lse/delta/dO/dK/dV");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     AttnArgs a = to_args(d);
+    if (dtype == EGV_BF16 && a.nsplit == 1 && egv_attn_dkv_mfma(a, d->B, st)) {
+        EGV_LAUNCH_CHECK();
+        return 0;
+    }
     if (a.nsplit > 1)
         EGV_CHECK(d->ws && d->ws_bytes >= egv_attn_bwd_dkv_workspace_bytes(d->B, d->G, d->H, d->k_n, a.nsplit),
                   "egv_attn_bwd_dkv: workspace too small");

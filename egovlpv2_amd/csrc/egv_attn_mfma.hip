@@ -1,0 +1,458 @@
+// MFMA (bf16) grouped attention for gfx950: divided space / time attention, RoBERTa self attention and the
+// small-key cross attention of the EgoVLPv2 hot path, head_dim 64.
+//
+// One workgroup per (problem, head[, own-tile chunk]).  The OTHER side of the kernel (keys for fwd/dQ, queries for
+// dK/dV; <= 224 rows incl. the optional extra CLS row) is staged once in LDS -- row-major (144-byte pitch, conflict-free
+// ds_read_b128 fragments) and/or transposed ([64 d][rows], built with an in-register 8x8 bf16 block transpose, read as
+// two ds_read_b64 per fragment) -- and every wave walks 16-row tiles of the OWN side with v_mfma_f32_16x16x32_bf16:
+//
+//   fwd : S^T = K Q^T (A = K rows from LDS, B = Q rows from global)  -> whole score row in registers (no online softmax),
+//         softmax over the lane-local 4*NT values + 2 xor-shuffles, P stays in registers as the B operand of
+//         O^T = V^T P^T (A = V^T from LDS).  The reduction index of the second MFMA is permuted (k = [tile 2kk rows g*4..,
+//         tile 2kk+1 rows g*4..]) so that the C layout of the first MFMA is already the B layout of the second.
+//   dQ  : S^T, dP^T = V dO^T, dS^T = P^T o (dP^T - delta), dQ^T = K^T dS^T.
+//   dKV : S = Q K^T, dP = dO V^T (A = Q / dO rows from LDS, B = own K / V rows from global), dV^T = dO^T P, dK^T = Q^T dS.
+//
+// Every output row is written exactly once as 8-byte packed bf16 (4 consecutive head columns per lane).
+#include "egv_attn.h"
+
+namespace egv {
+
+constexpr int RP = 144;                       // row pitch (bytes) of row-major tiles: 64 bf16 + 16 B pad
+
+__host__ __device__ constexpr int vt_pitch(int NT) { return NT * 32 + 16; }     // bytes: NT*16 rows of bf16 + pad
+
+__device__ __forceinline__ long long other_row(const AttnArgs& a, const RowSet& rs, int b, int g, int j) {
+    if (a.extra) return (j == 0) ? ((long long)b * a.extra_bs + a.extra_row) : rs_row(rs, b, g, j - 1);
+    return rs_row(rs, b, g, j);
+}
+
+// stage other-side rows [0, ntot) of one head into a row-major LDS tile (rows >= ntot are zero)
+template <int NT, int NTHR>
+__device__ __forceinline__ void stage_rows(unsigned char* s, const bf16_t* base, int ld, int off, const AttnArgs& a,
+                                           const RowSet& rs, int b, int g, int ntot, int tid) {
+    for (int c = tid; c < NT * 16 * 8; c += NTHR) {
+        const int r = c >> 3, v = c & 7;
+        u32x4_t x = {0u, 0u, 0u, 0u};
+        if (r < ntot) x = *reinterpret_cast<const u32x4_t*>(base + other_row(a, rs, b, g, r) * ld + off + v * 8);
+        *reinterpret_cast<u32x4_t*>(s + r * RP + v * 16) = x;
+    }
+}
+
+// stage the same rows transposed: sT[d][row] (bf16, pitch vt_pitch(NT)); 8x8 block transpose in registers
+template <int NT, int NTHR>
+__device__ __forceinline__ void stage_rows_t(unsigned char* s, const bf16_t* base, int ld, int off, const AttnArgs& a,
+                                             const RowSet& rs, int b, int g, int ntot, int tid) {
+    constexpr int VP = vt_pitch(NT);
+    for (int u = tid; u < NT * 2 * 8; u += NTHR) {      // NT*16/8 row blocks x 8 d blocks
+        const int kb = u >> 3, db = u & 7;
+        u32x4_t r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = kb * 8 + j;
+            r[j] = u32x4_t{0u, 0u, 0u, 0u};
+            if (row < ntot) r[j] = *reinterpret_cast<const u32x4_t*>(base + other_row(a, rs, b, g, row) * ld + off + db * 8);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            u32x4_t o;
+#pragma unroll
+            for (int d4 = 0; d4 < 4; ++d4) {
+                const unsigned int x = r[2 * d4][e >> 1], y = r[2 * d4 + 1][e >> 1];
+                o[d4] = (e & 1) ? ((x >> 16) | (y & 0xffff0000u)) : ((x & 0xffffu) | (y << 16));
+            }
+            *reinterpret_cast<u32x4_t*>(s + (db * 8 + e) * VP + kb * 16) = o;
+        }
+    }
+}
+
+__device__ __forceinline__ bf16x8_t ld_frag_row(const unsigned char* s, int row, int ks, int fg) {
+    return *reinterpret_cast<const bf16x8_t*>(s + row * RP + ks * 64 + fg * 16);
+}
+
+// fragment of a transposed tile for k-step kk: elements [row-tile 2kk rows g*4..+3 | row-tile 2kk+1 rows g*4..+3] at column d
+template <int NT>
+__device__ __forceinline__ bf16x8_t ld_frag_t(const unsigned char* s, int d, int kk, int fg) {
+    constexpr int VP = vt_pitch(NT);
+    const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(s + d * VP + ((2 * kk) * 16 + fg * 4) * 2);
+    const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(s + d * VP + ((2 * kk + 1) * 16 + fg * 4) * 2);
+    u32x4_t v = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+__device__ __forceinline__ bf16x8_t ld_frag_global(const bf16_t* p, bool valid) {
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (valid) v = *reinterpret_cast<const u32x4_t*>(p);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+__device__ __forceinline__ unsigned int pack2(float a, float b) { return (unsigned int)f2bf(a) | ((unsigned int)f2bf(b) << 16); }
+
+__device__ __forceinline__ bf16x8_t pack8(const f32x4_t& a, const f32x4_t& b) {
+    u32x4_t v = {pack2(a[0], a[1]), pack2(a[2], a[3]), pack2(b[0], b[1]), pack2(b[2], b[3])};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+__device__ __forceinline__ float grp_max(float v) {      // across the 4 lane groups (lanes l, l^16, l^32, l^48)
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float grp_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+__device__ __forceinline__ void st_bf16x4(bf16_t* p, float a, float b, float c, float d) {
+    u32x2_t v = {pack2(a, b), pack2(c, d)};
+    *reinterpret_cast<u32x2_t*>(p) = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward.  NT = 16-row tiles of the key side (even).  grid (own chunks, problems, heads), NW waves,
+// TPW own tiles per wave per workgroup.
+// ------------------------------------------------------------------------------------------------
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnArgs a, int tiles_per_wg) {
+    constexpr int VP = vt_pitch(NT);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sK = smem;                       // [NT*16][RP]
+    unsigned char* sVt = smem + NT * 16 * RP;       // [64][VP]
+
+    const int tid = threadIdx.x, lane = tid & 63, w = wave_id();
+    const int fr = lane & 15, fg = lane >> 4;
+    const int p = blockIdx.y, b = p / a.G, g = p % a.G, h = blockIdx.z;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.Q);
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.K);
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.V);
+    bf16_t* O = reinterpret_cast<bf16_t*>(a.O);
+    const int hq = a.qoff + h * HD, hk = a.koff + h * HD, hv = a.voff + h * HD, ho = a.ooff + h * HD;
+    const int ntot = a.k.n + a.extra;
+
+    stage_rows<NT, 64 * NW>(sK, K, a.ldk, hk, a, a.k, b, g, ntot, tid);
+    stage_rows_t<NT, 64 * NW>(sVt, V, a.ldv, hv, a, a.k, b, g, ntot, tid);
+    __syncthreads();
+
+    const int nqt = (a.q.n + 15) >> 4;
+    const int t0 = blockIdx.x * tiles_per_wg;
+    const int t1 = min(nqt, t0 + tiles_per_wg);
+    for (int qt = t0 + w; qt < t1; qt += NW) {
+        const int q = qt * 16 + fr;
+        const bool qv = q < a.q.n;
+        const long long qrow = qv ? rs_row(a.q, b, g, q) : 0;
+        const bf16x8_t q0 = ld_frag_global(Q + qrow * a.ldq + hq + fg * 8, qv);
+        const bf16x8_t q1 = ld_frag_global(Q + qrow * a.ldq + hq + 32 + fg * 8, qv);
+        f32x4_t s[NT];
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sK, t * 16 + fr, 0, fg), q0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sK, t * 16 + fr, 1, fg), q1, acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = t * 16 + fg * 4 + r;
+                float v = acc[r] * a.scale;
+                if (a.mask && key >= a.extra && key < ntot) v += a.mask[(long long)b * a.mask_ld + key - a.extra];
+                v = key < ntot ? v : -INFINITY;
+                acc[r] = v;
+                m = fmaxf(m, v);
+            }
+            s[t] = acc;
+            if (t & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        m = grp_max(m);
+        float l = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(s[t][r] - m);
+                s[t][r] = e;
+                l += e;
+            }
+        l = grp_sum(l);
+        f32x4_t o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < NT / 2; ++kk) {
+            const bf16x8_t pf = pack8(s[2 * kk], s[2 * kk + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_t<NT>(sVt, dt * 16 + fr, kk, fg), pf, o[dt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (qv) {
+            const float inv = 1.0f / l;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                st_bf16x4(O + qrow * a.ldo + ho + dt * 16 + fg * 4, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+            if (a.lse && fg == 0) a.lse[qrow * a.H + h] = m + __logf(l);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, query-owned: dQ and delta = rowsum(dO * O)
+// ------------------------------------------------------------------------------------------------
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a, int tiles_per_wg) {
+    constexpr int VP = vt_pitch(NT);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sK = smem;                       // [NT*16][RP]
+    unsigned char* sV = sK + NT * 16 * RP;          // [NT*16][RP]
+    unsigned char* sKt = sV + NT * 16 * RP;         // [64][VP]
+
+    const int tid = threadIdx.x, lane = tid & 63, w = wave_id();
+    const int fr = lane & 15, fg = lane >> 4;
+    const int p = blockIdx.y, b = p / a.G, g = p % a.G, h = blockIdx.z;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.Q);
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.K);
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.V);
+    const bf16_t* O = reinterpret_cast<const bf16_t*>(a.O);
+    const bf16_t* dO = reinterpret_cast<const bf16_t*>(a.dO);
+    bf16_t* dQ = reinterpret_cast<bf16_t*>(a.dQ);
+    const int hq = a.qoff + h * HD, hk = a.koff + h * HD, hv = a.voff + h * HD, ho = a.ooff + h * HD, hdq = a.dqoff + h * HD;
+    const int ntot = a.k.n + a.extra;
+
+    stage_rows<NT, 64 * NW>(sK, K, a.ldk, hk, a, a.k, b, g, ntot, tid);
+    stage_rows<NT, 64 * NW>(sV, V, a.ldv, hv, a, a.k, b, g, ntot, tid);
+    stage_rows_t<NT, 64 * NW>(sKt, K, a.ldk, hk, a, a.k, b, g, ntot, tid);
+    __syncthreads();
+
+    const int nqt = (a.q.n + 15) >> 4;
+    const int t0 = blockIdx.x * tiles_per_wg;
+    const int t1 = min(nqt, t0 + tiles_per_wg);
+    for (int qt = t0 + w; qt < t1; qt += NW) {
+        const int q = qt * 16 + fr;
+        const bool qv = q < a.q.n;
+        const long long qrow = qv ? rs_row(a.q, b, g, q) : 0;
+        const bf16x8_t q0 = ld_frag_global(Q + qrow * a.ldq + hq + fg * 8, qv);
+        const bf16x8_t q1 = ld_frag_global(Q + qrow * a.ldq + hq + 32 + fg * 8, qv);
+        const bf16x8_t g0 = ld_frag_global(dO + qrow * a.ldo + ho + fg * 8, qv);
+        const bf16x8_t g1 = ld_frag_global(dO + qrow * a.ldo + ho + 32 + fg * 8, qv);
+        const bf16x8_t o0 = ld_frag_global(O + qrow * a.ldo + ho + fg * 8, qv);
+        const bf16x8_t o1 = ld_frag_global(O + qrow * a.ldo + ho + 32 + fg * 8, qv);
+        float dl = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += (float)g0[e] * (float)o0[e] + (float)g1[e] * (float)o1[e];
+        dl = grp_sum(dl);
+        const float lse = qv ? a.lse[qrow * a.H + h] : 0.f;
+        if (qv && fg == 0) a.delta[qrow * a.H + h] = dl;
+
+        bf16x8_t dsf[NT / 2];
+#pragma unroll
+        for (int kk = 0; kk < NT / 2; ++kk) {
+            f32x4_t pr[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int t = 2 * kk + u;
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sK, t * 16 + fr, 0, fg), q0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sK, t * 16 + fr, 1, fg), q1, acc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sV, t * 16 + fr, 0, fg), g0, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sV, t * 16 + fr, 1, fg), g1, dp, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = t * 16 + fg * 4 + r;
+                    float v = acc[r] * a.scale;
+                    if (a.mask && key >= a.extra && key < ntot) v += a.mask[(long long)b * a.mask_ld + key - a.extra];
+                    const float pj = key < ntot ? __expf(v - lse) : 0.f;
+                    acc[r] = pj * (dp[r] - dl);
+                }
+                pr[u] = acc;
+            }
+            dsf[kk] = pack8(pr[0], pr[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x4_t o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < NT / 2; ++kk) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_t<NT>(sKt, dt * 16 + fr, kk, fg), dsf[kk], o[dt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (qv) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                st_bf16x4(dQ + qrow * a.lddq + hdq + dt * 16 + fg * 4, o[dt][0] * a.scale, o[dt][1] * a.scale, o[dt][2] * a.scale,
+                          o[dt][3] * a.scale);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, key-owned: dK, dV.  own = keys (no extra), other = queries [extra CLS query ; row set], NT query tiles.
+// ------------------------------------------------------------------------------------------------
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_dkv_mfma_kernel(const AttnArgs a, int tiles_per_wg) {
+    constexpr int VP = vt_pitch(NT);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sQ = smem;                        // [NT*16][RP]
+    unsigned char* sG = sQ + NT * 16 * RP;           // dO rows
+    unsigned char* sQt = sG + NT * 16 * RP;          // [64][VP]
+    unsigned char* sGt = sQt + 64 * VP;              // [64][VP]
+    float* sL = reinterpret_cast<float*>(sGt + 64 * VP);   // [NT*16] lse
+    float* sD = sL + NT * 16;                        // [NT*16] delta
+
+    const int tid = threadIdx.x, lane = tid & 63, w = wave_id();
+    const int fr = lane & 15, fg = lane >> 4;
+    const int p = blockIdx.y, b = p / a.G, g = p % a.G, h = blockIdx.z;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.Q);
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.K);
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.V);
+    const bf16_t* dO = reinterpret_cast<const bf16_t*>(a.dO);
+    bf16_t* dK = reinterpret_cast<bf16_t*>(a.dK);
+    bf16_t* dV = reinterpret_cast<bf16_t*>(a.dV);
+    const int hq = a.qoff + h * HD, hk = a.koff + h * HD, hv = a.voff + h * HD, ho = a.ooff + h * HD;
+    const int hdk = a.dkoff + h * HD, hdv = a.dvoff + h * HD;
+    const int ntot = a.q.n + a.extra;                // queries incl. the extra CLS query
+
+    stage_rows<NT, 64 * NW>(sQ, Q, a.ldq, hq, a, a.q, b, g, ntot, tid);
+    stage_rows<NT, 64 * NW>(sG, dO, a.ldo, ho, a, a.q, b, g, ntot, tid);
+    stage_rows_t<NT, 64 * NW>(sQt, Q, a.ldq, hq, a, a.q, b, g, ntot, tid);
+    stage_rows_t<NT, 64 * NW>(sGt, dO, a.ldo, ho, a, a.q, b, g, ntot, tid);
+    for (int i = tid; i < NT * 16; i += 64 * NW) {
+        float l = INFINITY, d = 0.f;                 // padded query rows: exp(s - inf) = 0
+        if (i < ntot) {
+            const long long row = other_row(a, a.q, b, g, i);
+            l = a.lse[row * a.H + h];
+            d = a.delta[row * a.H + h];
+        }
+        sL[i] = l;
+        sD[i] = d;
+    }
+    __syncthreads();
+
+    const int nkt = (a.k.n + 15) >> 4;
+    const int t0 = blockIdx.x * tiles_per_wg;
+    const int t1 = min(nkt, t0 + tiles_per_wg);
+    for (int kt = t0 + w; kt < t1; kt += NW) {
+        const int key = kt * 16 + fr;
+        const bool kv = key < a.k.n;
+        const long long krow = kv ? rs_row(a.k, b, g, key) : 0;
+        const bf16x8_t k0 = ld_frag_global(K + krow * a.ldk + hk + fg * 8, kv);
+        const bf16x8_t k1 = ld_frag_global(K + krow * a.ldk + hk + 32 + fg * 8, kv);
+        const bf16x8_t v0 = ld_frag_global(V + krow * a.ldv + hv + fg * 8, kv);
+        const bf16x8_t v1 = ld_frag_global(V + krow * a.ldv + hv + 32 + fg * 8, kv);
+        float mk = 0.f;
+        if (a.mask && kv) mk = a.mask[(long long)b * a.mask_ld + key];
+        bf16x8_t pf[NT / 2], df[NT / 2];
+#pragma unroll
+        for (int kk = 0; kk < NT / 2; ++kk) {
+            f32x4_t pr[2], dr[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int t = 2 * kk + u;
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sQ, t * 16 + fr, 0, fg), k0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sQ, t * 16 + fr, 1, fg), k1, acc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sG, t * 16 + fr, 0, fg), v0, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sG, t * 16 + fr, 1, fg), v1, dp, 0, 0, 0);
+                const f32x4_t lse = *reinterpret_cast<const f32x4_t*>(sL + t * 16 + fg * 4);
+                const f32x4_t dl = *reinterpret_cast<const f32x4_t*>(sD + t * 16 + fg * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pj = kv ? __expf(acc[r] * a.scale + mk - lse[r]) : 0.f;
+                    acc[r] = pj;
+                    dp[r] = pj * (dp[r] - dl[r]);
+                }
+                pr[u] = acc;
+                dr[u] = dp;
+            }
+            pf[kk] = pack8(pr[0], pr[1]);
+            df[kk] = pack8(dr[0], dr[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x4_t ov[4], ok[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) ov[dt] = ok[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < NT / 2; ++kk) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                ov[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_t<NT>(sGt, dt * 16 + fr, kk, fg), pf[kk], ov[dt], 0, 0, 0);
+                ok[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_t<NT>(sQt, dt * 16 + fr, kk, fg), df[kk], ok[dt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kv) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                st_bf16x4(dV + krow * a.lddv + hdv + dt * 16 + fg * 4, ov[dt][0], ov[dt][1], ov[dt][2], ov[dt][3]);
+                st_bf16x4(dK + krow * a.lddk + hdk + dt * 16 + fg * 4, ok[dt][0] * a.scale, ok[dt][1] * a.scale, ok[dt][2] * a.scale,
+                          ok[dt][3] * a.scale);
+            }
+        }
+    }
+}
+
+template <int NT> constexpr size_t fwd_lds() { return (size_t)NT * 16 * RP + 64 * vt_pitch(NT); }
+template <int NT> constexpr size_t dq_lds() { return (size_t)2 * NT * 16 * RP + 64 * vt_pitch(NT); }
+template <int NT> constexpr size_t dkv_lds() { return (size_t)2 * NT * 16 * RP + 2 * 64 * vt_pitch(NT) + 2 * NT * 16 * 4; }
+
+template <typename KFn>
+static void set_lds(KFn k, size_t bytes) {
+    if (bytes > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+}  // namespace egv
+using namespace egv;
+
+static bool aligned_ok(const AttnArgs& a) {
+    auto ok8 = [](int x) { return (x % 8) == 0; };
+    return ok8(a.ldq) && ok8(a.ldk) && ok8(a.ldv) && ok8(a.ldo) && ok8(a.qoff) && ok8(a.koff) && ok8(a.voff) && ok8(a.ooff);
+}
+
+// own tiles per workgroup: all of them for small problems, chunks of 16 for long own sides (cross attention)
+static inline void own_split(int n_own, int& nw, int& tpw, int& chunks) {
+    const int tiles = (n_own + 15) / 16;
+    nw = tiles >= 4 ? 4 : (tiles >= 2 ? 2 : 1);
+    tpw = tiles <= 16 ? tiles : 16;
+    chunks = (tiles + tpw - 1) / tpw;
+}
+
+#define EGV_MFMA_LAUNCH(KERNEL, LDSFN, NTV)                                                                  \
+    do {                                                                                                     \
+        const size_t lds = LDSFN<NTV>();                                                                     \
+        dim3 grid(chunks, B * a.G, a.H);                                                                     \
+        if (nw == 4) { set_lds(KERNEL<NTV, 4>, lds); hipLaunchKernelGGL((KERNEL<NTV, 4>), grid, dim3(256), lds, st, a, tpw); } \
+        else if (nw == 2) { set_lds(KERNEL<NTV, 2>, lds); hipLaunchKernelGGL((KERNEL<NTV, 2>), grid, dim3(128), lds, st, a, tpw); } \
+        else { set_lds(KERNEL<NTV, 1>, lds); hipLaunchKernelGGL((KERNEL<NTV, 1>), grid, dim3(64), lds, st, a, tpw); } \
+    } while (0)
+
+int egv_attn_fwd_mfma(const AttnArgs& a, int B, hipStream_t st) {
+    const int ntot = a.k.n + a.extra;
+    if (!aligned_ok(a) || ntot > 224) return 0;
+    int nw, tpw, chunks;
+    own_split(a.q.n, nw, tpw, chunks);
+    if (ntot <= 32) EGV_MFMA_LAUNCH(attn_fwd_mfma_kernel, fwd_lds, 2);
+    else if (ntot <= 64) EGV_MFMA_LAUNCH(attn_fwd_mfma_kernel, fwd_lds, 4);
+    else EGV_MFMA_LAUNCH(attn_fwd_mfma_kernel, fwd_lds, 14);
+    return 1;
+}
+
+int egv_attn_dq_mfma(const AttnArgs& a, int B, hipStream_t st) {
+    const int ntot = a.k.n + a.extra;
+    if (!aligned_ok(a) || (a.lddq % 4) || (a.dqoff % 4) || ntot > 224) return 0;
+    int nw, tpw, chunks;
+    own_split(a.q.n, nw, tpw, chunks);
+    if (ntot <= 32) EGV_MFMA_LAUNCH(attn_dq_mfma_kernel, dq_lds, 2);
+    else if (ntot <= 64) EGV_MFMA_LAUNCH(attn_dq_mfma_kernel, dq_lds, 4);
+    else EGV_MFMA_LAUNCH(attn_dq_mfma_kernel, dq_lds, 14);
+    return 1;
+}
+
+int egv_attn_dkv_mfma(const AttnArgs& a, int B, hipStream_t st) {
+    const int ntot = a.q.n + a.extra;
+    if (!aligned_ok(a) || (a.lddk % 4) || (a.lddv % 4) || (a.dkoff % 4) || (a.dvoff % 4) || ntot > 224) return 0;
+    int nw, tpw, chunks;
+    own_split(a.k.n, nw, tpw, chunks);
+    if (ntot <= 32) EGV_MFMA_LAUNCH(attn_dkv_mfma_kernel, dkv_lds, 2);
+    else if (ntot <= 64) EGV_MFMA_LAUNCH(attn_dkv_mfma_kernel, dkv_lds, 4);
+    else EGV_MFMA_LAUNCH(attn_dkv_mfma_kernel, dkv_lds, 14);
+    return 1;
+}

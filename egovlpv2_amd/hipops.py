@@ -356,6 +356,16 @@ def _dkv_ws(B, G, H, k_n, nsplit, device):
     return (workspace(nb, device, slot=1), nb) if nb else (None, 0)
 
 
+def _split_ws(which, B, G, H, n_own, nsplit, device):
+    nb = lib.egv_attn_split_workspace_bytes(which, B, G, H, n_own, nsplit)
+    return (workspace(nb, device, slot=1), nb) if nb else (None, 0)
+
+
+def _nsplit_for(n_other):
+    """split count for launches whose other side is too long for one workgroup / the MFMA kernels (<= 224 rows)"""
+    return 1 if n_other <= 224 else max(2, min(32, n_other // 96))
+
+
 class DividedAttnFn(Function):
     """Divided space / time attention core of VarAttention (video_transformer.py:121-150) on the fused qkv buffer
     [B*S, 3*D]: CLS query over all S keys, patch queries over [CLS ; own frame | own patch column]."""
@@ -378,7 +388,10 @@ class DividedAttnFn(Function):
         dt = _dt(qkv)
         d1 = _mk_desc(Q, K, V, O, lse, B, G, H, gset, gset, (S, 0), scale)
         check(lib.egv_attn_fwd(dt, C.byref(d1), _st()), 'egv_attn_fwd(groups)')
-        d2 = _mk_desc(Q, K, V, O, lse, B, 1, H, _rowset(S, 0, 0, 1, 1), _rowset(S, 0, 0, 1, S), None, scale)
+        ns = _nsplit_for(S)
+        ws, nb = _split_ws(0, B, 1, H, 1, ns, qkv.device)
+        d2 = _mk_desc(Q, K, V, O, lse, B, 1, H, _rowset(S, 0, 0, 1, 1), _rowset(S, 0, 0, 1, S), None, scale, nsplit=ns, ws=ws,
+                      ws_bytes=nb)
         check(lib.egv_attn_fwd(dt, C.byref(d2), _st()), 'egv_attn_fwd(cls)')
         ctx.cfg = (B, Fr, N, H, mode)
         ctx.save_for_backward(qkv, O, lse)
@@ -406,12 +419,14 @@ class DividedAttnFn(Function):
         kw = dict(dO=dO, dQ=dQ, dK=dK, dV=dV, delta=delta)
         d1 = _mk_desc(Q, K, V, O, lse, B, G, H, gset, gset, (S, 0), scale, **kw)
         check(lib.egv_attn_bwd_dq(dt, C.byref(d1), _st()), 'egv_attn_bwd_dq(groups)')
-        d2 = _mk_desc(Q, K, V, O, lse, B, 1, H, cls1, allS, None, scale, **kw)
+        ns = _nsplit_for(S)
+        ws, nb = _split_ws(1, B, 1, H, 1, ns, qkv.device)
+        d2 = _mk_desc(Q, K, V, O, lse, B, 1, H, cls1, allS, None, scale, nsplit=ns, ws=ws, ws_bytes=nb, **kw)
         check(lib.egv_attn_bwd_dq(dt, C.byref(d2), _st()), 'egv_attn_bwd_dq(cls)')
         # key-owned: group keys <- [CLS query ; group queries];  CLS key <- all S queries (split + reduce)
         d3 = _mk_desc(Q, K, V, O, lse, B, G, H, gset, gset, (S, 0), scale, **kw)
         check(lib.egv_attn_bwd_dkv(dt, C.byref(d3), _st()), 'egv_attn_bwd_dkv(groups)')
-        nsplit = max(1, min(32, S // 64))
+        nsplit = _nsplit_for(S)
         ws, nb = _dkv_ws(B, 1, H, 1, nsplit, qkv.device)
         d4 = _mk_desc(Q, K, V, O, lse, B, 1, H, allS, cls1, None, scale, nsplit=nsplit, ws=ws, ws_bytes=nb, **kw)
         check(lib.egv_attn_bwd_dkv(dt, C.byref(d4), _st()), 'egv_attn_bwd_dkv(cls)')
@@ -435,7 +450,10 @@ class PlainAttnFn(Function):
             assert t.dim() == 2 and t.stride(1) == 1 and t.shape[1] == D
         O = torch.empty(B * nq, D, dtype=q.dtype, device=q.device)
         lse = torch.empty(B * nq, H, dtype=torch.float32, device=q.device)
-        d = _mk_desc(q, k, v, O, lse, B, 1, H, _rowset(nq, 0, 0, 1, nq), _rowset(nk, 0, 0, 1, nk), None, scale, mask=mask)
+        ns = _nsplit_for(nk)
+        ws, nb = _split_ws(0, B, 1, H, nq, ns, q.device)
+        d = _mk_desc(q, k, v, O, lse, B, 1, H, _rowset(nq, 0, 0, 1, nq), _rowset(nk, 0, 0, 1, nk), None, scale, mask=mask,
+                     nsplit=ns, ws=ws, ws_bytes=nb)
         check(lib.egv_attn_fwd(_dt(q), C.byref(d), _st()), 'egv_attn_fwd')
         ctx.cfg = (B, H, nq, nk, scale, dkv_nsplit)
         ctx.save_for_backward(q, k, v, O, lse, mask)
@@ -452,10 +470,14 @@ class PlainAttnFn(Function):
         dv = torch.empty(B * nk, D, dtype=q.dtype, device=q.device)
         delta = torch.empty(B * nq, H, dtype=torch.float32, device=q.device)
         qs, ks = _rowset(nq, 0, 0, 1, nq), _rowset(nk, 0, 0, 1, nk)
-        ws, nb = _dkv_ws(B, 1, H, nk, nsplit, q.device)
-        d = _mk_desc(q, k, v, O, lse, B, 1, H, qs, ks, None, scale, mask=mask, dO=dO, dQ=dq, dK=dk, dV=dv, delta=delta,
-                     nsplit=nsplit, ws=ws, ws_bytes=nb)
+        kw = dict(mask=mask, dO=dO, dQ=dq, dK=dk, dV=dv, delta=delta)
+        ns = _nsplit_for(nk)
+        ws, nb = _split_ws(1, B, 1, H, nq, ns, q.device)
+        d = _mk_desc(q, k, v, O, lse, B, 1, H, qs, ks, None, scale, nsplit=ns, ws=ws, ws_bytes=nb, **kw)
         check(lib.egv_attn_bwd_dq(_dt(q), C.byref(d), _st()), 'egv_attn_bwd_dq')
+        nsplit = max(nsplit, _nsplit_for(nq))
+        ws, nb = _dkv_ws(B, 1, H, nk, nsplit, q.device)
+        d = _mk_desc(q, k, v, O, lse, B, 1, H, qs, ks, None, scale, nsplit=nsplit, ws=ws, ws_bytes=nb, **kw)
         check(lib.egv_attn_bwd_dkv(_dt(q), C.byref(d), _st()), 'egv_attn_bwd_dkv')
         return dq, dk, dv, None, None, None, None, None, None, None
 

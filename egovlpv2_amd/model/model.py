@@ -179,8 +179,7 @@ class FrozenInTime(nn.Module):
             s = self._lin(s_ctx, a + '.proj')
             kv = self._lin(y, a + '.qkv_text_i2t')                                    # (B*L, 2D) = [k | v]   (:159-164)
             q = self._lin(self._ln(s, a + '.norm_i2t_i', c.eps_video), a + '.qkv_i2t')
-            o = ops.plain_attention(q, kv[:, :c.dim], kv[:, c.dim:], B, H, c.seq, L, c.head_dim ** -0.5, mask=y_mask,
-                                    dkv_nsplit=max(1, min(32, c.seq // 64)))
+            o = ops.plain_attention(q, kv[:, :c.dim], kv[:, c.dim:], B, H, c.seq, L, c.head_dim ** -0.5, mask=y_mask)
             # x + (s + alpha * proj_i2t(o))   (:185, :222)
             sr = self._lin(o, a + '.proj_i2t', gate=self.p(a + '.alpha_i2t'), res1=s, res2=x)
         return ops.mlp(self._ln(sr, pfx + '.norm2', c.eps_video), self.p(pfx + '.mlp.fc1.weight'), self.p(pfx + '.mlp.fc1.bias'),

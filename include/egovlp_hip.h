@@ -100,8 +100,13 @@ typedef struct egv_attn_desc {
     int extra; long long extra_bs, extra_row;
     float scale;
     const float* mask; int mask_ld;
-    int nsplit; float* ws; long long ws_bytes;   /* dkv only: split of the query loop, fp32 partial slabs */
+    int nsplit; float* ws; long long ws_bytes;   /* split of the other-side loop, fp32 partial slabs */
 } egv_attn_desc;
+/* nsplit > 1 splits the OTHER side of a launch across workgroups (fp32 partials in ws, combined in a fixed order):
+ * needed when one own row meets thousands of other rows (CLS query/key over all S tokens, text<->video cross attention).
+ * which = 0 fwd, 1 dq, 2 dkv; n_own = q_n (fwd, dq) or k_n (dkv).  With nsplit == 1 and dtype == EGV_BF16, problems whose
+ * other side has <= 224 rows run on the MFMA kernels (csrc/egv_attn_mfma.hip). */
+long long egv_attn_split_workspace_bytes(int which, int B, int G, int H, int n_own, int nsplit);
 int egv_attn_fwd(int dtype, const egv_attn_desc* d, void* stream);
 int egv_attn_bwd_dq(int dtype, const egv_attn_desc* d, void* stream);
 long long egv_attn_bwd_dkv_workspace_bytes(int B, int G, int H, int k_n, int nsplit);
