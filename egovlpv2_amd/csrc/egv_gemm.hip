@@ -17,39 +17,13 @@
 // (v_mfma_f32_16x16x32_bf16 / exact-fp32 v_mfma_f32_16x16x4_f32), fp32 accumulation.
 // Operands are swapped in the MFMA (D = W_frag * X_frag^T) so that every lane owns 4 consecutive
 // output columns of one row: bias / residual / aux loads and the store are 8-16 B vectors.
-#include "egv_common.h"
+#include "egv_gemm.h"
 
 namespace egv {
 
 constexpr int BM = 128, BN = 128;
 constexpr int PITCH = 144;          // bytes per LDS row: 128 B of K + 16 B pad
 constexpr int ROWB = 128;           // payload bytes per LDS row
-
-struct GemmEpi {
-    const float* bias;   // [N] fp32 or null
-    const float* gate;   // device scalar (alpha gate) or null
-    const void* res1;    // [M,N] T or null
-    const void* res2;    // [M,N] T or null
-    void* pre;           // [M,N] T: save (acc + bias) before activation, or null
-    const void* aux;     // [M,N] T: operand of the activation derivative (backward), or null
-    int act;             // 0 none, 1 gelu(erf), 2 relu, 3 tanh
-    int dact;            // 0 none, 1 gelu'(aux = pre-activation), 2 relu'(aux = output), 3 tanh'(aux = output)
-    int ldr;             // leading dim of res1/res2/pre/aux
-    float scale;         // host scalar applied to the accumulator first
-};
-
-struct GemmArgs {
-    const void* A;
-    const void* B;
-    void* C;
-    int M, N, K;
-    int lda, ldb, ldc;
-    int a_vec_ok, b_vec_ok, c_vec_ok;   // 16-byte vector path allowed (pointer + leading dim aligned)
-    int k_per_split;                    // K range per blockIdx.z (== K when not split)
-    long long slab_stride;              // elements between split slabs of C
-    int tiles_m, tiles_n;
-    GemmEpi e;
-};
 
 template <typename T> struct Tile;
 template <> struct Tile<bf16_t> { static constexpr int BK = 64; };
@@ -201,19 +175,6 @@ template <> struct Mma<float> {
     }
 };
 
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == 1) return gelu_f(v);
-    if (act == 2) return fmaxf(v, 0.0f);
-    if (act == 3) return tanhf(v);
-    return v;
-}
-__device__ __forceinline__ float apply_dact(float aux, int dact) {
-    if (dact == 1) return dgelu_f(aux);
-    if (dact == 2) return aux > 0.0f ? 1.0f : 0.0f;
-    if (dact == 3) return 1.0f - aux * aux;
-    return 1.0f;
-}
-
 template <typename T, int AT, int BT, typename OutT>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     constexpr int BK = Tile<T>::BK;
@@ -264,15 +225,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     }
 
     // ---------------- epilogue ----------------
-    const GemmEpi& e = g.e;
     OutT* C = reinterpret_cast<OutT*>(g.C) + (size_t)blockIdx.z * g.slab_stride;
-    const T* R1 = reinterpret_cast<const T*>(e.res1);
-    const T* R2 = reinterpret_cast<const T*>(e.res2);
-    const T* AUX = reinterpret_cast<const T*>(e.aux);
-    T* PRE = reinterpret_cast<T*>(e.pre);
-    const float gate = e.gate ? *e.gate : 1.0f;
+    const float gate = g.e.gate ? *g.e.gate : 1.0f;
     const int fr = lane & 15, fg = lane >> 4;
-    const bool rvec = (e.ldr & 3) == 0;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int m = m0 + wm * 64 + mi * 16 + fr;
@@ -281,60 +236,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
         for (int ni = 0; ni < 4; ++ni) {
             const int n = n0 + wn * 64 + ni * 16 + fg * 4;
             if (n >= g.N) continue;
-            float v[4] = {acc[mi][ni][0] * e.scale, acc[mi][ni][1] * e.scale, acc[mi][ni][2] * e.scale, acc[mi][ni][3] * e.scale};
-            const bool full = (n + 3 < g.N);
-            const size_t ro = (size_t)m * e.ldr + n;
-            if (e.bias) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (full || n + r < g.N) v[r] += e.bias[n + r];
-            }
-            if (PRE) {
-                if (full && rvec) st4(PRE + ro, v);
-                else
-                    for (int r = 0; r < 4; ++r)
-                        if (n + r < g.N) Elem<T>::st(PRE + ro + r, v[r]);
-            }
-            if (e.act) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], e.act);
-            }
-            if (e.gate) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= gate;
-            }
-            if (R1) {
-                float x[4] = {0.f, 0.f, 0.f, 0.f};
-                if (full && rvec) ld4(R1 + ro, x);
-                else
-                    for (int r = 0; r < 4; ++r)
-                        if (n + r < g.N) x[r] = Elem<T>::ld(R1 + ro + r);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += x[r];
-            }
-            if (R2) {
-                float x[4] = {0.f, 0.f, 0.f, 0.f};
-                if (full && rvec) ld4(R2 + ro, x);
-                else
-                    for (int r = 0; r < 4; ++r)
-                        if (n + r < g.N) x[r] = Elem<T>::ld(R2 + ro + r);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += x[r];
-            }
-            if (e.dact) {
-                float x[4] = {0.f, 0.f, 0.f, 0.f};
-                if (full && rvec) ld4(AUX + ro, x);
-                else
-                    for (int r = 0; r < 4; ++r)
-                        if (n + r < g.N) x[r] = Elem<T>::ld(AUX + ro + r);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= apply_dact(x[r], e.dact);
-            }
-            const size_t co = (size_t)m * g.ldc + n;
-            if (full && g.c_vec_ok) st4(C + co, v);
-            else
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < g.N) Elem<OutT>::st(C + co + r, v[r]);
+            float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+            gemm_epilogue4<T, OutT>(g, C, m, n, v, gate);
         }
     }
 }
@@ -392,6 +295,11 @@ extern "C" int egv_gemm(int dtype, int a_trans, int b_trans, int M, int N, int K
     g.e.act = act; g.e.dact = dact; g.e.ldr = ldr ? ldr : ldc; g.e.scale = scale;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     void* ph = egv_prof_begin(stream);
+    if (dtype == EGV_BF16 && egv_gemm2_launch(g, a_trans, b_trans, out_f32, 1, st)) {
+        egv_prof_end(ph, stream, 2.0 * M * N * K, 8 + (b_trans ? 1 : 0));
+        EGV_LAUNCH_CHECK();
+        return 0;
+    }
 #define EGV_DISPATCH(TT)                                                                   \
     if (!a_trans && !b_trans) {                                                            \
         if (out_f32) launch_gemm<TT, 0, 0, float>(g, 1, st); else launch_gemm<TT, 0, 0, TT>(g, 1, st); \
@@ -407,11 +315,19 @@ extern "C" int egv_gemm(int dtype, int a_trans, int b_trans, int M, int N, int K
     return 0;
 }
 
-extern "C" long long egv_gemm_wgrad_workspace_bytes(int N, int K, int M) {
-    // slabs of fp32 [N,K]; split count chosen by egv_gemm_wgrad
-    const int tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
+static inline int wgrad_splits(int tiles, int M) {
     int nz = 1;
-    while (tiles * nz < 512 && nz < 32 && M / (nz * 2) >= 512) nz *= 2;
+    while (tiles * nz < 512 && nz < 64 && M / (nz * 2) >= 512) nz *= 2;
+    return nz;
+}
+
+static inline bool wgrad_use_gemm2(int dtype, int M, int N, int K) { return dtype == EGV_BF16 && N >= 128 && K >= 64 && M >= 256; }
+
+extern "C" long long egv_gemm_wgrad_workspace_bytes(int N, int K, int M) {
+    // slabs of fp32 [N,K]; upper bound over both kernel paths
+    const int t1 = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
+    const int t2 = ((N + 255) / 256) * ((K + 127) / 128);
+    const int nz = max(wgrad_splits(t1, M), wgrad_splits(t2, M));
     return (long long)nz * N * K * 4;
 }
 
@@ -421,9 +337,15 @@ extern "C" int egv_gemm_wgrad(int dtype, int M, int N, int K, const void* dY, in
                               void* stream) {
     EGV_CHECK(dtype == EGV_F32 || dtype == EGV_BF16, "egv_gemm_wgrad: bad dtype %d", dtype);
     EGV_CHECK(M > 0 && N > 0 && K > 0, "egv_gemm_wgrad: bad shape");
-    const int tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
-    int nz = 1;
-    while (tiles * nz < 512 && nz < 32 && M / (nz * 2) >= 512) nz *= 2;
+    const bool v2 = wgrad_use_gemm2(dtype, M, N, K);
+    int tiles;
+    if (v2) {
+        const int ta = ((N + 255) / 256) * ((K + 255) / 256), tb = ((N + 255) / 256) * ((K + 127) / 128);
+        tiles = (ta >= 256) ? ta : tb;
+    } else {
+        tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
+    }
+    int nz = wgrad_splits(tiles, M);
     const int bk = dtype == EGV_BF16 ? 64 : 32;
     int kper = (M + nz - 1) / nz;
     kper = ((kper + bk - 1) / bk) * bk;
@@ -451,9 +373,13 @@ extern "C" int egv_gemm_wgrad(int dtype, int M, int N, int K, const void* dY, in
         g.e.scale = 1.0f;
     }
     void* ph = egv_prof_begin(stream);
-    if (dtype == EGV_BF16) launch_gemm<bf16_t, 1, 1, float>(g, nz, st);
-    else launch_gemm<float, 1, 1, float>(g, nz, st);
-    egv_prof_end(ph, stream, 2.0 * M * N * K, (dtype == EGV_BF16 ? 0 : 4) + 2);
+    if (v2 && egv_gemm2_launch(g, 1, 1, 1, nz, st)) {
+        egv_prof_end(ph, stream, 2.0 * M * N * K, 10);
+    } else {
+        if (dtype == EGV_BF16) launch_gemm<bf16_t, 1, 1, float>(g, nz, st);
+        else launch_gemm<float, 1, 1, float>(g, nz, st);
+        egv_prof_end(ph, stream, 2.0 * M * N * K, (dtype == EGV_BF16 ? 0 : 4) + 2);
+    }
     EGV_LAUNCH_CHECK();
     if (nz > 1) {
         const long long n = (long long)N * K;

@@ -1,0 +1,226 @@
+// 256-row MFMA GEMM for gfx950 (bf16 storage, fp32 accumulate): the throughput path for the large Linear layers of the
+// EgoVLPv2 hot path (M = B*S = 25 096 tokens).
+//
+// Differences from the generic 128x128 kernel (egv_gemm.hip):
+//   * 512-thread workgroups (8 waves), 256x256 or 256x128 output tiles, K step 64;
+//   * operands that are K-contiguous in memory are staged by the DMA path: global_load_lds_dwordx4 (16 B per lane, 1 KiB per
+//     wave instruction) straight into LDS, no VGPR round trip;  the LDS image is linear (the DMA writes lane-linear) and the
+//     bank-conflict-free XOR swizzle (16-byte chunk c of row r lives at chunk c ^ (r & 7)) is applied on the per-lane SOURCE
+//     address and again on the fragment read (cdna_hip_programming.md rule 21);
+//   * operands whose reduction index is the slow (row) index (both operands of wgrad) go global -> VGPR -> 8x8 bf16 block
+//     transpose -> ds_write_b128 into the SAME swizzled image, so the MFMA loop is shared;
+//   * two LDS stages: the loads of K-tile t+1 are in flight while tile t feeds the matrix cores, one barrier per K step.
+// Ragged edges: rows beyond M/N are clamped on load (their products are never stored); the reduction tail of wgrad is
+// zero-filled; direct operands require K % 64 == 0 (true for every Linear of the model), otherwise the caller falls back.
+#include "egv_gemm.h"
+
+namespace egv {
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int WGM_, int WGN_, int MI_, int NI_>
+struct Cfg {
+    static constexpr int WGM = WGM_, WGN = WGN_, MI = MI_, NI = NI_;
+    static constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
+    static constexpr int STAGE = (BM + BN) * 128;      // bytes per LDS stage (rows of 64 bf16)
+};
+using CfgA = Cfg<2, 4, 8, 4>;   // 256 x 256
+using CfgB = Cfg<4, 2, 4, 4>;   // 256 x 128
+
+// ---- DMA staging of a K-contiguous operand tile: ROWS rows x 128 B into s (swizzled) ----
+template <int ROWS>
+__device__ __forceinline__ void stage_dma(const bf16_t* base, int rows_total, int ld, int row0, int k0, unsigned char* s,
+                                          int wave, int lane) {
+    const int rl = lane >> 3;
+    const int c = (lane & 7) ^ rl;
+#pragma unroll
+    for (int p = wave; p < ROWS / 8; p += 8) {
+        const int gr = min(row0 + p * 8 + rl, rows_total - 1);
+        const bf16_t* src = base + (size_t)gr * ld + k0 + c * 8;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s + p * 1024), 16, 0, 0);
+    }
+}
+
+// ---- register staging of a transposed operand (stored [reduction, rows]): one 8x8 unit per thread ----
+struct TUnit {
+    u32x4_t r[8];
+};
+
+template <int ROWS>
+__device__ __forceinline__ void tload(TUnit& u, const bf16_t* base, int rows_total, int ld, int row0, int k0, int kend, int unit,
+                                      bool vec_ok) {
+    constexpr int RB = ROWS / 8;
+    const int kb = unit / RB, rb = unit % RB;
+    const int grow0 = row0 + rb * 8;
+    const int nv_rows = rows_total - grow0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int gk = k0 + kb * 8 + j;
+        u32x4_t x = {0u, 0u, 0u, 0u};
+        if (gk < kend && nv_rows > 0) {
+            const bf16_t* p = base + (size_t)gk * ld + grow0;
+            if (nv_rows >= 8 && vec_ok) {
+                x = *reinterpret_cast<const u32x4_t*>(p);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (e < nv_rows) x[e >> 1] |= ((unsigned int)reinterpret_cast<const unsigned short*>(p)[e]) << ((e & 1) * 16);
+            }
+        }
+        u.r[j] = x;
+    }
+}
+
+template <int ROWS>
+__device__ __forceinline__ void tstore(const TUnit& u, unsigned char* s, int unit) {
+    constexpr int RB = ROWS / 8;
+    const int kb = unit / RB, rb = unit % RB;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        u32x4_t o;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const unsigned int a = u.r[2 * d][e >> 1], b = u.r[2 * d + 1][e >> 1];
+            o[d] = (e & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+        }
+        // row rb*8+e, logical chunk kb -> physical chunk kb ^ (row & 7) = kb ^ e
+        *reinterpret_cast<u32x4_t*>(s + (rb * 8 + e) * 128 + ((kb ^ e) * 16)) = o;
+    }
+}
+
+template <typename CFG, int AT, int BT, typename OutT>
+__global__ __launch_bounds__(512) void gemm2_kernel(const GemmArgs g) {
+    constexpr int BM = CFG::BM, BN = CFG::BN, MI = CFG::MI, NI = CFG::NI;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 stages
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = wave_id();
+    const int wm = wave / CFG::WGN, wn = wave % CFG::WGN;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    const int ntile = g.tiles_m * g.tiles_n;
+    const int t = xcd_remap(blockIdx.x, ntile);
+    const int tm = t / g.tiles_n, tn = t % g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = blockIdx.z * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A);
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B);
+
+    f32x4_t acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // transposed-operand unit assignment: A units on threads [0, BM), B units on threads [BM, BM+BN) when both are
+    // transposed; a single transposed operand uses threads [0, rows)
+    const int unitA = tid;
+    const int unitB = (AT && BT) ? tid - BM : tid;
+    const bool hasA = AT && unitA < BM;
+    const bool hasB = BT && unitB >= 0 && unitB < BN;
+    TUnit ua, ub;
+
+    auto issue = [&](int k0, int stage) {
+        unsigned char* sA = smem + stage * CFG::STAGE;
+        unsigned char* sB = sA + BM * 128;
+        if constexpr (!AT) stage_dma<BM>(A, g.M, g.lda, m0, k0, sA, wave, lane);
+        else if (hasA) tload<BM>(ua, A, g.M, g.lda, m0, k0, kend, unitA, g.a_vec_ok != 0);
+        if constexpr (!BT) stage_dma<BN>(B, g.N, g.ldb, n0, k0, sB, wave, lane);
+        else if (hasB) tload<BN>(ub, B, g.N, g.ldb, n0, k0, kend, unitB, g.b_vec_ok != 0);
+    };
+    auto commit = [&](int stage) {      // write register-staged operands of the tile issued last
+        unsigned char* sA = smem + stage * CFG::STAGE;
+        unsigned char* sB = sA + BM * 128;
+        if constexpr (AT) { if (hasA) tstore<BM>(ua, sA, unitA); }
+        if constexpr (BT) { if (hasB) tstore<BN>(ub, sB, unitB); }
+    };
+
+    issue(kbeg, 0);
+    commit(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int stage = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += 64) {
+        const bool more = k0 + 64 < kend;
+        if (more) issue(k0 + 64, stage ^ 1);
+        const unsigned char* sA = smem + stage * CFG::STAGE;
+        const unsigned char* sB = sA + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t b[NI];
+            const int co = (((ks * 4 + fg) ^ (fr & 7)) * 16);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(sB + (wn * NI * 16 + j * 16 + fr) * 128 + co);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(sA + (wm * MI * 16 + i * 16 + fr) * 128 + co);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a, acc[i][j], 0, 0, 0);
+            }
+        }
+        if (more) commit(stage ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        stage ^= 1;
+    }
+
+    OutT* C = reinterpret_cast<OutT*>(g.C) + (size_t)blockIdx.z * g.slab_stride;
+    const float gate = g.e.gate ? *g.e.gate : 1.0f;
+#pragma clang loop unroll(full)
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + wm * MI * 16 + mi * 16 + fr;
+        if (m >= g.M) continue;
+#pragma clang loop unroll(full)
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = n0 + wn * NI * 16 + ni * 16 + fg * 4;
+            if (n >= g.N) continue;
+            float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+            gemm_epilogue4<bf16_t, OutT>(g, C, m, n, v, gate);
+        }
+    }
+}
+
+template <typename CFG, int AT, int BT, typename OutT>
+static void launch2(GemmArgs g, int nz, hipStream_t st) {
+    g.tiles_m = (g.M + CFG::BM - 1) / CFG::BM;
+    g.tiles_n = (g.N + CFG::BN - 1) / CFG::BN;
+    const size_t lds = 2 * CFG::STAGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_kernel<CFG, AT, BT, OutT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm2_kernel<CFG, AT, BT, OutT>), dim3(g.tiles_m * g.tiles_n, 1, nz), dim3(512), lds, st, g);
+}
+
+}  // namespace egv
+using namespace egv;
+
+static inline double wave_eff(int M, int N, int bm, int bn, int nz) {
+    const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * nz;
+    const long long rounds = (tiles + 255) / 256;
+    const double useful = (double)M * N / ((double)((M + bm - 1) / bm) * bm * ((N + bn - 1) / bn) * bn);
+    return useful * (double)tiles / (double)(rounds * 256);
+}
+
+int egv_gemm2_launch(const GemmArgs& g, int a_trans, int b_trans, int out_f32, int nz, hipStream_t st) {
+    if (!((a_trans == 0 && b_trans == 0) || (a_trans == 1 && b_trans == 1))) return 0;
+    if (g.M < 128 || g.N < 64) return 0;
+    if (!a_trans) {
+        if ((g.K % 64) || !g.a_vec_ok || !g.b_vec_ok) return 0;       // DMA staging needs aligned, whole K steps
+        if (out_f32) return 0;
+    } else {
+        if (!out_f32) return 0;                                        // wgrad writes fp32 (slabs or dW)
+    }
+    const bool useA = wave_eff(g.M, g.N, 256, 256, nz) >= wave_eff(g.M, g.N, 256, 128, nz) * 0.98;
+    if (!a_trans) {
+        if (useA) launch2<CfgA, 0, 0, bf16_t>(g, nz, st); else launch2<CfgB, 0, 0, bf16_t>(g, nz, st);
+    } else {
+        if (useA) launch2<CfgA, 1, 1, float>(g, nz, st); else launch2<CfgB, 1, 1, float>(g, nz, st);
+    }
+    return 1;
+}

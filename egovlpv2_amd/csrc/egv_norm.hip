@@ -145,14 +145,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     }
 }
 
-// out[c] = scale * gate * sum_p partial[p][c]   (deterministic order)
-__global__ void colsum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int P, int ncol,
-                                       int stride, float scale, const float* gate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncol) return;
+// out[c] = scale * gate * sum_p partial[p][c]   (deterministic order).  64 columns per workgroup, the P partial rows are
+// split over 16 waves and combined through LDS in a fixed order.
+__global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int P,
+                                                               int ncol, int stride, float scale, const float* gate) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, w = wave_id();
+    const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int p = 0; p < P; ++p) s += partial[(size_t)p * stride + c];
-    out[c] = s * scale * (gate ? *gate : 1.0f);
+    if (c < ncol)
+        for (int p = w; p < P; p += 16) s += partial[(size_t)p * stride + c];
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && c < ncol) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][lane];
+        out[c] = t * scale * (gate ? *gate : 1.0f);
+    }
 }
 
 // partial column sums of X[M,N]: grid (ceil(N/256), chunks); each lane owns 4 columns, waves split rows.
@@ -229,8 +239,31 @@ __global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, long
     }
 }
 
+// dst[c][r] (bf16) = src[r][c] (fp32): transposed compute copy of a weight matrix (dgrad runs in the NT form on it)
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int R, int Cc) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < Cc) ? src[(size_t)r * Cc + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < Cc && r < R) dst[(size_t)c * R + r].v = f2bf(tile[tx][i]);
+    }
+}
+
 }  // namespace egv
 using namespace egv;
+
+extern "C" int egv_cast_transpose(const float* src, void* dst, int R, int Cc, void* stream) {
+    hipLaunchKernelGGL(cast_transpose_kernel, dim3((Cc + 63) / 64, (R + 63) / 64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src,
+                       (bf16_t*)dst, R, Cc);
+    EGV_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int egv_layernorm_fwd(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* stats,
                                  int M, int D, float eps, void* stream) {
@@ -270,9 +303,9 @@ extern "C" int egv_layernorm_bwd(int dtype, const void* dy, const void* x, const
                            (const float*)add, (float*)dx, partial, M, D, rpb);
     EGV_LAUNCH_CHECK();
     // partial layout [nb2][2][D]: columns 0..D-1 = dgamma, D..2D-1 = dbeta
-    hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 255) / 256), dim3(256), 0, st, (const float*)partial, dgamma, nb2, D,
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 63) / 64), dim3(1024), 0, st, (const float*)partial, dgamma, nb2, D,
                        2 * D, 1.0f, (const float*)nullptr);
-    hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 255) / 256), dim3(256), 0, st, (const float*)partial + D, dbeta, nb2, D,
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 63) / 64), dim3(1024), 0, st, (const float*)partial + D, dbeta, nb2, D,
                        2 * D, 1.0f, (const float*)nullptr);
     EGV_LAUNCH_CHECK();
     return 0;
@@ -297,7 +330,7 @@ extern "C" int egv_colsum(int dtype, const void* X, int M, int N, int ld, float*
     else
         hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)X, (float*)workspace, M, N, ld, rpb);
     EGV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, st, (const float*)workspace, out, ch2, N, N, scale, gate);
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((N + 63) / 64), dim3(1024), 0, st, (const float*)workspace, out, ch2, N, N, scale, gate);
     EGV_LAUNCH_CHECK();
     return 0;
 }

@@ -77,6 +77,39 @@ def compute_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return out
 
 
+_wtcache = {}
+
+
+def compute_weight_t(w: torch.Tensor, dtype: torch.dtype):
+    """transposed bf16 compute copy W^T [K_in, N_out] of an fp32 weight [N_out, K_in] (cached per parameter version):
+    lets dgrad run in the K-contiguous (NT) GEMM form on the DMA-staged kernel.  None when not applicable."""
+    if dtype != torch.bfloat16 or w.dim() != 2 or (w.shape[0] % 64) or (w.shape[1] % 8):
+        return None
+    key = id(w)
+    ent = _wtcache.get(key)
+    if ent is not None and ent[0] == w._version and ent[1].device == w.device and ent[2] is w:
+        return ent[1]
+    N, K = w.shape
+    out = torch.empty(K, N, dtype=dtype, device=w.device)
+    src = w.detach()
+    if not src.is_contiguous():
+        src = src.contiguous()
+    check(lib.egv_cast_transpose(_p(src), _p(out), N, K, _st()), 'egv_cast_transpose')
+    _wtcache[key] = (w._version, out, w)
+    return out
+
+
+def dgrad(dz, weight, dx, M, N, K, gate=None, aux=None, dact=0):
+    """dx[M,K] = gate * (dz[M,N] @ W[N,K]) * act'(aux): NT form on the transposed bf16 copy when available, else the
+    generic kernel reading W as a [reduction, out] operand."""
+    wt = compute_weight_t(weight, dz.dtype)
+    if wt is not None:
+        gemm(dz, wt, dx, a_trans=0, b_trans=0, M=M, N=K, K=N, lda=N, ldb=N, ldc=K, gate=gate, aux=aux, dact=dact)
+    else:
+        gemm(dz, compute_weight(weight, dz.dtype), dx, a_trans=0, b_trans=1, M=M, N=K, K=N, lda=N, ldb=K, ldc=K, gate=gate,
+             aux=aux, dact=dact)
+
+
 def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     if x.dtype == dtype:
         return x
@@ -172,10 +205,9 @@ class LinearFn(Function):
             dz = torch.empty_like(dy2)
             check(lib.egv_act_bwd(_dt(dy2), _p(dy2), _p(pre), _p(dz), dy2.numel(), L.ACT_GELU, _st()), 'egv_act_bwd')
         dx = dw = db = dg = None
-        w = compute_weight(weight, dy2.dtype)
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, dtype=dy2.dtype, device=dy2.device)
-            gemm(dz, w, dx, a_trans=0, b_trans=1, M=M, N=K, K=N, lda=N, ldb=K, ldc=K, gate=gate)
+            dgrad(dz, weight, dx, M, N, K, gate=gate)
             dx = dx.reshape(ctx.xshape)
         if ctx.needs_input_grad[1]:
             dw = wgrad(dz, x2, M, N, K, gate=gate)
@@ -226,9 +258,8 @@ class MlpFn(Function):
         dy2 = dy.reshape(M, N)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        c1, c2 = compute_weight(w1, dy2.dtype), compute_weight(w2, dy2.dtype)
         dpre = torch.empty(M, Hd, dtype=dy2.dtype, device=dy2.device)
-        gemm(dy2, c2, dpre, a_trans=0, b_trans=1, M=M, N=Hd, K=N, lda=N, ldb=Hd, ldc=Hd, aux=pre, dact=L.ACT_GELU)
+        dgrad(dy2, w2, dpre, M, N, Hd, aux=pre, dact=L.ACT_GELU)
         dw2 = wgrad(dy2, h, M, N, Hd)
         db2 = colsum(dy2, M, N)
         dw1 = wgrad(dpre, x2, M, Hd, K)
@@ -236,7 +267,7 @@ class MlpFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, dtype=dy2.dtype, device=dy2.device)
-            gemm(dpre, c1, dx, a_trans=0, b_trans=1, M=M, N=K, K=Hd, lda=Hd, ldb=K, ldc=K)
+            dgrad(dpre, w1, dx, M, Hd, K)
             dx = dx.reshape(ctx.xshape)
         return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None)
 
@@ -703,3 +734,4 @@ def prof_collect(max_records: int = 1 << 16):
 def invalidate_weight_cache():
     """Drop the compute-dtype weight copies (call once per optimisation step: the fp32 masters changed)."""
     _wcache.clear()
+    _wtcache.clear()

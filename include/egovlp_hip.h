@@ -79,6 +79,8 @@ int egv_dot(int dtype, const void* a, const void* b, long long n, float* out, fl
 /* out = dy * act'(aux)  (kind = EGV_ACT_*; aux = forward output for RELU/TANH, pre-activation for GELU) */
 int egv_act_bwd(int dtype, const void* dy, const void* aux, void* out, long long n, int kind, void* stream);
 int egv_cast(int dtype_src, int dtype_dst, const void* src, void* dst, long long n, void* stream);
+/* dst[C][R] (bf16) = src[R][C] (fp32): transposed bf16 compute copy of a weight, so that dgrad runs in the NT form */
+int egv_cast_transpose(const float* src, void* dst, int R, int C, void* stream);
 
 /* ---- grouped attention, head_dim 64 (video_transformer.py:35-39,117-150,155-182; roberta.py:257-327) ----
  * Query rows and key rows are affine row sets of token matrices:

@@ -331,3 +331,26 @@ def test_sim_matrix_and_egonce(ops):
 def test_cpu_tensor_is_refused(ops):
     with pytest.raises(RuntimeError):
         ops.linear(torch.randn(4, 8), torch.randn(8, 8))
+
+
+@pytest.mark.parametrize('shape', [(1000, 768, 768), (700, 2304, 768), (513, 768, 3072), (3137, 3072, 768), (300, 768, 128)])
+def test_linear_large_tiles_bf16(ops, shape):
+    """shapes that take the 256-row DMA-staged kernel (egv_gemm2.hip): fwd, dgrad on W^T, wgrad with split reduction"""
+    M, N, K = shape
+    dtype = torch.bfloat16
+    x = _rnd((M, K), dtype, 1.0, 1).cuda().requires_grad_(True)
+    w = _rnd((N, K), torch.float32, 0.05, 2).cuda().requires_grad_(True)
+    b = _rnd((N,), torch.float32, 0.5, 3).cuda().requires_grad_(True)
+    r = _rnd((M, N), dtype, 1.0, 4).cuda()
+    y = ops.linear(x, w, b, res1=r)
+    wq = w.detach().to(dtype).double().cpu()
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    w64, b64 = wq.clone().requires_grad_(True), b.detach().double().cpu().requires_grad_(True)
+    y64 = x64 @ w64.t() + b64 + r.double().cpu()
+    assert _rel(y, y64) < _tol(dtype)
+    dy = _rnd((M, N), dtype, 1.0, 5)
+    y.backward(dy.cuda())
+    y64.backward(dy.double())
+    assert _rel(x.grad, x64.grad) < _tol(dtype, True)
+    assert _rel(w.grad, w64.grad) < _tol(dtype, True)
+    assert _rel(b.grad, b64.grad) < _tol(dtype, True)
