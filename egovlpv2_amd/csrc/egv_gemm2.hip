@@ -197,6 +197,184 @@ static void launch2(GemmArgs g, int nz, hipStream_t st) {
     hipLaunchKernelGGL((gemm2_kernel<CFG, AT, BT, OutT>), dim3(g.tiles_m * g.tiles_n, 1, nz), dim3(512), lds, st, g);
 }
 
+// ------------------------------------------------------------------------------------------------
+// NT ring kernel: K step 32 (64-byte LDS rows), NS-stage LDS ring filled by global_load_lds with NS-1 K-tiles in flight,
+// counted s_waitcnt vmcnt (never 0 in steady state) + one raw s_barrier per K step (cdna_hip_programming.md T3+T4).
+// LDS image per operand tile: rows of 64 B = 4 chunks of 16 B; chunk c of row r is stored at chunk c ^ (((r >> 2) & 1) * 3),
+// which makes the 16-lane ds_read_b128 service groups of gfx950 conflict free for a 64-byte pitch.
+// ------------------------------------------------------------------------------------------------
+template <int ROWS>
+__device__ __forceinline__ void ring_dma(const bf16_t* base, int rows_total, int ld, int row0, int k0, unsigned char* s, int wave,
+                                         int lane) {
+    const int rl = lane >> 2;                                  // row inside the 16-row piece
+    const int c = (lane & 3) ^ (((rl >> 2) & 1) * 3);
+#pragma unroll
+    for (int p = wave; p < ROWS / 16; p += 8) {
+        const int gr = min(row0 + p * 16 + rl, rows_total - 1);
+        const bf16_t* src = base + (size_t)gr * ld + k0 + c * 8;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s + p * 1024), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ unsigned int pack2f(float a, float b) { return (unsigned int)f2bf(a) | ((unsigned int)f2bf(b) << 16); }
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename CFG, int NS>
+__global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmArgs g) {
+    constexpr int BM = CFG::BM, BN = CFG::BN, MI = CFG::MI, NI = CFG::NI;
+    constexpr int STG = (BM + BN) * 64;                        // bytes per stage
+    constexpr int P = (BM + BN) / 128;                         // DMA instructions per wave per K-tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = wave_id();
+    const int wm = wave / CFG::WGN, wn = wave % CFG::WGN;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    const int ntile = g.tiles_m * g.tiles_n;
+    const int t = xcd_remap(blockIdx.x, ntile);
+    const int tm = t / g.tiles_n, tn = t % g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A);
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B);
+
+    f32x4_t acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nt = g.K / 32;
+    auto issue = [&](int kt, int slot) {
+        unsigned char* sA = smem + slot * STG;
+        ring_dma<BM>(A, g.M, g.lda, m0, kt * 32, sA, wave, lane);
+        ring_dma<BN>(B, g.N, g.ldb, n0, kt * 32, sA + BM * 64, wave, lane);
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nt) issue(s, s);
+
+    const int frag_off = fr * 64 + ((fg ^ (((fr >> 2) & 1) * 3)) * 16);
+    int slot = 0, islot = NS - 1;
+    for (int kt = 0; kt < nt; ++kt) {
+        const int rem = nt - 1 - kt;
+        if (rem >= NS - 2) wait_vmcnt<P*(NS - 2)>();
+        else if (NS > 3 && rem == 1) wait_vmcnt<P>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS - 1 < nt) issue(kt + NS - 1, islot);
+        const unsigned char* sA = smem + slot * STG + frag_off;
+        const unsigned char* sB = sA + BM * 64;
+        bf16x8_t b[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(sB + (wn * NI * 16 + j * 16) * 64);
+        bf16x8_t a[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(sA + (wm * MI * 16 + i * 16) * 64);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        slot = (slot + 1 == NS) ? 0 : slot + 1;
+        islot = (islot + 1 == NS) ? 0 : islot + 1;
+    }
+
+    // ---------------- epilogue through LDS ----------------
+    // Each wave transposes its accumulators 16 rows at a time through a private fp32 LDS slab so that every lane owns 8
+    // CONSECUTIVE output columns of one row: bias is two float4 loads per lane for the whole tile, and residual / aux / pre /
+    // C accesses are 16-byte vectors forming 128-byte row segments (8 lanes per row) instead of 8-byte scattered ones.
+    static_assert(NI == 4, "wave tile must be 64 columns wide");
+    constexpr int EP = 68;                                     // floats per LDS slab row (64 + 4 pad)
+    __syncthreads();                                           // every wave is done with the operand stages
+    float* slab = reinterpret_cast<float*>(smem) + wave * 16 * EP;
+    bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
+    const GemmEpi& e = g.e;
+    const float gate = e.gate ? *e.gate : 1.0f;
+    const bf16_t* R1 = reinterpret_cast<const bf16_t*>(e.res1);
+    const bf16_t* R2 = reinterpret_cast<const bf16_t*>(e.res2);
+    const bf16_t* AUX = reinterpret_cast<const bf16_t*>(e.aux);
+    bf16_t* PRE = reinterpret_cast<bf16_t*>(e.pre);
+    const int er = lane >> 3, ec = (lane & 7) * 8;             // read-back: row er (+8), columns ec .. ec+7 of the wave tile
+    const int ncol = n0 + wn * 64 + ec;
+    const bool col_ok = ncol < g.N;                            // N % 8 == 0 is a launch precondition
+    float bias8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bias8[k] = 0.f;
+    if (e.bias && col_ok) {
+        const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(e.bias + ncol);
+        const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(e.bias + ncol + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { bias8[k] = b0[k]; bias8[4 + k] = b1[k]; }
+    }
+#pragma clang loop unroll(full)
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) *reinterpret_cast<f32x4_t*>(slab + fr * EP + ni * 16 + fg * 4) = acc[mi][ni];
+        // same-wave LDS write -> read: program order + lgkmcnt is enough, no barrier needed
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int row = half * 8 + er;
+            const int m = m0 + wm * MI * 16 + mi * 16 + row;
+            const f32x4_t x0 = *reinterpret_cast<const f32x4_t*>(slab + row * EP + ec);
+            const f32x4_t x1 = *reinterpret_cast<const f32x4_t*>(slab + row * EP + ec + 4);
+            if (m < g.M && col_ok) {
+                float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+                const size_t ro = (size_t)m * e.ldr + ncol;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = v[k] * e.scale + bias8[k];
+                if (PRE) {
+                    u32x4_t o = {pack2f(v[0], v[1]), pack2f(v[2], v[3]), pack2f(v[4], v[5]), pack2f(v[6], v[7])};
+                    *reinterpret_cast<u32x4_t*>(PRE + ro) = o;
+                }
+                if (e.act) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = apply_act(v[k], e.act);
+                }
+                if (e.gate) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] *= gate;
+                }
+                if (R1) {
+                    const u32x4_t r = *reinterpret_cast<const u32x4_t*>(R1 + ro);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { v[2 * k] += __uint_as_float(r[k] << 16); v[2 * k + 1] += __uint_as_float(r[k] & 0xffff0000u); }
+                }
+                if (R2) {
+                    const u32x4_t r = *reinterpret_cast<const u32x4_t*>(R2 + ro);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { v[2 * k] += __uint_as_float(r[k] << 16); v[2 * k + 1] += __uint_as_float(r[k] & 0xffff0000u); }
+                }
+                if (e.dact) {
+                    const u32x4_t r = *reinterpret_cast<const u32x4_t*>(AUX + ro);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[2 * k] *= apply_dact(__uint_as_float(r[k] << 16), e.dact);
+                        v[2 * k + 1] *= apply_dact(__uint_as_float(r[k] & 0xffff0000u), e.dact);
+                    }
+                }
+                u32x4_t o = {pack2f(v[0], v[1]), pack2f(v[2], v[3]), pack2f(v[4], v[5]), pack2f(v[6], v[7])};
+                *reinterpret_cast<u32x4_t*>(C + (size_t)m * g.ldc + ncol) = o;
+            }
+        }
+    }
+}
+
+template <typename CFG, int NS>
+static void launch_ring(GemmArgs g, hipStream_t st) {
+    g.tiles_m = (g.M + CFG::BM - 1) / CFG::BM;
+    g.tiles_n = (g.N + CFG::BN - 1) / CFG::BN;
+    const size_t lds = (size_t)NS * (CFG::BM + CFG::BN) * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<CFG, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_ring_kernel<CFG, NS>), dim3(g.tiles_m * g.tiles_n), dim3(512), lds, st, g);
+}
+
 }  // namespace egv
 using namespace egv;
 
@@ -213,12 +391,16 @@ int egv_gemm2_launch(const GemmArgs& g, int a_trans, int b_trans, int out_f32, i
     if (!a_trans) {
         if ((g.K % 64) || !g.a_vec_ok || !g.b_vec_ok) return 0;       // DMA staging needs aligned, whole K steps
         if (out_f32) return 0;
+        auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+        if ((g.N % 8) || (g.ldc % 8) || (g.e.ldr % 8) || !al16(g.C) || !al16(g.e.res1) || !al16(g.e.res2) || !al16(g.e.pre) ||
+            !al16(g.e.aux) || (g.e.bias && !al16(g.e.bias)))
+            return 0;
     } else {
         if (!out_f32) return 0;                                        // wgrad writes fp32 (slabs or dW)
     }
     const bool useA = wave_eff(g.M, g.N, 256, 256, nz) >= wave_eff(g.M, g.N, 256, 128, nz) * 0.98;
     if (!a_trans) {
-        if (useA) launch2<CfgA, 0, 0, bf16_t>(g, nz, st); else launch2<CfgB, 0, 0, bf16_t>(g, nz, st);
+        if (useA) launch_ring<CfgA, 4>(g, st); else launch_ring<CfgB, 4>(g, st);
     } else {
         if (useA) launch2<CfgA, 1, 1, float>(g, nz, st); else launch2<CfgB, 1, 1, float>(g, nz, st);
     }
