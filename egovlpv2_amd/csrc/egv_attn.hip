@@ -404,6 +404,168 @@ __global__ void attn_dkv_reduce_kernel(const AttnArgs a, int P) {
     Elem<T>::st(dV + row * a.lddv + a.dvoff + h * HD + lane, sv);
 }
 
+// ------------------------------------------------------------------------------------------------
+// "one row against many" kernels (CLS query over all S keys; CLS key under all S queries).  lane = other-side row:
+// every lane keeps a private online-softmax / gradient accumulator over its rows and the 64 lanes are merged once per
+// wave; partial states go to the same fp32 workspaces as the split launches above (combined by the same kernels).
+// grid (nsplit, problems, heads), one wave per workgroup; each split covers a contiguous range of other rows.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void load_row_f(const T* p, float (&o)[HD]) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        float x[4];
+        ld4(p + v * 4, x);
+        o[v * 4] = x[0]; o[v * 4 + 1] = x[1]; o[v * 4 + 2] = x[2]; o[v * 4 + 3] = x[3];
+    }
+}
+
+__device__ __forceinline__ long long other_row_v(const AttnArgs& a, const RowSet& rs, int b, int g, int j) {
+    if (a.extra) return (j == 0) ? ((long long)b * a.extra_bs + a.extra_row) : rs_row(rs, b, g, j - 1);
+    return rs_row(rs, b, g, j);
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void attn1_fwd_kernel(const AttnArgs a) {
+    const int lane = threadIdx.x;
+    const int split = blockIdx.x, p = blockIdx.y, b = p / a.G, g = p % a.G, h = blockIdx.z;
+    const T* Q = reinterpret_cast<const T*>(a.Q);
+    const T* K = reinterpret_cast<const T*>(a.K);
+    const T* V = reinterpret_cast<const T*>(a.V);
+    const long long qrow = rs_row(a.q, b, g, 0);
+    float q[HD];
+    load_row_f(Q + qrow * a.ldq + a.qoff + h * HD, q);
+#pragma unroll
+    for (int d = 0; d < HD; ++d) q[d] *= a.scale;
+    const int ntot = a.k.n + a.extra;
+    const int per = (ntot + a.nsplit - 1) / a.nsplit;
+    const int j0 = split * per, j1 = min(ntot, j0 + per);
+    float m = -INFINITY, l = 0.f, o[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = 0.f;
+    for (int j = j0 + lane; j < j1; j += 64) {
+        const long long row = other_row_v(a, a.k, b, g, j);
+        float kr[HD];
+        load_row_f(K + row * a.ldk + a.koff + h * HD, kr);
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) s = fmaf(q[d], kr[d], s);
+        if (a.mask && !(a.extra && j == 0)) s += a.mask[(long long)b * a.mask_ld + (j - a.extra)];
+        const float mn = fmaxf(m, s);
+        const float c = __expf(m - mn), pj = __expf(s - mn);
+        load_row_f(V + row * a.ldv + a.voff + h * HD, kr);
+        l = l * c + pj;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) o[d] = fmaf(o[d], c, pj * kr[d]);
+        m = mn;
+    }
+    const float M = wave_max(m);
+    const float c = (m == -INFINITY) ? 0.f : __expf(m - M);
+    const float L = wave_sum(l * c);
+    const long long nrows = (long long)gridDim.y * a.q.n;
+    const long long orow = (long long)p * a.q.n;
+    float* dst = a.ws + (((long long)split * nrows + orow) * a.H + h) * 66;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
+        const float t = wave_sum(o[d] * c);
+        if (lane == d) dst[2 + d] = t;
+    }
+    if (lane == 0) { dst[0] = M; dst[1] = L; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void attn1_dq_kernel(const AttnArgs a) {
+    const int lane = threadIdx.x;
+    const int split = blockIdx.x, p = blockIdx.y, b = p / a.G, g = p % a.G, h = blockIdx.z;
+    const T* Q = reinterpret_cast<const T*>(a.Q);
+    const T* K = reinterpret_cast<const T*>(a.K);
+    const T* V = reinterpret_cast<const T*>(a.V);
+    const T* O = reinterpret_cast<const T*>(a.O);
+    const T* dO = reinterpret_cast<const T*>(a.dO);
+    const long long qrow = rs_row(a.q, b, g, 0);
+    float q[HD], go[HD];
+    load_row_f(Q + qrow * a.ldq + a.qoff + h * HD, q);
+    load_row_f(dO + qrow * a.ldo + a.ooff + h * HD, go);
+    float dl = 0.f;
+    {
+        float ov[HD];
+        load_row_f(O + qrow * a.ldo + a.ooff + h * HD, ov);
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { dl = fmaf(go[d], ov[d], dl); q[d] *= a.scale; }
+    }
+    const float lse = a.lse[qrow * a.H + h];
+    if (split == 0 && lane == 0) a.delta[qrow * a.H + h] = dl;
+    const int ntot = a.k.n + a.extra;
+    const int per = (ntot + a.nsplit - 1) / a.nsplit;
+    const int j0 = split * per, j1 = min(ntot, j0 + per);
+    float acc[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) acc[d] = 0.f;
+    for (int j = j0 + lane; j < j1; j += 64) {
+        const long long row = other_row_v(a, a.k, b, g, j);
+        float kr[HD], vr[HD];
+        load_row_f(K + row * a.ldk + a.koff + h * HD, kr);
+        load_row_f(V + row * a.ldv + a.voff + h * HD, vr);
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { s = fmaf(q[d], kr[d], s); dp = fmaf(go[d], vr[d], dp); }
+        if (a.mask && !(a.extra && j == 0)) s += a.mask[(long long)b * a.mask_ld + (j - a.extra)];
+        const float ds = __expf(s - lse) * (dp - dl);
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc[d] = fmaf(ds, kr[d], acc[d]);
+    }
+    const long long nrows = (long long)gridDim.y * a.q.n;
+    const long long orow = (long long)p * a.q.n;
+    float* dst = a.ws + (((long long)split * nrows + orow) * a.H + h) * HD;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
+        const float t = wave_sum(acc[d]);
+        if (lane == d) dst[d] = t * a.scale;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void attn1_dkv_kernel(const AttnArgs a) {
+    const int lane = threadIdx.x;
+    const int split = blockIdx.x, p = blockIdx.y, b = p / a.G, g = p % a.G, h = blockIdx.z;
+    const T* Q = reinterpret_cast<const T*>(a.Q);
+    const T* K = reinterpret_cast<const T*>(a.K);
+    const T* V = reinterpret_cast<const T*>(a.V);
+    const T* dO = reinterpret_cast<const T*>(a.dO);
+    const long long krow = rs_row(a.k, b, g, 0);
+    float kc[HD], vc[HD];
+    load_row_f(K + krow * a.ldk + a.koff + h * HD, kc);
+    load_row_f(V + krow * a.ldv + a.voff + h * HD, vc);
+    const float mk = a.mask ? a.mask[(long long)b * a.mask_ld] : 0.f;
+    const int ntot = a.q.n + a.extra;
+    const int per = (ntot + a.nsplit - 1) / a.nsplit;
+    const int i0 = split * per, i1 = min(ntot, i0 + per);
+    float dk[HD], dv[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) dk[d] = dv[d] = 0.f;
+    for (int i = i0 + lane; i < i1; i += 64) {
+        const long long row = other_row_v(a, a.q, b, g, i);
+        float qr[HD], gr[HD];
+        load_row_f(Q + row * a.ldq + a.qoff + h * HD, qr);
+        load_row_f(dO + row * a.ldo + a.ooff + h * HD, gr);
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { s = fmaf(qr[d], kc[d], s); dp = fmaf(gr[d], vc[d], dp); }
+        const float pj = __expf(s * a.scale + mk - a.lse[row * a.H + h]);
+        const float ds = pj * (dp - a.delta[row * a.H + h]) * a.scale;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { dv[d] = fmaf(pj, gr[d], dv[d]); dk[d] = fmaf(ds, qr[d], dk[d]); }
+    }
+    const long long nrows = (long long)gridDim.y * a.k.n;
+    const long long orow = (long long)p * a.k.n;
+    float* dst = a.ws + (((long long)split * nrows + orow) * a.H + h) * 2 * HD;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
+        const float t = wave_sum(dk[d]), u = wave_sum(dv[d]);
+        if (lane == d) { dst[d] = t; dst[HD + d] = u; }
+    }
+}
+
 static inline size_t fwd_smem(int nw) { return (size_t)(2 * TK * LDT + 2 * nw * QPW * HD + nw * QPW * 2) * 4; }
 static inline size_t dq_smem(int nw) { return (size_t)(2 * TK * LDT + 3 * nw * QPW * HD + nw * QPW * 2) * 4; }
 static inline size_t dkv_smem() { return (size_t)(2 * TK * LDT) * 4; }
@@ -454,10 +616,16 @@ extern "C" int egv_attn_fwd(int dtype, const egv_attn_desc* d, void* stream) {
     if (a.nsplit > 1)
         EGV_CHECK(d->ws && d->ws_bytes >= egv_attn_split_workspace_bytes(0, d->B, d->G, d->H, d->q_n, a.nsplit),
                   "egv_attn_fwd: workspace too small");
-    const int nw = pick_nw(d->q_n);
-    dim3 grid(((d->q_n + nw * QPW - 1) / (nw * QPW)) * a.nsplit, d->B * d->G, d->H);
-    const size_t sm = fwd_smem(nw);
-    EGV_ATTN_LAUNCH(attn_fwd_kernel, nw, sm, grid);
+    if (d->q_n == 1 && a.nsplit > 1) {
+        dim3 grid1(a.nsplit, d->B * d->G, d->H);
+        if (dtype == EGV_BF16) hipLaunchKernelGGL(attn1_fwd_kernel<bf16_t>, grid1, dim3(64), 0, st, a);
+        else hipLaunchKernelGGL(attn1_fwd_kernel<float>, grid1, dim3(64), 0, st, a);
+    } else {
+        const int nw = pick_nw(d->q_n);
+        dim3 grid(((d->q_n + nw * QPW - 1) / (nw * QPW)) * a.nsplit, d->B * d->G, d->H);
+        const size_t sm = fwd_smem(nw);
+        EGV_ATTN_LAUNCH(attn_fwd_kernel, nw, sm, grid);
+    }
     EGV_LAUNCH_CHECK();
     if (a.nsplit > 1) {
         const long long n = (long long)d->B * d->G * d->q_n * d->H;
@@ -481,10 +649,16 @@ extern "C" int egv_attn_bwd_dq(int dtype, const egv_attn_desc* d, void* stream) 
     if (a.nsplit > 1)
         EGV_CHECK(d->ws && d->ws_bytes >= egv_attn_split_workspace_bytes(1, d->B, d->G, d->H, d->q_n, a.nsplit),
                   "egv_attn_bwd_dq: workspace too small");
-    const int nw = pick_nw(d->q_n);
-    dim3 grid(((d->q_n + nw * QPW - 1) / (nw * QPW)) * a.nsplit, d->B * d->G, d->H);
-    const size_t sm = dq_smem(nw);
-    EGV_ATTN_LAUNCH(attn_bwd_dq_kernel, nw, sm, grid);
+    if (d->q_n == 1 && a.nsplit > 1) {
+        dim3 grid1(a.nsplit, d->B * d->G, d->H);
+        if (dtype == EGV_BF16) hipLaunchKernelGGL(attn1_dq_kernel<bf16_t>, grid1, dim3(64), 0, st, a);
+        else hipLaunchKernelGGL(attn1_dq_kernel<float>, grid1, dim3(64), 0, st, a);
+    } else {
+        const int nw = pick_nw(d->q_n);
+        dim3 grid(((d->q_n + nw * QPW - 1) / (nw * QPW)) * a.nsplit, d->B * d->G, d->H);
+        const size_t sm = dq_smem(nw);
+        EGV_ATTN_LAUNCH(attn_bwd_dq_kernel, nw, sm, grid);
+    }
     EGV_LAUNCH_CHECK();
     if (a.nsplit > 1) {
         const long long n = (long long)d->B * d->G * d->q_n * d->H;
@@ -513,13 +687,21 @@ extern "C" int egv_attn_bwd_dkv(int dtype, const egv_attn_desc* d, void* stream)
     if (a.nsplit > 1)
         EGV_CHECK(d->ws && d->ws_bytes >= egv_attn_bwd_dkv_workspace_bytes(d->B, d->G, d->H, d->k_n, a.nsplit),
                   "egv_attn_bwd_dkv: workspace too small");
-    const int ntot = d->q_n + d->extra;
-    const int per = (ntot + a.nsplit - 1) / a.nsplit;
-    const int nw = per >= 4 ? 4 : (per >= 2 ? 2 : 1);
-    const int tiles = (d->k_n + TK - 1) / TK;
-    dim3 grid(tiles * a.nsplit, d->B * d->G, d->H);
-    const size_t sm = dkv_smem();
-    EGV_ATTN_LAUNCH(attn_bwd_dkv_kernel, nw, sm, grid);
+    if (d->k_n == 1 && a.nsplit > 1) {
+        dim3 grid1(a.nsplit, d->B * d->G, d->H);
+        if (dtype == EGV_BF16) hipLaunchKernelGGL(attn1_dkv_kernel<bf16_t>, grid1, dim3(64), 0, st, a);
+        else hipLaunchKernelGGL(attn1_dkv_kernel<float>, grid1, dim3(64), 0, st, a);
+    } else if (dtype == EGV_BF16 && a.nsplit > 1 && egv_attn_dkv_mfma(a, d->B, st)) {
+        // long query side, short key side (image->text cross attention): MFMA kernel per query chunk, fp32 partials
+    } else {
+        const int ntot = d->q_n + d->extra;
+        const int per = (ntot + a.nsplit - 1) / a.nsplit;
+        const int nw = per >= 4 ? 4 : (per >= 2 ? 2 : 1);
+        const int tiles = (d->k_n + TK - 1) / TK;
+        dim3 grid(tiles * a.nsplit, d->B * d->G, d->H);
+        const size_t sm = dkv_smem();
+        EGV_ATTN_LAUNCH(attn_bwd_dkv_kernel, nw, sm, grid);
+    }
     EGV_LAUNCH_CHECK();
     if (a.nsplit > 1) {
         const long long n = (long long)d->B * d->G * d->k_n * d->H;

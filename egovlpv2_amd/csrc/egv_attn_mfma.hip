@@ -30,11 +30,11 @@ __device__ __forceinline__ long long other_row(const AttnArgs& a, const RowSet& 
 // stage other-side rows [0, ntot) of one head into a row-major LDS tile (rows >= ntot are zero)
 template <int NT, int NTHR>
 __device__ __forceinline__ void stage_rows(unsigned char* s, const bf16_t* base, int ld, int off, const AttnArgs& a,
-                                           const RowSet& rs, int b, int g, int ntot, int tid) {
+                                           const RowSet& rs, int b, int g, int ntot, int tid, int r0 = 0) {
     for (int c = tid; c < NT * 16 * 8; c += NTHR) {
         const int r = c >> 3, v = c & 7;
         u32x4_t x = {0u, 0u, 0u, 0u};
-        if (r < ntot) x = *reinterpret_cast<const u32x4_t*>(base + other_row(a, rs, b, g, r) * ld + off + v * 8);
+        if (r < ntot) x = *reinterpret_cast<const u32x4_t*>(base + other_row(a, rs, b, g, r0 + r) * ld + off + v * 8);
         *reinterpret_cast<u32x4_t*>(s + r * RP + v * 16) = x;
     }
 }
@@ -42,7 +42,7 @@ __device__ __forceinline__ void stage_rows(unsigned char* s, const bf16_t* base,
 // stage the same rows transposed: sT[d][row] (bf16, pitch vt_pitch(NT)); 8x8 block transpose in registers
 template <int NT, int NTHR>
 __device__ __forceinline__ void stage_rows_t(unsigned char* s, const bf16_t* base, int ld, int off, const AttnArgs& a,
-                                             const RowSet& rs, int b, int g, int ntot, int tid) {
+                                             const RowSet& rs, int b, int g, int ntot, int tid, int r0 = 0) {
     constexpr int VP = vt_pitch(NT);
     for (int u = tid; u < NT * 2 * 8; u += NTHR) {      // NT*16/8 row blocks x 8 d blocks
         const int kb = u >> 3, db = u & 7;
@@ -51,7 +51,7 @@ __device__ __forceinline__ void stage_rows_t(unsigned char* s, const bf16_t* bas
         for (int j = 0; j < 8; ++j) {
             const int row = kb * 8 + j;
             r[j] = u32x4_t{0u, 0u, 0u, 0u};
-            if (row < ntot) r[j] = *reinterpret_cast<const u32x4_t*>(base + other_row(a, rs, b, g, row) * ld + off + db * 8);
+            if (row < ntot) r[j] = *reinterpret_cast<const u32x4_t*>(base + other_row(a, rs, b, g, r0 + row) * ld + off + db * 8);
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -309,16 +309,21 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_mfma_kernel(const AttnArgs a
     bf16_t* dV = reinterpret_cast<bf16_t*>(a.dV);
     const int hq = a.qoff + h * HD, hk = a.koff + h * HD, hv = a.voff + h * HD, ho = a.ooff + h * HD;
     const int hdk = a.dkoff + h * HD, hdv = a.dvoff + h * HD;
-    const int ntot = a.q.n + a.extra;                // queries incl. the extra CLS query
+    // queries incl. the extra CLS query; with nsplit > 1 this workgroup covers the chunk [r0, r0 + ntot) of them
+    const int nall = a.q.n + a.extra;
+    const int split = blockIdx.x % a.nsplit;
+    const int per = a.nsplit > 1 ? ((((nall + a.nsplit - 1) / a.nsplit) + 15) & ~15) : nall;
+    const int r0 = split * per;
+    const int ntot = max(0, min(per, nall - r0));
 
-    stage_rows<NT, 64 * NW>(sQ, Q, a.ldq, hq, a, a.q, b, g, ntot, tid);
-    stage_rows<NT, 64 * NW>(sG, dO, a.ldo, ho, a, a.q, b, g, ntot, tid);
-    stage_rows_t<NT, 64 * NW>(sQt, Q, a.ldq, hq, a, a.q, b, g, ntot, tid);
-    stage_rows_t<NT, 64 * NW>(sGt, dO, a.ldo, ho, a, a.q, b, g, ntot, tid);
+    stage_rows<NT, 64 * NW>(sQ, Q, a.ldq, hq, a, a.q, b, g, ntot, tid, r0);
+    stage_rows<NT, 64 * NW>(sG, dO, a.ldo, ho, a, a.q, b, g, ntot, tid, r0);
+    stage_rows_t<NT, 64 * NW>(sQt, Q, a.ldq, hq, a, a.q, b, g, ntot, tid, r0);
+    stage_rows_t<NT, 64 * NW>(sGt, dO, a.ldo, ho, a, a.q, b, g, ntot, tid, r0);
     for (int i = tid; i < NT * 16; i += 64 * NW) {
         float l = INFINITY, d = 0.f;                 // padded query rows: exp(s - inf) = 0
         if (i < ntot) {
-            const long long row = other_row(a, a.q, b, g, i);
+            const long long row = other_row(a, a.q, b, g, r0 + i);
             l = a.lse[row * a.H + h];
             d = a.delta[row * a.H + h];
         }
@@ -328,7 +333,7 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_mfma_kernel(const AttnArgs a
     __syncthreads();
 
     const int nkt = (a.k.n + 15) >> 4;
-    const int t0 = blockIdx.x * tiles_per_wg;
+    const int t0 = (blockIdx.x / a.nsplit) * tiles_per_wg;
     const int t1 = min(nkt, t0 + tiles_per_wg);
     for (int kt = t0 + w; kt < t1; kt += NW) {
         const int key = kt * 16 + fr;
@@ -379,7 +384,17 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_mfma_kernel(const AttnArgs a
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (kv) {
+        if (kv && a.nsplit > 1) {
+            // fp32 partials: ws[split][P * k.n own rows][H][2][64]  (summed by attn_dkv_reduce_kernel)
+            const long long nrows = (long long)gridDim.y * a.k.n;
+            const long long orow = (long long)p * a.k.n + key;
+            float* dst = a.ws + (((long long)split * nrows + orow) * a.H + h) * 2 * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                *reinterpret_cast<f32x4_t*>(dst + dt * 16 + fg * 4) = ok[dt] * a.scale;
+                *reinterpret_cast<f32x4_t*>(dst + HD + dt * 16 + fg * 4) = ov[dt];
+            }
+        } else if (kv) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 st_bf16x4(dV + krow * a.lddv + hdv + dt * 16 + fg * 4, ov[dt][0], ov[dt][1], ov[dt][2], ov[dt][3]);
@@ -447,10 +462,13 @@ int egv_attn_dq_mfma(const AttnArgs& a, int B, hipStream_t st) {
 }
 
 int egv_attn_dkv_mfma(const AttnArgs& a, int B, hipStream_t st) {
-    const int ntot = a.q.n + a.extra;
+    const int nall = a.q.n + a.extra;
+    const int ntot = a.nsplit > 1 ? ((((nall + a.nsplit - 1) / a.nsplit) + 15) & ~15) : nall;
     if (!aligned_ok(a) || (a.lddk % 4) || (a.lddv % 4) || (a.dkoff % 4) || (a.dvoff % 4) || ntot > 224) return 0;
+    if (a.nsplit > 1 && (a.k.n > 64 || !a.ws)) return 0;          // split form: short key side only
     int nw, tpw, chunks;
     own_split(a.k.n, nw, tpw, chunks);
+    chunks *= a.nsplit;
     if (ntot <= 32) EGV_MFMA_LAUNCH(attn_dkv_mfma_kernel, dkv_lds, 2);
     else if (ntot <= 64) EGV_MFMA_LAUNCH(attn_dkv_mfma_kernel, dkv_lds, 4);
     else EGV_MFMA_LAUNCH(attn_dkv_mfma_kernel, dkv_lds, 14);

@@ -506,7 +506,7 @@ class PlainAttnFn(Function):
         ws, nb = _split_ws(1, B, 1, H, nq, ns, q.device)
         d = _mk_desc(q, k, v, O, lse, B, 1, H, qs, ks, None, scale, nsplit=ns, ws=ws, ws_bytes=nb, **kw)
         check(lib.egv_attn_bwd_dq(_dt(q), C.byref(d), _st()), 'egv_attn_bwd_dq')
-        nsplit = max(nsplit, _nsplit_for(nq))
+        nsplit = max(nsplit, 1 if nq <= 224 else (nq + 223) // 224)      # MFMA kernel per 224-query chunk
         ws, nb = _dkv_ws(B, 1, H, nk, nsplit, q.device)
         d = _mk_desc(q, k, v, O, lse, B, 1, H, qs, ks, None, scale, nsplit=nsplit, ws=ws, ws_bytes=nb, **kw)
         check(lib.egv_attn_bwd_dkv(_dt(q), C.byref(d), _st()), 'egv_attn_bwd_dkv')
