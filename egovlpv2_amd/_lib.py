@@ -43,7 +43,7 @@ PROTOTYPES = {
     'egv_last_error': (C.c_char_p, []),
     'egv_gemm': (i32, [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     'egv_gemm_wgrad_workspace_bytes': (i64, [i32, i32, i32]),
-    'egv_gemm_wgrad': (i32, [i32, i32, i32, i32, vp, i32, vp, i32, vp, f32, vp, vp, i64, vp]),
+    'egv_gemm_wgrad': (i32, [i32, i32, i32, i32, vp, i32, vp, i32, vp, vp, f32, vp, vp, i64, vp]),
     'egv_layernorm_fwd': (i32, [i32, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     'egv_layernorm_bwd_workspace_bytes': (i64, [i32, i32]),
     'egv_layernorm_bwd': (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),

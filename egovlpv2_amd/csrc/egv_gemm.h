@@ -27,6 +27,7 @@ struct GemmArgs {
     int k_per_split;                    // K range per blockIdx.z (== K when not split)
     long long slab_stride;              // elements between split slabs of C
     int tiles_m, tiles_n;
+    float* colsum;                      // wgrad only: fp32 [gridDim.z][M] partial column sums of the A operand (dY), or null
     GemmEpi e;
 };
 

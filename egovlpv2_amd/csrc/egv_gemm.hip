@@ -289,6 +289,7 @@ extern "C" int egv_gemm(int dtype, int a_trans, int b_trans, int M, int N, int K
     g.c_vec_ok = out_f32 ? vec_ok(C, ldc, EGV_F32) : (((reinterpret_cast<uintptr_t>(C) & 15) == 0) && (ldc % 4 == 0));
     g.k_per_split = K;
     g.slab_stride = 0;
+    g.colsum = nullptr;
     g.tiles_m = (M + BM - 1) / BM;
     g.tiles_n = (N + BN - 1) / BN;
     g.e.bias = bias; g.e.gate = gate; g.e.res1 = res1; g.e.res2 = res2; g.e.pre = pre; g.e.aux = aux;
@@ -315,42 +316,64 @@ extern "C" int egv_gemm(int dtype, int a_trans, int b_trans, int M, int N, int K
     return 0;
 }
 
-static inline int wgrad_splits(int tiles, int M) {
-    int nz = 1;
-    while (tiles * nz < 512 && nz < 64 && M / (nz * 2) >= 512) nz *= 2;
-    return nz;
+// split count of the wgrad reduction: minimise (MFMA time / wave-quantisation efficiency) + slab write/read time
+static inline int wgrad_splits(int tiles, int M, long long out_elems, double flops, int slots) {
+    int best = 1;
+    double best_cost = 1e30;
+    for (int nz = 1; nz <= 64; ++nz) {
+        if (nz > 1 && M / nz < 512) break;
+        const long long wgs = (long long)tiles * nz;
+        const double eff = (double)wgs / (double)(((wgs + slots - 1) / slots) * slots);
+        const double t_mma = flops / 450e12 / eff;
+        const double t_slab = nz > 1 ? (2.0 * nz * out_elems * 4.0) / 4.0e12 : 0.0;
+        const double cost = t_mma + t_slab;
+        if (cost < best_cost * 0.97) { best_cost = cost; best = nz; }
+    }
+    return best;
 }
 
 static inline bool wgrad_use_gemm2(int dtype, int M, int N, int K) { return dtype == EGV_BF16 && N >= 128 && K >= 64 && M >= 256; }
 
-extern "C" long long egv_gemm_wgrad_workspace_bytes(int N, int K, int M) {
-    // slabs of fp32 [N,K]; upper bound over both kernel paths
-    const int t1 = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
-    const int t2 = ((N + 255) / 256) * ((K + 127) / 128);
-    const int nz = max(wgrad_splits(t1, M), wgrad_splits(t2, M));
-    return (long long)nz * N * K * 4;
+static inline int wgrad_plan(int dtype, int M, int N, int K, bool& v2) {
+    v2 = wgrad_use_gemm2(dtype, M, N, K);
+    if (v2) {
+        const int tb = ((N + 255) / 256) * ((K + 127) / 128);
+        return wgrad_splits(tb, M, (long long)N * K, 2.0 * M * N * K, 256);
+    }
+    return wgrad_splits(((N + BM - 1) / BM) * ((K + BN - 1) / BN), M, (long long)N * K, 2.0 * M * N * K, 512);
 }
 
-// dW[N,K] (fp32) = scale * gate * dY[M,N]^T X[M,K], reduction over M split across blockIdx.z.
+extern "C" long long egv_gemm_wgrad_workspace_bytes(int N, int K, int M) {
+    // fp32 slabs [nz][N,K] + [nz][N] column-sum partials + the colsum fallback workspace
+    bool v2;
+    const int nz = wgrad_plan(EGV_BF16, M, N, K, v2);
+    bool v2f;
+    const int nzf = wgrad_plan(EGV_F32, M, N, K, v2f);
+    const long long z = nz > nzf ? nz : nzf;
+    return z * N * K * 4 + z * N * 4 + (long long)32 * N * 4 + 4096;
+}
+
+extern "C" int egv_colsum(int dtype, const void* X, int M, int N, int ld, float* out, float scale, const float* gate,
+                          void* workspace, void* stream);
+
+// dW[N,K] (fp32) = scale * gate * dY[M,N]^T X[M,K], reduction over M split across blockIdx.z;
+// dbias[N] (fp32, optional) = scale * gate * sum_m dY[m, :]  (fused: the wgrad kernel already streams dY).
 extern "C" int egv_gemm_wgrad(int dtype, int M, int N, int K, const void* dY, int ldy, const void* X, int ldx,
-                              float* dW, float scale, const float* gate, void* workspace, long long workspace_bytes,
+                              float* dW, float* dbias, float scale, const float* gate, void* workspace, long long workspace_bytes,
                               void* stream) {
     EGV_CHECK(dtype == EGV_F32 || dtype == EGV_BF16, "egv_gemm_wgrad: bad dtype %d", dtype);
     EGV_CHECK(M > 0 && N > 0 && K > 0, "egv_gemm_wgrad: bad shape");
-    const bool v2 = wgrad_use_gemm2(dtype, M, N, K);
-    int tiles;
-    if (v2) {
-        const int ta = ((N + 255) / 256) * ((K + 255) / 256), tb = ((N + 255) / 256) * ((K + 127) / 128);
-        tiles = (ta >= 256) ? ta : tb;
-    } else {
-        tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
-    }
-    int nz = wgrad_splits(tiles, M);
+    EGV_CHECK(workspace && workspace_bytes >= egv_gemm_wgrad_workspace_bytes(N, K, M), "egv_gemm_wgrad: workspace too small");
+    bool v2;
+    int nz = wgrad_plan(dtype, M, N, K, v2);
     const int bk = dtype == EGV_BF16 ? 64 : 32;
     int kper = (M + nz - 1) / nz;
     kper = ((kper + bk - 1) / bk) * bk;
     nz = (M + kper - 1) / kper;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float* slabs = (float*)workspace;
+    float* bias_part = slabs + (size_t)nz * N * K;          // [nz][N]
+    void* cs_ws = bias_part + (size_t)nz * N;
     GemmArgs g;
     g.A = dY; g.B = X;
     g.M = N; g.N = K; g.K = M;           // output rows = N (of dY), cols = K (of X), reduction = M
@@ -360,6 +383,7 @@ extern "C" int egv_gemm_wgrad(int dtype, int M, int N, int K, const void* dY, in
     g.k_per_split = kper;
     g.tiles_m = (N + BM - 1) / BM;
     g.tiles_n = (K + BN - 1) / BN;
+    g.colsum = nullptr;
     g.e = GemmEpi{};
     g.e.ldr = K;
     if (nz == 1) {
@@ -367,15 +391,23 @@ extern "C" int egv_gemm_wgrad(int dtype, int M, int N, int K, const void* dY, in
         g.c_vec_ok = vec_ok(dW, K, EGV_F32);
         g.e.scale = scale; g.e.gate = gate;
     } else {
-        EGV_CHECK(workspace && workspace_bytes >= (long long)nz * N * K * 4, "egv_gemm_wgrad: workspace too small");
-        g.C = workspace; g.slab_stride = (long long)N * K;
-        g.c_vec_ok = vec_ok(workspace, K, EGV_F32) && (((long long)N * K) % 4 == 0);
+        g.C = slabs; g.slab_stride = (long long)N * K;
+        g.c_vec_ok = vec_ok(slabs, K, EGV_F32) && (((long long)N * K) % 4 == 0);
         g.e.scale = 1.0f;
     }
     void* ph = egv_prof_begin(stream);
-    if (v2 && egv_gemm2_launch(g, 1, 1, 1, nz, st)) {
-        egv_prof_end(ph, stream, 2.0 * M * N * K, 10);
-    } else {
+    bool bias_fused = false;
+    if (v2) {
+        if (dbias) g.colsum = bias_part;
+        if (egv_gemm2_launch(g, 1, 1, 1, nz, st)) {
+            egv_prof_end(ph, stream, 2.0 * M * N * K, 10);
+            bias_fused = dbias != nullptr;
+        } else {
+            v2 = false;
+            g.colsum = nullptr;
+        }
+    }
+    if (!v2) {
         if (dtype == EGV_BF16) launch_gemm<bf16_t, 1, 1, float>(g, nz, st);
         else launch_gemm<float, 1, 1, float>(g, nz, st);
         egv_prof_end(ph, stream, 2.0 * M * N * K, (dtype == EGV_BF16 ? 0 : 4) + 2);
@@ -385,9 +417,19 @@ extern "C" int egv_gemm_wgrad(int dtype, int M, int N, int K, const void* dY, in
         const long long n = (long long)N * K;
         int blocks = (int)((n + 255) / 256);
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dW, n, nz,
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, (const float*)slabs, dW, n, nz,
                            (long long)N * K, scale, gate);
         EGV_LAUNCH_CHECK();
+    }
+    if (dbias) {
+        if (bias_fused) {
+            const int blocks = (N + 255) / 256;
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, (const float*)bias_part, dbias, (long long)N, nz,
+                               (long long)N, scale, gate);
+            EGV_LAUNCH_CHECK();
+        } else {
+            return egv_colsum(dtype, dY, M, N, ldy, dbias, scale, gate, cs_ws, stream);
+        }
     }
     return 0;
 }

@@ -48,26 +48,16 @@ struct TUnit {
 };
 
 template <int ROWS>
-__device__ __forceinline__ void tload(TUnit& u, const bf16_t* base, int rows_total, int ld, int row0, int k0, int kend, int unit,
-                                      bool vec_ok) {
+__device__ __forceinline__ void tload(TUnit& u, const bf16_t* base, int rows_total, int ld, int row0, int k0, int kend, int unit) {
     constexpr int RB = ROWS / 8;
     const int kb = unit / RB, rb = unit % RB;
     const int grow0 = row0 + rb * 8;
-    const int nv_rows = rows_total - grow0;
+    const bool row_ok = grow0 < rows_total;          // rows_total % 8 == 0 is a launch precondition
+    const bf16_t* p = base + (size_t)(k0 + kb * 8) * ld + grow0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int gk = k0 + kb * 8 + j;
         u32x4_t x = {0u, 0u, 0u, 0u};
-        if (gk < kend && nv_rows > 0) {
-            const bf16_t* p = base + (size_t)gk * ld + grow0;
-            if (nv_rows >= 8 && vec_ok) {
-                x = *reinterpret_cast<const u32x4_t*>(p);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (e < nv_rows) x[e >> 1] |= ((unsigned int)reinterpret_cast<const unsigned short*>(p)[e]) << ((e & 1) * 16);
-            }
-        }
+        if (row_ok && k0 + kb * 8 + j < kend) x = *reinterpret_cast<const u32x4_t*>(p + (size_t)j * ld);
         u.r[j] = x;
     }
 }
@@ -115,38 +105,41 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // transposed-operand unit assignment: A units on threads [0, BM), B units on threads [BM, BM+BN) when both are
-    // transposed; a single transposed operand uses threads [0, rows)
+    // transposed-operand unit assignment: A units on threads [0, BM), B units on threads [BM, BM+BN)
+    static_assert(AT && BT, "gemm2_kernel is the wgrad (both operands reduction-major) kernel");
     const int unitA = tid;
-    const int unitB = (AT && BT) ? tid - BM : tid;
-    const bool hasA = AT && unitA < BM;
-    const bool hasB = BT && unitB >= 0 && unitB < BN;
-    TUnit ua, ub;
+    const int unitB = tid - BM;
+    const bool hasA = unitA < BM;
+    const bool hasB = unitB >= 0 && unitB < BN;
+    TUnit ur[1];                       // next K-tile in flight in registers
+    float bsum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+    const bool want_colsum = (g.colsum != nullptr) && (tn == 0);
 
-    auto issue = [&](int k0, int stage) {
+    auto issue = [&](TUnit& u, int k0) {
+        if (hasA) tload<BM>(u, A, g.M, g.lda, m0, k0, kend, unitA);
+        else if (hasB) tload<BN>(u, B, g.N, g.ldb, n0, k0, kend, unitB);
+    };
+    auto commit = [&](const TUnit& u, int stage) {
         unsigned char* sA = smem + stage * CFG::STAGE;
         unsigned char* sB = sA + BM * 128;
-        if constexpr (!AT) stage_dma<BM>(A, g.M, g.lda, m0, k0, sA, wave, lane);
-        else if (hasA) tload<BM>(ua, A, g.M, g.lda, m0, k0, kend, unitA, g.a_vec_ok != 0);
-        if constexpr (!BT) stage_dma<BN>(B, g.N, g.ldb, n0, k0, sB, wave, lane);
-        else if (hasB) tload<BN>(ub, B, g.N, g.ldb, n0, k0, kend, unitB, g.b_vec_ok != 0);
+        if (hasA) {
+            tstore<BM>(u, sA, unitA);
+            if (want_colsum) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        bsum[2 * d] += __uint_as_float(u.r[j][d] << 16);
+                        bsum[2 * d + 1] += __uint_as_float(u.r[j][d] & 0xffff0000u);
+                    }
+            }
+        } else if (hasB) {
+            tstore<BN>(u, sB, unitB);
+        }
     };
-    auto commit = [&](int stage) {      // write register-staged operands of the tile issued last
-        unsigned char* sA = smem + stage * CFG::STAGE;
-        unsigned char* sB = sA + BM * 128;
-        if constexpr (AT) { if (hasA) tstore<BM>(ua, sA, unitA); }
-        if constexpr (BT) { if (hasB) tstore<BN>(ub, sB, unitB); }
-    };
-
-    issue(kbeg, 0);
-    commit(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    int stage = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += 64) {
-        const bool more = k0 + 64 < kend;
-        if (more) issue(k0 + 64, stage ^ 1);
+    auto compute = [&](int stage) {
         const unsigned char* sA = smem + stage * CFG::STAGE;
         const unsigned char* sB = sA + BM * 128;
 #pragma unroll
@@ -162,10 +155,39 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmArgs g) {
                 for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a, acc[i][j], 0, 0, 0);
             }
         }
-        if (more) commit(stage ^ 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    // software pipeline: the loads of tile t+1 are in flight (registers) while tile t feeds the MFMAs from LDS stage t&1
+    issue(ur[0], kbeg);
+    commit(ur[0], 0);
+    __syncthreads();
+    int stage = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += 64) {
+        const bool more = k0 + 64 < kend;
+        if (more) issue(ur[0], k0 + 64);
+        compute(stage);
+        if (more) commit(ur[0], stage ^ 1);
         __syncthreads();
         stage ^= 1;
+    }
+
+    if (want_colsum) {
+        // threads with the same row block rb (unit % RB) hold partial sums of 8 different k blocks: combine through LDS
+        float* red = reinterpret_cast<float*>(smem);                 // [8 kb][BM]
+        __syncthreads();
+        if (hasA) {
+            constexpr int RB = BM / 8;
+            const int kb = unitA / RB, rb = unitA % RB;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[kb * BM + rb * 8 + e] = bsum[e];
+        }
+        __syncthreads();
+        if (tid < BM && m0 + tid < g.M) {
+            float t = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) t += red[kb * BM + tid];
+            g.colsum[(size_t)blockIdx.z * g.M + m0 + tid] = t;
+        }
     }
 
     OutT* C = reinterpret_cast<OutT*>(g.C) + (size_t)blockIdx.z * g.slab_stride;
@@ -397,6 +419,9 @@ int egv_gemm2_launch(const GemmArgs& g, int a_trans, int b_trans, int out_f32, i
             return 0;
     } else {
         if (!out_f32) return 0;                                        // wgrad writes fp32 (slabs or dW)
+        if (!g.a_vec_ok || !g.b_vec_ok || (g.M % 8) || (g.N % 8)) return 0;
+        launch2<CfgB, 1, 1, float>(g, nz, st);
+        return 1;
     }
     const bool useA = wave_eff(g.M, g.N, 256, 256, nz) >= wave_eff(g.M, g.N, 256, 128, nz) * 0.98;
     if (!a_trans) {

@@ -137,14 +137,15 @@ def gemm(x, w, out, *, a_trans=0, b_trans=0, M, N, K, lda, ldb, ldc, bias=None, 
                        _p(gate), _p(res1), _p(res2), _p(pre), _p(aux), dact, ldc, float(scale), _st()), 'egv_gemm')
 
 
-def wgrad(dy, x, M, N, K, gate=None, scale=1.0, ldy=None):
-    """dW[N,K] fp32 = scale*gate * dy[M,N]^T x[M,K]"""
+def wgrad(dy, x, M, N, K, gate=None, scale=1.0, ldy=None, bias=False):
+    """dW[N,K] fp32 = scale*gate * dy[M,N]^T x[M,K]  (and, with bias=True, db[N] = scale*gate * colsum(dy) from the same pass)"""
     dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+    db = torch.empty(N, dtype=torch.float32, device=dy.device) if bias else None
     nb = lib.egv_gemm_wgrad_workspace_bytes(N, K, M)
     ws = workspace(nb, dy.device)
-    check(lib.egv_gemm_wgrad(_dt(dy), M, N, K, _p(dy), N if ldy is None else ldy, _p(x), K, _p(dw), float(scale), _p(gate),
-                             _p(ws), nb, _st()), 'egv_gemm_wgrad')
-    return dw
+    check(lib.egv_gemm_wgrad(_dt(dy), M, N, K, _p(dy), N if ldy is None else ldy, _p(x), K, _p(dw), _p(db), float(scale),
+                             _p(gate), _p(ws), nb, _st()), 'egv_gemm_wgrad')
+    return (dw, db) if bias else dw
 
 
 def colsum(dy, M, N, gate=None, scale=1.0, ld=None):
@@ -210,8 +211,11 @@ class LinearFn(Function):
             dgrad(dz, weight, dx, M, N, K, gate=gate)
             dx = dx.reshape(ctx.xshape)
         if ctx.needs_input_grad[1]:
-            dw = wgrad(dz, x2, M, N, K, gate=gate)
-        if has_b and ctx.needs_input_grad[2]:
+            if has_b and ctx.needs_input_grad[2]:
+                dw, db = wgrad(dz, x2, M, N, K, gate=gate, bias=True)
+            else:
+                dw = wgrad(dz, x2, M, N, K, gate=gate)
+        elif has_b and ctx.needs_input_grad[2]:
             db = colsum(dz, M, N, gate=gate)
         if has_g and ctx.needs_input_grad[3]:
             dg = dot(dy2, pre)
@@ -260,10 +264,8 @@ class MlpFn(Function):
             dy2 = dy2.contiguous()
         dpre = torch.empty(M, Hd, dtype=dy2.dtype, device=dy2.device)
         dgrad(dy2, w2, dpre, M, N, Hd, aux=pre, dact=L.ACT_GELU)
-        dw2 = wgrad(dy2, h, M, N, Hd)
-        db2 = colsum(dy2, M, N)
-        dw1 = wgrad(dpre, x2, M, Hd, K)
-        db1 = colsum(dpre, M, Hd)
+        dw2, db2 = wgrad(dy2, h, M, N, Hd, bias=True)
+        dw1, db1 = wgrad(dpre, x2, M, Hd, K, bias=True)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, dtype=dy2.dtype, device=dy2.device)
@@ -302,8 +304,7 @@ class VocabLinearFn(Function):
         w = compute_weight(weight, dy.dtype)
         dx = torch.empty(M, K, dtype=dy.dtype, device=dy.device)
         gemm(dy, w, dx, a_trans=0, b_trans=1, M=M, N=K, K=V, lda=Vp, ldb=K, ldc=K)
-        dw = wgrad(dy, x2, M, V, K, ldy=Vp)
-        db = colsum(dy, M, V, ld=Vp)
+        dw, db = wgrad(dy, x2, M, V, K, ldy=Vp, bias=True)
         return dx.reshape(ctx.xshape), dw, db, None
 
 
@@ -560,8 +561,8 @@ class PatchTokensFn(Function):
         check(lib.egv_assemble_tokens_bwd(dt, _p(dX), _p(dpatch), _p(dcls), _p(dpos), _p(dtem), B, Fr, N, D, _p(ws), _st()),
               'egv_assemble_tokens_bwd')
         M = B * Fr * N
-        dw = wgrad(dpatch, patches, M, D, Kp).reshape(wshape)
-        db = colsum(dpatch, M, D)
+        dw, db = wgrad(dpatch, patches, M, D, Kp, bias=True)
+        dw = dw.reshape(wshape)
         return None, dw, db, dcls.reshape(cshape), dpos.reshape(pshape), dtem.reshape(tshape), None
 
 

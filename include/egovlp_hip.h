@@ -56,10 +56,12 @@ int egv_gemm(int dtype, int a_trans, int b_trans, int M, int N, int K,
              void* pre, const void* aux, int dact, int ldr, float scale, void* stream);
 
 /* wgrad: dW[N,K] (fp32) = scale * (*gate) * dY[M,N]^T X[M,K]; reduction over the M tokens is split across
- * workgroups into fp32 slabs in `workspace` and summed in a fixed order (deterministic). */
+ * workgroups into fp32 slabs in `workspace` and summed in a fixed order (deterministic).  If dbias != NULL it also
+ * returns dbias[N] (fp32) = scale * (*gate) * sum_m dY[m,:] from the same pass over dY (bias gradient of the Linear). */
 long long egv_gemm_wgrad_workspace_bytes(int N, int K, int M);
 int egv_gemm_wgrad(int dtype, int M, int N, int K, const void* dY, int ldy, const void* X, int ldx,
-                   float* dW, float scale, const float* gate, void* workspace, long long workspace_bytes, void* stream);
+                   float* dW, float* dbias, float scale, const float* gate, void* workspace, long long workspace_bytes,
+                   void* stream);
 
 /* ---- LayerNorm (video_transformer.py:196,207,210,304,115; roberta.py:160,336,417; model.py:155;
  * BertPredictionHeadTransform.LayerNorm heads.py:41).  stats = [M][2] fp32 {mean, rstd} (may be NULL in
