@@ -397,6 +397,166 @@ static void launch_ring(GemmArgs g, hipStream_t st) {
     hipLaunchKernelGGL((gemm_ring_kernel<CFG, NS>), dim3(g.tiles_m * g.tiles_n), dim3(512), lds, st, g);
 }
 
+// ------------------------------------------------------------------------------------------------
+// wgrad ring kernel: both operands are stored [reduction, rows] (dY [M,N], X [M,K]).  The K-tile (32 reduction rows x
+// BM / BN contiguous columns) is DMA-staged AS STORED (buffer_load ... lds, out-of-range reduction rows read as zero
+// through the buffer descriptor) and the MFMA fragments (8 consecutive reduction elements of one column) are gathered
+// with the gfx950 transposing LDS read ds_read_b64_tr_b16 (2 per fragment).  16-byte chunk c of reduction row k is
+// stored at chunk c ^ f(k), f(k) = 2*((k & 3) + 4*((k >> 3) & 1)): the 32 lanes of a half-wave then cover all 64 banks
+// exactly once per transposing read.  Same NS-stage ring / counted-vmcnt schedule as gemm_ring_kernel; the column sums
+// of the A operand (bias gradient) are accumulated from the fragments that are already in registers.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+__device__ __forceinline__ int swz_k(int k) { return 2 * ((k & 3) + 4 * ((k >> 3) & 1)); }
+
+// COLS contiguous columns per reduction row; one 1-KiB piece = 1024 / (COLS*2) reduction rows
+template <int COLS>
+__device__ __forceinline__ void wring_dma(__amdgpu_buffer_rsrc_t rsrc, int ld, int col0, int k0, unsigned char* s, int wave, int lane) {
+    constexpr int CH = COLS / 8;                 // 16-byte chunks per reduction row
+    constexpr int RPP = 64 / CH;                 // reduction rows per piece
+    constexpr int NPIECE = 32 / RPP;             // pieces per K-tile
+    const int kr = lane / CH, cp = lane % CH;
+#pragma unroll
+    for (int p = wave; p < NPIECE; p += 8) {
+        const int k = p * RPP + kr;
+        const int c = cp ^ swz_k(k);
+        const int voff = ((k0 + k) * ld + col0 + c * 8) * 2;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(s + p * 1024), 16, voff, 0, 0, 0);
+    }
+}
+
+// fragment: 8 consecutive reduction rows (g*8 .. g*8+7) of column idx0 + fr, from a [32][COLS] tile
+template <int COLS>
+__device__ __forceinline__ bf16x8_t wfrag(const unsigned char* s, int idx0, int fr, int fg) {
+    const int c16 = (idx0 >> 3) + ((fr >> 1) & 1);
+    const int f = 2 * ((fr >> 2) + 4 * (fg & 1));
+    const int krow = fg * 8 + (fr >> 2);
+    const unsigned char* p = s + krow * (COLS * 2) + ((c16 ^ f) * 16) + (fr & 1) * 8;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + 4 * COLS * 2));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <typename CFG, int NS>
+__global__ __launch_bounds__(512) void gemm_wgrad_ring_kernel(const GemmArgs g) {
+    constexpr int BM = CFG::BM, BN = CFG::BN, MI = CFG::MI, NI = CFG::NI;
+    constexpr int STG = (BM + BN) * 64;                        // bytes per stage (32 reduction rows)
+    constexpr int P = ((BM + BN) * 64) / (8 * 1024);           // DMA instructions per wave per K-tile
+    static_assert((BM * 64) % (8 * 1024) == 0 && (BN * 64) % (8 * 1024) == 0, "pieces must divide evenly over 8 waves");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = wave_id();
+    const int wm = wave / CFG::WGN, wn = wave % CFG::WGN;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    const int ntile = g.tiles_m * g.tiles_n;
+    const int t = xcd_remap(blockIdx.x, ntile);
+    const int tm = t / g.tiles_n, tn = t % g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = blockIdx.z * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+
+    // buffer descriptors over the whole operands: reduction rows >= K read as zero
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, g.K * g.lda * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), 0, g.K * g.ldb * 2, 0x00020000);
+
+    f32x4_t acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float bsum[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) bsum[i] = 0.f;
+    const bool want_colsum = (g.colsum != nullptr) && (tn == 0) && (wn == 0);
+
+    const int nt = (kend - kbeg + 31) / 32;
+    auto issue = [&](int kt, int slot) {
+        unsigned char* sA = smem + slot * STG;
+        wring_dma<BM>(ra, g.lda, m0, kbeg + kt * 32, sA, wave, lane);
+        wring_dma<BN>(rb, g.ldb, n0, kbeg + kt * 32, sA + BM * 64, wave, lane);
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nt) issue(s, s);
+
+    int slot = 0, islot = NS - 1;
+    for (int kt = 0; kt < nt; ++kt) {
+        const int rem = nt - 1 - kt;
+        if (rem >= NS - 2) wait_vmcnt<P*(NS - 2)>();
+        else if (NS > 3 && rem == 1) wait_vmcnt<P>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS - 1 < nt) issue(kt + NS - 1, islot);
+        const unsigned char* sA = smem + slot * STG;
+        const unsigned char* sB = sA + BM * 64;
+        bf16x8_t b[NI], a[MI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) b[j] = wfrag<BN>(sB, wn * NI * 16 + j * 16, fr, fg);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = wfrag<BM>(sA, wm * MI * 16 + i * 16, fr, fg);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (want_colsum) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const u32x4_t u = __builtin_bit_cast(u32x4_t, a[i]);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) bsum[i] += __uint_as_float(u[d] << 16) + __uint_as_float(u[d] & 0xffff0000u);
+            }
+        }
+        slot = (slot + 1 == NS) ? 0 : slot + 1;
+        islot = (islot + 1 == NS) ? 0 : islot + 1;
+    }
+
+    if (want_colsum) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            float v = bsum[i];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int row = m0 + wm * MI * 16 + i * 16 + fr;
+            if (fg == 0 && row < g.M) g.colsum[(size_t)blockIdx.z * g.M + row] = v;
+        }
+    }
+
+    float* C = reinterpret_cast<float*>(g.C) + (size_t)blockIdx.z * g.slab_stride;
+    const float gate = g.e.gate ? *g.e.gate : 1.0f;
+#pragma clang loop unroll(full)
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + wm * MI * 16 + mi * 16 + fr;
+        if (m >= g.M) continue;
+#pragma clang loop unroll(full)
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = n0 + wn * NI * 16 + ni * 16 + fg * 4;
+            if (n >= g.N) continue;
+            float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+            gemm_epilogue4<bf16_t, float>(g, C, m, n, v, gate);
+        }
+    }
+}
+
+template <typename CFG, int NS>
+static void launch_wgrad_ring(GemmArgs g, int nz, hipStream_t st) {
+    g.tiles_m = (g.M + CFG::BM - 1) / CFG::BM;
+    g.tiles_n = (g.N + CFG::BN - 1) / CFG::BN;
+    const size_t lds = (size_t)NS * (CFG::BM + CFG::BN) * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_ring_kernel<CFG, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_wgrad_ring_kernel<CFG, NS>), dim3(g.tiles_m * g.tiles_n, 1, nz), dim3(512), lds, st, g);
+}
+
 }  // namespace egv
 using namespace egv;
 
@@ -420,7 +580,9 @@ int egv_gemm2_launch(const GemmArgs& g, int a_trans, int b_trans, int out_f32, i
     } else {
         if (!out_f32) return 0;                                        // wgrad writes fp32 (slabs or dW)
         if (!g.a_vec_ok || !g.b_vec_ok || (g.M % 8) || (g.N % 8)) return 0;
-        launch2<CfgB, 1, 1, float>(g, nz, st);
+        if ((long long)g.K * g.lda * 2 >= (1LL << 31) || (long long)g.K * g.ldb * 2 >= (1LL << 31)) return 0;   // 32-bit buffer range
+        if (g.k_per_split % 32) return 0;
+        launch_wgrad_ring<CfgB, 4>(g, nz, st);
         return 1;
     }
     const bool useA = wave_eff(g.M, g.N, 256, 256, nz) >= wave_eff(g.M, g.N, 256, 128, nz) * 0.98;
