@@ -338,7 +338,7 @@ static inline int wgrad_plan(int dtype, int M, int N, int K, bool& v2) {
     v2 = wgrad_use_gemm2(dtype, M, N, K);
     if (v2) {
         const int tb = ((N + 255) / 256) * ((K + 127) / 128);
-        return wgrad_splits(tb, M, (long long)N * K, 2.0 * M * N * K, 256);
+        return wgrad_splits(tb, M, (long long)N * K, 2.0 * M * N * K, 512);
     }
     return wgrad_splits(((N + BM - 1) / BM) * ((K + BN - 1) / BN), M, (long long)N * K, 2.0 * M * N * K, 512);
 }

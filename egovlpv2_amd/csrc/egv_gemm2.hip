@@ -582,12 +582,13 @@ int egv_gemm2_launch(const GemmArgs& g, int a_trans, int b_trans, int out_f32, i
         if (!g.a_vec_ok || !g.b_vec_ok || (g.M % 8) || (g.N % 8)) return 0;
         if ((long long)g.K * g.lda * 2 >= (1LL << 31) || (long long)g.K * g.ldb * 2 >= (1LL << 31)) return 0;   // 32-bit buffer range
         if (g.k_per_split % 32) return 0;
-        launch_wgrad_ring<CfgB, 4>(g, nz, st);
+        launch_wgrad_ring<CfgB, 3>(g, nz, st);
         return 1;
     }
     const bool useA = wave_eff(g.M, g.N, 256, 256, nz) >= wave_eff(g.M, g.N, 256, 128, nz) * 0.98;
     if (!a_trans) {
-        if (useA) launch_ring<CfgA, 4>(g, st); else launch_ring<CfgB, 4>(g, st);
+        (void)useA;
+        launch_ring<CfgB, 3>(g, st);      // 256x128 tile x 3 stages = 72 KB: 2 workgroups per CU (epilogue of one overlaps the K loop of the other)
     } else {
         if (useA) launch2<CfgA, 1, 1, float>(g, nz, st); else launch2<CfgB, 1, 1, float>(g, nz, st);
     }
