@@ -244,12 +244,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
 
 // sum split-K slabs: out[i] = scale * gate * sum_z slab[z][i]   (fp32, deterministic order)
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out, long long n, int nz,
-                                    long long stride, float scale, const float* gate) {
+                                    long long stride, float scale, const float* gate, const float* __restrict__ slabs2,
+                                    float* __restrict__ out2, long long n2) {
     const float gsc = scale * (gate ? *gate : 1.0f);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int z = 0; z < nz; ++z) s += slabs[(size_t)z * stride + i];
         out[i] = s * gsc;
+    }
+    // optional second, small reduction (bias-gradient partials [nz][n2]) in the same launch
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < nz; ++z) s += slabs2[(size_t)z * n2 + i];
+        out2[i] = s * gsc;
     }
 }
 
@@ -413,19 +420,21 @@ extern "C" int egv_gemm_wgrad(int dtype, int M, int N, int K, const void* dY, in
         egv_prof_end(ph, stream, 2.0 * M * N * K, (dtype == EGV_BF16 ? 0 : 4) + 2);
     }
     EGV_LAUNCH_CHECK();
+    const bool fuse_bias_reduce = dbias && bias_fused && nz > 1;
     if (nz > 1) {
         const long long n = (long long)N * K;
         int blocks = (int)((n + 255) / 256);
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, (const float*)slabs, dW, n, nz,
-                           (long long)N * K, scale, gate);
+                           (long long)N * K, scale, gate, fuse_bias_reduce ? (const float*)bias_part : (const float*)nullptr,
+                           fuse_bias_reduce ? dbias : (float*)nullptr, fuse_bias_reduce ? (long long)N : 0LL);
         EGV_LAUNCH_CHECK();
     }
-    if (dbias) {
+    if (dbias && !fuse_bias_reduce) {
         if (bias_fused) {
             const int blocks = (N + 255) / 256;
             hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, (const float*)bias_part, dbias, (long long)N, nz,
-                               (long long)N, scale, gate);
+                               (long long)N, scale, gate, (const float*)nullptr, (float*)nullptr, 0LL);
             EGV_LAUNCH_CHECK();
         } else {
             return egv_colsum(dtype, dY, M, N, ldy, dbias, scale, gate, cs_ws, stream);

@@ -13,6 +13,7 @@
 // Ragged edges: rows beyond M/N are clamped on load (their products are never stored); the reduction tail of wgrad is
 // zero-filled; direct operands require K % 64 == 0 (true for every Linear of the model), otherwise the caller falls back.
 #include "egv_gemm.h"
+#include <cstdlib>
 
 namespace egv {
 
@@ -27,6 +28,7 @@ struct Cfg {
 };
 using CfgA = Cfg<2, 4, 8, 4>;   // 256 x 256
 using CfgB = Cfg<4, 2, 4, 4>;   // 256 x 128
+using CfgC = Cfg<4, 2, 2, 4>;   // 128 x 128 (3 workgroups per CU with a 3-stage ring: fills the wave-quantisation tail of N=768 GEMMs)
 
 // ---- DMA staging of a K-contiguous operand tile: ROWS rows x 128 B into s (swizzled) ----
 template <int ROWS>
@@ -588,7 +590,11 @@ int egv_gemm2_launch(const GemmArgs& g, int a_trans, int b_trans, int out_f32, i
     const bool useA = wave_eff(g.M, g.N, 256, 256, nz) >= wave_eff(g.M, g.N, 256, 128, nz) * 0.98;
     if (!a_trans) {
         (void)useA;
-        launch_ring<CfgB, 3>(g, st);      // 256x128 tile x 3 stages = 72 KB: 2 workgroups per CU (epilogue of one overlaps the K loop of the other)
+        static const int force = getenv("EGV_GEMM_CFG") ? atoi(getenv("EGV_GEMM_CFG")) : 0;     // experiments only
+        const long long tb = (long long)((g.M + 255) / 256) * ((g.N + 127) / 128);
+        if (force == 3) launch_ring<CfgC, 3>(g, st);
+        else if (tb <= 128) launch_ring<CfgB, 6>(g, st);     // latency-bound small grids (text tokens): 5 K-tiles in flight
+        else launch_ring<CfgB, 3>(g, st);      // 256x128 tile x 3 stages = 72 KB: 2 workgroups per CU (epilogue of one overlaps the K loop of the other)
     } else {
         if (useA) launch2<CfgA, 1, 1, float>(g, nz, st); else launch2<CfgB, 1, 1, float>(g, nz, st);
     }

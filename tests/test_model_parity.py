@@ -152,3 +152,64 @@ def test_base_f4_vs_golden(dtype, tol_e, tol_l):
     rel = (np.abs(gn - g['grad_norms']) / (g['grad_norms'] + 1e-5))[keep]
     kn = [k for k, kk in zip(names, keep) if kk]
     assert (rel < gtol).all(), [(kn[i], float(rel[i])) for i in np.argsort(-rel)[:8]]
+
+
+@pytest.mark.parametrize('dtype,tol_e,tol_l', [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 3e-2, 2e-2)])
+def test_full_resolution_two_layer_vs_oracle(dtype, tol_e, tol_l):
+    """BASELINE.json's full token geometry (16 x 224^2 frames -> S = 3137 tokens, 197-key space attention, 17-key time
+    attention, 32 text tokens) on a 2+2-layer / 1-fused-layer model, where the CPU oracle still finishes in seconds:
+    embeddings, the three losses and every parameter gradient against the oracle."""
+    from oracle import ref_model as O
+    from egovlpv2_amd.config import PathConfig
+    cfg = PathConfig(depth=2, n_fuse=1, frames=16, img=224)
+    B, L = 2, 32
+    sd, data, noun, verb, oc = oracle_setup(cfg, B, L, 5, 77, requires_grad=True)
+    m = _build(cfg, sd, dtype)
+    np.random.seed(5)
+    torch.manual_seed(5)
+    loss, ld, ret = _forward(m, data, noun, verb, 'EgoNCE_MLM_ITM')
+    loss.backward()
+    np.random.seed(5)
+    torch.manual_seed(5)
+    oloss, old, oret = O.forward_losses(sd, data, noun, verb, oc, 'EgoNCE_MLM_ITM')
+    oloss.backward()
+    assert rel_err(ret['video_embeds'].float(), oret['video_embeds']) < tol_e
+    assert rel_err(ret['text_embeds'].float(), oret['text_embeds']) < tol_e
+    for k in old:
+        a, b = float(ld[k].detach()), float(old[k].detach())
+        assert abs(a - b) <= tol_l * abs(b), (k, a, b)
+    if dtype == torch.float32:
+        bad = []
+        for name, p in m.named_parameters():
+            if name.endswith('.key.bias'):
+                continue
+            a, r = p.grad.double().cpu().reshape(-1), sd[name].grad.double().reshape(-1)
+            if (a - r).norm().item() > 5e-3 * r.norm().item() + 2e-6:
+                bad.append((name, ((a - r).norm() / r.norm()).item()))
+        assert not bad, bad[:10]
+    else:
+        ga = torch.cat([p.grad.double().cpu().reshape(-1) for _, p in m.named_parameters()])
+        gr = torch.cat([sd[n].grad.double().reshape(-1) for n, _ in m.named_parameters()])
+        assert float(torch.dot(ga, gr) / (ga.norm() * gr.norm())) > 0.99
+        assert float((ga - gr).norm() / gr.norm()) < 0.15
+
+
+def test_batch_independence_full_size_bf16():
+    """size-independent property at BASELINE.json's full configuration (ViT-B/16 + RoBERTa-base, 12+12 layers, 16 x 224^2,
+    32 tokens): the pooled embeddings of a sample do not depend on what else is in the batch (exercises the b-offsets of
+    every row-set / tile computation at B=8)."""
+    from egovlpv2_amd.config import PathConfig
+    from egovlpv2_amd.synthetic import make_state_dict, make_batch
+    cfg = PathConfig(frames=16)
+    sd = make_state_dict(cfg, 3)
+    m = _build(cfg, sd, torch.bfloat16)
+    data, _, _ = make_batch(cfg, 8, 32, 11)
+    cu = _to_cuda(data)
+    with torch.no_grad():
+        full = m.infer(cu, task_names='EgoNCE')
+        one = {'video': cu['video'][5:6], 'text': {k: v[5:6] for k, v in cu['text'].items()}}
+        single = m.infer(one, task_names='EgoNCE')
+    # identical kernels and reduction orders per sample -> bitwise equal rows
+    assert torch.equal(full['video_embeds'][5], single['video_embeds'][0])
+    assert torch.equal(full['text_embeds'][5], single['text_embeds'][0])
+    assert torch.isfinite(full['video_embeds'].float()).all()
