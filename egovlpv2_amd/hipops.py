@@ -48,7 +48,7 @@ _ws = {}
 
 
 def workspace(nbytes: int, device, slot: int = 0) -> torch.Tensor:
-    key = (device, slot)
+    key = (device, slot, torch.cuda.current_stream().cuda_stream)      # one scratch buffer per stream
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -60,6 +60,20 @@ def workspace(nbytes: int, device, slot: int = 0) -> torch.Tensor:
 _wcache = {}
 
 
+def _cast_event():
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    return ev
+
+
+def _cross_stream(ent):
+    """a cached copy made on another stream: order this stream after the cast kernel, keep the allocator informed"""
+    if ent[3] != _st():
+        torch.cuda.current_stream().wait_event(ent[4])
+        ent[1].record_stream(torch.cuda.current_stream())
+    return ent[1]
+
+
 def compute_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """fp32 parameter -> tensor in the compute dtype (cached per parameter version)."""
     if dtype == torch.float32:
@@ -67,13 +81,13 @@ def compute_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     key = id(w)
     ent = _wcache.get(key)
     if ent is not None and ent[0] == w._version and ent[1].device == w.device and ent[2] is w:
-        return ent[1]
+        return _cross_stream(ent)
     out = torch.empty(w.shape, dtype=dtype, device=w.device)
     src = w.detach()
     if not src.is_contiguous():
         src = src.contiguous()
     check(lib.egv_cast(L.EGV_F32, _dt(out), _p(src), _p(out), src.numel(), _st()), 'egv_cast')
-    _wcache[key] = (w._version, out, w)
+    _wcache[key] = (w._version, out, w, _st(), _cast_event())
     return out
 
 
@@ -88,14 +102,14 @@ def compute_weight_t(w: torch.Tensor, dtype: torch.dtype):
     key = id(w)
     ent = _wtcache.get(key)
     if ent is not None and ent[0] == w._version and ent[1].device == w.device and ent[2] is w:
-        return ent[1]
+        return _cross_stream(ent)
     N, K = w.shape
     out = torch.empty(K, N, dtype=dtype, device=w.device)
     src = w.detach()
     if not src.is_contiguous():
         src = src.contiguous()
     check(lib.egv_cast_transpose(_p(src), _p(out), N, K, _st()), 'egv_cast_transpose')
-    _wtcache[key] = (w._version, out, w)
+    _wtcache[key] = (w._version, out, w, _st(), _cast_event())
     return out
 
 

@@ -140,6 +140,29 @@ class FrozenInTime(nn.Module):
     def set_device(self, device):
         self.device = device
 
+    def _fork_text(self, fn):
+        """Run the (latency-bound, 6-workgroup) text-encoder prefix on a second HIP stream so that it overlaps the video
+        blocks; autograd replays each backward node on the stream of its forward, so the overlap holds for backward too.
+        Returns a join() that orders the calling stream after the side stream."""
+        import os
+        if os.environ.get('EGV_NO_OVERLAP') or not torch.cuda.is_available():
+            out = fn()
+            return out, (lambda: None)
+        main = torch.cuda.current_stream()
+        if getattr(self, '_side', None) is None or self._side.device != main.device:
+            self._side = torch.cuda.Stream(device=main.device)
+        side = self._side
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            out = fn()
+
+        def join():
+            main.wait_stream(side)
+            for t in (out if isinstance(out, (tuple, list)) else (out,)):
+                if torch.is_tensor(t):
+                    t.record_stream(main)
+        return out, join
+
     def p(self, name: str) -> torch.Tensor:
         if self._P is None:
             self._P = dict(self.named_parameters())
@@ -265,14 +288,19 @@ class FrozenInTime(nn.Module):
         output the reference computes and discards, is skipped."""
         c = self.cfg
         B, L = input_ids.shape
-        v = self._patch_tokens(video, 'cls_token')
-        t = self._text_embeddings(input_ids)
         mask = self._key_mask(attention_mask)
         n_plain = c.depth - c.n_fuse
+
+        def text_prefix():
+            t = self._text_embeddings(input_ids)
+            for i in range(n_plain):
+                t = self._text_layer(t, mask, i, B, L)
+            return t
+        t, join = self._fork_text(text_prefix)
+        v = self._patch_tokens(video, 'cls_token')
         for i in range(n_plain):
             v = self._video_block(v, i, B)
-        for i in range(n_plain):
-            t = self._text_layer(t, mask, i, B, L)
+        join()
         for i in range(n_plain, c.depth):
             last = i == c.depth - 1
             v_new = None if (last and not need_video_out) else self._video_block(v, i, B, y=t, y_mask=mask, L=L)
@@ -288,8 +316,9 @@ class FrozenInTime(nn.Module):
             self.task_names = task_names
         c = self.cfg
         if 'EgoNCE' in self.task_names:
-            text_embeddings = self.compute_text(text_data)
+            text_embeddings, join = self._fork_text(lambda: self.compute_text(text_data))
             video_embeddings = self.compute_video(video_data)
+            join()
             if return_embeds:
                 ret.update({'text_embeds': text_embeddings, 'video_embeds': video_embeddings})
         if 'ITM' in self.task_names:
