@@ -425,57 +425,101 @@ __device__ __forceinline__ long long other_row_v(const AttnArgs& a, const RowSet
     return rs_row(rs, b, g, j);
 }
 
+// 8 lanes share one other-side row (16 B = 8 head dims per lane -> 128-byte coalesced row reads); a wave walks 8 rows at a
+// time, a workgroup (4 waves) 32 rows.  Dot products are reduced over the 8-lane group with 3 xor-shuffles; every lane
+// accumulates its own 8 output dims; the 8 groups of a wave are merged with 3 more shuffle steps at the end.
 template <typename T>
-__global__ __launch_bounds__(64) void attn1_fwd_kernel(const AttnArgs a) {
-    const int lane = threadIdx.x;
+__device__ __forceinline__ void ld8(const T* p, float (&o)[8]) {
+    float a[4], b[4];
+    ld4(p, a);
+    ld4(p + 4, b);
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+}
+__device__ __forceinline__ float grp8_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    return v + __shfl_xor(v, 4, 64);
+}
+__device__ __forceinline__ float xgrp_sum(float v) {           // across the 8 row groups of a wave (same sub-lane)
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+__device__ __forceinline__ float xgrp_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 8, 64));
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn1_fwd_kernel(const AttnArgs a) {
+    __shared__ float red[4][66];
+    const int lane = threadIdx.x & 63, w = wave_id(), sub = lane & 7, grp = lane >> 3;
     const int split = blockIdx.x, p = blockIdx.y, b = p / a.G, g = p % a.G, h = blockIdx.z;
     const T* Q = reinterpret_cast<const T*>(a.Q);
     const T* K = reinterpret_cast<const T*>(a.K);
     const T* V = reinterpret_cast<const T*>(a.V);
     const long long qrow = rs_row(a.q, b, g, 0);
-    float q[HD];
-    load_row_f(Q + qrow * a.ldq + a.qoff + h * HD, q);
+    float q[8];
+    ld8(Q + qrow * a.ldq + a.qoff + h * HD + sub * 8, q);
 #pragma unroll
-    for (int d = 0; d < HD; ++d) q[d] *= a.scale;
+    for (int d = 0; d < 8; ++d) q[d] *= a.scale;
     const int ntot = a.k.n + a.extra;
     const int per = (ntot + a.nsplit - 1) / a.nsplit;
     const int j0 = split * per, j1 = min(ntot, j0 + per);
-    float m = -INFINITY, l = 0.f, o[HD];
+    float m = -INFINITY, l = 0.f, o[8];
 #pragma unroll
-    for (int d = 0; d < HD; ++d) o[d] = 0.f;
-    for (int j = j0 + lane; j < j1; j += 64) {
+    for (int d = 0; d < 8; ++d) o[d] = 0.f;
+    for (int j = j0 + w * 8 + grp; j < j1; j += 32) {
         const long long row = other_row_v(a, a.k, b, g, j);
-        float kr[HD];
-        load_row_f(K + row * a.ldk + a.koff + h * HD, kr);
+        float kr[8], vr[8];
+        ld8(K + row * a.ldk + a.koff + h * HD + sub * 8, kr);
+        ld8(V + row * a.ldv + a.voff + h * HD + sub * 8, vr);
         float s = 0.f;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) s = fmaf(q[d], kr[d], s);
+        for (int d = 0; d < 8; ++d) s = fmaf(q[d], kr[d], s);
+        s = grp8_sum(s);
         if (a.mask && !(a.extra && j == 0)) s += a.mask[(long long)b * a.mask_ld + (j - a.extra)];
         const float mn = fmaxf(m, s);
         const float c = __expf(m - mn), pj = __expf(s - mn);
-        load_row_f(V + row * a.ldv + a.voff + h * HD, kr);
         l = l * c + pj;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) o[d] = fmaf(o[d], c, pj * kr[d]);
+        for (int d = 0; d < 8; ++d) o[d] = fmaf(o[d], c, pj * vr[d]);
         m = mn;
     }
-    const float M = wave_max(m);
+    // merge the 8 groups of the wave, then the 4 waves through LDS
+    const float M = xgrp_max(m);
     const float c = (m == -INFINITY) ? 0.f : __expf(m - M);
-    const float L = wave_sum(l * c);
-    const long long nrows = (long long)gridDim.y * a.q.n;
-    const long long orow = (long long)p * a.q.n;
-    float* dst = a.ws + (((long long)split * nrows + orow) * a.H + h) * 66;
+    const float Lw = xgrp_sum(l * c);
 #pragma unroll
-    for (int d = 0; d < HD; ++d) {
-        const float t = wave_sum(o[d] * c);
-        if (lane == d) dst[2 + d] = t;
+    for (int d = 0; d < 8; ++d) o[d] = xgrp_sum(o[d] * c);
+    if (grp == 0) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) red[w][2 + sub * 8 + d] = o[d];
+        if (sub == 0) { red[w][0] = M; red[w][1] = Lw; }
     }
-    if (lane == 0) { dst[0] = M; dst[1] = L; }
+    __syncthreads();
+    if (w == 0) {
+        const float MM = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
+        float L = 0.f, od = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            const float cw = (red[ww][0] == -INFINITY) ? 0.f : __expf(red[ww][0] - MM);
+            L += red[ww][1] * cw;
+            od += red[ww][2 + lane] * cw;
+        }
+        const long long nrows = (long long)gridDim.y * a.q.n;
+        const long long orow = (long long)p * a.q.n;
+        float* dst = a.ws + (((long long)split * nrows + orow) * a.H + h) * 66;
+        dst[2 + lane] = od;
+        if (lane == 0) { dst[0] = MM; dst[1] = L; }
+    }
 }
 
 template <typename T>
-__global__ __launch_bounds__(64) void attn1_dq_kernel(const AttnArgs a) {
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(256) void attn1_dq_kernel(const AttnArgs a) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = wave_id(), sub = lane & 7, grp = lane >> 3;
     const int split = blockIdx.x, p = blockIdx.y, b = p / a.G, g = p % a.G, h = blockIdx.z;
     const T* Q = reinterpret_cast<const T*>(a.Q);
     const T* K = reinterpret_cast<const T*>(a.K);
@@ -483,86 +527,99 @@ __global__ __launch_bounds__(64) void attn1_dq_kernel(const AttnArgs a) {
     const T* O = reinterpret_cast<const T*>(a.O);
     const T* dO = reinterpret_cast<const T*>(a.dO);
     const long long qrow = rs_row(a.q, b, g, 0);
-    float q[HD], go[HD];
-    load_row_f(Q + qrow * a.ldq + a.qoff + h * HD, q);
-    load_row_f(dO + qrow * a.ldo + a.ooff + h * HD, go);
+    float q[8], go[8], ov[8];
+    ld8(Q + qrow * a.ldq + a.qoff + h * HD + sub * 8, q);
+    ld8(dO + qrow * a.ldo + a.ooff + h * HD + sub * 8, go);
+    ld8(O + qrow * a.ldo + a.ooff + h * HD + sub * 8, ov);
     float dl = 0.f;
-    {
-        float ov[HD];
-        load_row_f(O + qrow * a.ldo + a.ooff + h * HD, ov);
 #pragma unroll
-        for (int d = 0; d < HD; ++d) { dl = fmaf(go[d], ov[d], dl); q[d] *= a.scale; }
-    }
+    for (int d = 0; d < 8; ++d) { dl = fmaf(go[d], ov[d], dl); q[d] *= a.scale; }
+    dl = grp8_sum(dl);
     const float lse = a.lse[qrow * a.H + h];
-    if (split == 0 && lane == 0) a.delta[qrow * a.H + h] = dl;
+    if (split == 0 && threadIdx.x == 0) a.delta[qrow * a.H + h] = dl;
     const int ntot = a.k.n + a.extra;
     const int per = (ntot + a.nsplit - 1) / a.nsplit;
     const int j0 = split * per, j1 = min(ntot, j0 + per);
-    float acc[HD];
+    float acc[8];
 #pragma unroll
-    for (int d = 0; d < HD; ++d) acc[d] = 0.f;
-    for (int j = j0 + lane; j < j1; j += 64) {
+    for (int d = 0; d < 8; ++d) acc[d] = 0.f;
+    for (int j = j0 + w * 8 + grp; j < j1; j += 32) {
         const long long row = other_row_v(a, a.k, b, g, j);
-        float kr[HD], vr[HD];
-        load_row_f(K + row * a.ldk + a.koff + h * HD, kr);
-        load_row_f(V + row * a.ldv + a.voff + h * HD, vr);
+        float kr[8], vr[8];
+        ld8(K + row * a.ldk + a.koff + h * HD + sub * 8, kr);
+        ld8(V + row * a.ldv + a.voff + h * HD + sub * 8, vr);
         float s = 0.f, dp = 0.f;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) { s = fmaf(q[d], kr[d], s); dp = fmaf(go[d], vr[d], dp); }
+        for (int d = 0; d < 8; ++d) { s = fmaf(q[d], kr[d], s); dp = fmaf(go[d], vr[d], dp); }
+        s = grp8_sum(s);
+        dp = grp8_sum(dp);
         if (a.mask && !(a.extra && j == 0)) s += a.mask[(long long)b * a.mask_ld + (j - a.extra)];
         const float ds = __expf(s - lse) * (dp - dl);
 #pragma unroll
-        for (int d = 0; d < HD; ++d) acc[d] = fmaf(ds, kr[d], acc[d]);
+        for (int d = 0; d < 8; ++d) acc[d] = fmaf(ds, kr[d], acc[d]);
     }
-    const long long nrows = (long long)gridDim.y * a.q.n;
-    const long long orow = (long long)p * a.q.n;
-    float* dst = a.ws + (((long long)split * nrows + orow) * a.H + h) * HD;
 #pragma unroll
-    for (int d = 0; d < HD; ++d) {
-        const float t = wave_sum(acc[d]);
-        if (lane == d) dst[d] = t * a.scale;
+    for (int d = 0; d < 8; ++d) acc[d] = xgrp_sum(acc[d]);
+    if (grp == 0) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) red[w][sub * 8 + d] = acc[d];
+    }
+    __syncthreads();
+    if (w == 0) {
+        const long long nrows = (long long)gridDim.y * a.q.n;
+        const long long orow = (long long)p * a.q.n;
+        a.ws[(((long long)split * nrows + orow) * a.H + h) * HD + lane] = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) * a.scale;
     }
 }
 
 template <typename T>
-__global__ __launch_bounds__(64) void attn1_dkv_kernel(const AttnArgs a) {
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(256) void attn1_dkv_kernel(const AttnArgs a) {
+    __shared__ float red[4][128];
+    const int lane = threadIdx.x & 63, w = wave_id(), sub = lane & 7, grp = lane >> 3;
     const int split = blockIdx.x, p = blockIdx.y, b = p / a.G, g = p % a.G, h = blockIdx.z;
     const T* Q = reinterpret_cast<const T*>(a.Q);
     const T* K = reinterpret_cast<const T*>(a.K);
     const T* V = reinterpret_cast<const T*>(a.V);
     const T* dO = reinterpret_cast<const T*>(a.dO);
     const long long krow = rs_row(a.k, b, g, 0);
-    float kc[HD], vc[HD];
-    load_row_f(K + krow * a.ldk + a.koff + h * HD, kc);
-    load_row_f(V + krow * a.ldv + a.voff + h * HD, vc);
+    float kc[8], vc[8];
+    ld8(K + krow * a.ldk + a.koff + h * HD + sub * 8, kc);
+    ld8(V + krow * a.ldv + a.voff + h * HD + sub * 8, vc);
     const float mk = a.mask ? a.mask[(long long)b * a.mask_ld] : 0.f;
     const int ntot = a.q.n + a.extra;
     const int per = (ntot + a.nsplit - 1) / a.nsplit;
     const int i0 = split * per, i1 = min(ntot, i0 + per);
-    float dk[HD], dv[HD];
+    float dk[8], dv[8];
 #pragma unroll
-    for (int d = 0; d < HD; ++d) dk[d] = dv[d] = 0.f;
-    for (int i = i0 + lane; i < i1; i += 64) {
+    for (int d = 0; d < 8; ++d) dk[d] = dv[d] = 0.f;
+    for (int i = i0 + w * 8 + grp; i < i1; i += 32) {
         const long long row = other_row_v(a, a.q, b, g, i);
-        float qr[HD], gr[HD];
-        load_row_f(Q + row * a.ldq + a.qoff + h * HD, qr);
-        load_row_f(dO + row * a.ldo + a.ooff + h * HD, gr);
+        float qr[8], gr[8];
+        ld8(Q + row * a.ldq + a.qoff + h * HD + sub * 8, qr);
+        ld8(dO + row * a.ldo + a.ooff + h * HD + sub * 8, gr);
         float s = 0.f, dp = 0.f;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) { s = fmaf(qr[d], kc[d], s); dp = fmaf(gr[d], vc[d], dp); }
+        for (int d = 0; d < 8; ++d) { s = fmaf(qr[d], kc[d], s); dp = fmaf(gr[d], vc[d], dp); }
+        s = grp8_sum(s);
+        dp = grp8_sum(dp);
         const float pj = __expf(s * a.scale + mk - a.lse[row * a.H + h]);
         const float ds = pj * (dp - a.delta[row * a.H + h]) * a.scale;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) { dv[d] = fmaf(pj, gr[d], dv[d]); dk[d] = fmaf(ds, qr[d], dk[d]); }
+        for (int d = 0; d < 8; ++d) { dv[d] = fmaf(pj, gr[d], dv[d]); dk[d] = fmaf(ds, qr[d], dk[d]); }
     }
-    const long long nrows = (long long)gridDim.y * a.k.n;
-    const long long orow = (long long)p * a.k.n;
-    float* dst = a.ws + (((long long)split * nrows + orow) * a.H + h) * 2 * HD;
 #pragma unroll
-    for (int d = 0; d < HD; ++d) {
-        const float t = wave_sum(dk[d]), u = wave_sum(dv[d]);
-        if (lane == d) { dst[d] = t; dst[HD + d] = u; }
+    for (int d = 0; d < 8; ++d) { dk[d] = xgrp_sum(dk[d]); dv[d] = xgrp_sum(dv[d]); }
+    if (grp == 0) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) { red[w][sub * 8 + d] = dk[d]; red[w][64 + sub * 8 + d] = dv[d]; }
+    }
+    __syncthreads();
+    if (w < 2) {
+        const long long nrows = (long long)gridDim.y * a.k.n;
+        const long long orow = (long long)p * a.k.n;
+        float* dst = a.ws + (((long long)split * nrows + orow) * a.H + h) * 2 * HD;
+        const int c = w * 64 + lane;
+        dst[c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
     }
 }
 
@@ -618,8 +675,8 @@ extern "C" int egv_attn_fwd(int dtype, const egv_attn_desc* d, void* stream) {
                   "egv_attn_fwd: workspace too small");
     if (d->q_n == 1 && a.nsplit > 1) {
         dim3 grid1(a.nsplit, d->B * d->G, d->H);
-        if (dtype == EGV_BF16) hipLaunchKernelGGL(attn1_fwd_kernel<bf16_t>, grid1, dim3(64), 0, st, a);
-        else hipLaunchKernelGGL(attn1_fwd_kernel<float>, grid1, dim3(64), 0, st, a);
+        if (dtype == EGV_BF16) hipLaunchKernelGGL(attn1_fwd_kernel<bf16_t>, grid1, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(attn1_fwd_kernel<float>, grid1, dim3(256), 0, st, a);
     } else {
         const int nw = pick_nw(d->q_n);
         dim3 grid(((d->q_n + nw * QPW - 1) / (nw * QPW)) * a.nsplit, d->B * d->G, d->H);
@@ -651,8 +708,8 @@ extern "C" int egv_attn_bwd_dq(int dtype, const egv_attn_desc* d, void* stream) 
                   "egv_attn_bwd_dq: workspace too small");
     if (d->q_n == 1 && a.nsplit > 1) {
         dim3 grid1(a.nsplit, d->B * d->G, d->H);
-        if (dtype == EGV_BF16) hipLaunchKernelGGL(attn1_dq_kernel<bf16_t>, grid1, dim3(64), 0, st, a);
-        else hipLaunchKernelGGL(attn1_dq_kernel<float>, grid1, dim3(64), 0, st, a);
+        if (dtype == EGV_BF16) hipLaunchKernelGGL(attn1_dq_kernel<bf16_t>, grid1, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(attn1_dq_kernel<float>, grid1, dim3(256), 0, st, a);
     } else {
         const int nw = pick_nw(d->q_n);
         dim3 grid(((d->q_n + nw * QPW - 1) / (nw * QPW)) * a.nsplit, d->B * d->G, d->H);
@@ -689,8 +746,8 @@ extern "C" int egv_attn_bwd_dkv(int dtype, const egv_attn_desc* d, void* stream)
                   "egv_attn_bwd_dkv: workspace too small");
     if (d->k_n == 1 && a.nsplit > 1) {
         dim3 grid1(a.nsplit, d->B * d->G, d->H);
-        if (dtype == EGV_BF16) hipLaunchKernelGGL(attn1_dkv_kernel<bf16_t>, grid1, dim3(64), 0, st, a);
-        else hipLaunchKernelGGL(attn1_dkv_kernel<float>, grid1, dim3(64), 0, st, a);
+        if (dtype == EGV_BF16) hipLaunchKernelGGL(attn1_dkv_kernel<bf16_t>, grid1, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(attn1_dkv_kernel<float>, grid1, dim3(256), 0, st, a);
     } else if (dtype == EGV_BF16 && a.nsplit > 1 && egv_attn_dkv_mfma(a, d->B, st)) {
         // long query side, short key side (image->text cross attention): MFMA kernel per query chunk, fp32 partials
     } else {

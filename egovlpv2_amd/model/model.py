@@ -371,6 +371,23 @@ class FrozenInTime(nn.Module):
             ret.update({'sim_v2t': output, 'sim_t2v': output.t()})
             loss_dict.update({'EgoNCE': loss})
 
+        itm_pre = None
+        if 'ITM' in task_names:                                                                  # :426-447
+            # The sampling weights only depend on the EgoNCE branch: compute them and start the device->host copy now, so
+            # that the copy (and the host-side draw below) overlaps the MLM pass instead of draining the GPU queue.
+            rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else getattr(args, 'rank', 0)
+            bsz = data['video'].size(0)
+            with torch.no_grad():
+                sl = slice(bsz * rank, bsz * (rank + 1))
+                w_v2t = F.softmax(ret['sim_v2t'][sl] / temp, dim=1).masked_fill(mask_bool[sl], 0)
+                w_t2v = F.softmax(ret['sim_t2v'][sl] / temp, dim=1).masked_fill(mask_bool[sl], 0)
+                w_dev = torch.stack([w_v2t, w_t2v]).float()
+                w_host = torch.empty(w_dev.shape, dtype=torch.float32, pin_memory=True)
+                w_host.copy_(w_dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            itm_pre = (rank, bsz, w_host, ev)
+
         if 'MLM' in task_names:                                                                  # :404-422
             ret = self.infer(data, task_names='MLM', ret=ret)
             logits = ret.pop('_mlm_logits_padded')
@@ -385,21 +402,17 @@ class FrozenInTime(nn.Module):
             loss_dict.update({'loss_mlm': loss_mlm})
 
         if 'ITM' in task_names:                                                                  # :426-483
-            rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else getattr(args, 'rank', 0)
+            rank, bsz, w_host, ev = itm_pre
             all_video = gather(data['video'])
             all_text_ids = gather(data['text']['input_ids'])
             all_text_masks = gather(data['text']['attention_mask'])
-            bsz = data['video'].size(0)
             pos_len = bsz // 2
             itm_labels = torch.cat([torch.ones(pos_len), torch.zeros(bsz - pos_len)])
             itm_labels = itm_labels[torch.randperm(itm_labels.size(0))]
-            with torch.no_grad():
-                sl = slice(bsz * rank, bsz * (rank + 1))
-                w_v2t = F.softmax(ret['sim_v2t'][sl] / temp, dim=1).masked_fill(mask_bool[sl], 0)
-                w_t2v = F.softmax(ret['sim_t2v'][sl] / temp, dim=1).masked_fill(mask_bool[sl], 0)
-                # ONE device->host copy; negatives are drawn on the host with the reference's RNG consumption order
-                # (np.random.rand then torch.multinomial per negative, model.py:459-468) instead of one sync per sample.
-                w_cpu = torch.stack([w_v2t, w_t2v]).float().cpu()
+            # ONE device->host copy (started above); negatives are drawn on the host with the reference's RNG consumption
+            # order (np.random.rand then torch.multinomial per negative, model.py:459-468) instead of one sync per sample.
+            ev.synchronize()
+            w_cpu = w_host
             vid_idx = torch.arange(bsz) + rank * bsz
             txt_idx = vid_idx.clone()
             neg_log = []
