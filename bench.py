@@ -196,8 +196,15 @@ def main():
         dom = max(agg, key=lambda k: agg[k][1])
         fl, ms, n = agg[dom]
         ach = fl / (ms * 1e-3) / 1e12
+        traffic = None
+        try:                                    # PMC numbers are collected in separate rocprofv3 passes (profiles/round1_pmc_gemm.md)
+            pm = json.load(open(os.path.join(REPO, 'profiles', 'pmc_traffic.json')))
+            if dom == 8:
+                traffic = pm['gemm_ring_kernel']
+        except Exception:
+            traffic = None
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                 "kernel": kinds.get(dom, str(dom)), "launches": n, "avg_launch_ms": round(ms / n, 4),
                 "all_gemm": {kinds.get(k, str(k)): {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1), "ms_per_step": round(v[1] / a.steps, 2),
                                                     "launches_per_step": v[2] // a.steps} for k, v in agg.items()},
