@@ -592,8 +592,9 @@ int egv_gemm2_launch(const GemmArgs& g, int a_trans, int b_trans, int out_f32, i
         (void)useA;
         static const int force = getenv("EGV_GEMM_CFG") ? atoi(getenv("EGV_GEMM_CFG")) : 0;     // experiments only
         const long long tb = (long long)((g.M + 255) / 256) * ((g.N + 127) / 128);
+        if (force == 1 && tb <= 128) return 0;                  // experiment: generic 128x128 kernel for small grids
         if (force == 3) launch_ring<CfgC, 3>(g, st);
-        else if (tb <= 128) launch_ring<CfgB, 6>(g, st);     // latency-bound small grids (text tokens): 5 K-tiles in flight
+        else if (tb <= 128) launch_ring<CfgC, 6>(g, st);     // latency-bound small grids (text tokens): 128x128 tiles, 5 K-tiles in flight
         else launch_ring<CfgB, 3>(g, st);      // 256x128 tile x 3 stages = 72 KB: 2 workgroups per CU (epilogue of one overlaps the K loop of the other)
     } else {
         if (useA) launch2<CfgA, 1, 1, float>(g, nz, st); else launch2<CfgB, 1, 1, float>(g, nz, st);

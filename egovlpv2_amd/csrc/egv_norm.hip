@@ -281,7 +281,7 @@ extern "C" int egv_layernorm_fwd(int dtype, const void* x, void* y, const float*
 
 static inline int ln_bwd_blocks(int M) {
     int nb = (M + 3) / 4;
-    return nb > 1024 ? 1024 : nb;
+    return nb > 512 ? 512 : nb;          // 2 workgroups per CU; the partial-sum reduction reads nb rows
 }
 
 extern "C" long long egv_layernorm_bwd_workspace_bytes(int M, int D) { return (long long)ln_bwd_blocks(M) * 2 * D * 4; }
