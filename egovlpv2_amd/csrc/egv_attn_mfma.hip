@@ -80,6 +80,21 @@ __device__ __forceinline__ bf16x8_t ld_frag_t(const unsigned char* s, int d, int
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// A-operand fragment (row = tile row fr, 8 consecutive head dims of k-step ks) gathered from a TRANSPOSED tile sT[d][row]
+// with the gfx950 transposing LDS read: lane fr supplies the address of (d0 + fr/4, row0 + (fr%4)*4 ..+3) and receives
+// column row0 + fr of the 4 x 16 block (layout verified on hardware by tools/probe_tr.hip).
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+template <int NT>
+__device__ __forceinline__ bf16x8_t ld_frag_tr(const unsigned char* sT, int row0, int ks, int fr, int fg) {
+    constexpr int VP = vt_pitch(NT);
+    const unsigned char* p = sT + (ks * 32 + fg * 8 + (fr >> 2)) * VP + (row0 + (fr & 3) * 4) * 2;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + 4 * VP));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
 __device__ __forceinline__ bf16x8_t ld_frag_global(const bf16_t* p, bool valid) {
     u32x4_t v = {0u, 0u, 0u, 0u};
     if (valid) v = *reinterpret_cast<const u32x4_t*>(p);
@@ -199,9 +214,8 @@ template <int NT, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a, int tiles_per_wg) {
     constexpr int VP = vt_pitch(NT);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* sK = smem;                       // [NT*16][RP]
-    unsigned char* sV = sK + NT * 16 * RP;          // [NT*16][RP]
-    unsigned char* sKt = sV + NT * 16 * RP;         // [64][VP]
+    unsigned char* sKt = smem;                      // [64][VP]  K transposed (A operand of S^T via transposing reads, and of dQ^T)
+    unsigned char* sVt = sKt + 64 * VP;             // [64][VP]  V transposed (A operand of dP^T via transposing reads)
 
     const int tid = threadIdx.x, lane = tid & 63, w = wave_id();
     const int fr = lane & 15, fg = lane >> 4;
@@ -215,9 +229,8 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a,
     const int hq = a.qoff + h * HD, hk = a.koff + h * HD, hv = a.voff + h * HD, ho = a.ooff + h * HD, hdq = a.dqoff + h * HD;
     const int ntot = a.k.n + a.extra;
 
-    stage_rows<NT, 64 * NW>(sK, K, a.ldk, hk, a, a.k, b, g, ntot, tid);
-    stage_rows<NT, 64 * NW>(sV, V, a.ldv, hv, a, a.k, b, g, ntot, tid);
     stage_rows_t<NT, 64 * NW>(sKt, K, a.ldk, hk, a, a.k, b, g, ntot, tid);
+    stage_rows_t<NT, 64 * NW>(sVt, V, a.ldv, hv, a, a.k, b, g, ntot, tid);
     __syncthreads();
 
     const int nqt = (a.q.n + 15) >> 4;
@@ -248,10 +261,10 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a,
             for (int u = 0; u < 2; ++u) {
                 const int t = 2 * kk + u;
                 f32x4_t acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sK, t * 16 + fr, 0, fg), q0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sK, t * 16 + fr, 1, fg), q1, acc, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sV, t * 16 + fr, 0, fg), g0, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sV, t * 16 + fr, 1, fg), g1, dp, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sKt, t * 16, 0, fr, fg), q0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sKt, t * 16, 1, fr, fg), q1, acc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sVt, t * 16, 0, fr, fg), g0, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sVt, t * 16, 1, fr, fg), g1, dp, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = t * 16 + fg * 4 + r;
@@ -291,10 +304,8 @@ template <int NT, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_dkv_mfma_kernel(const AttnArgs a, int tiles_per_wg) {
     constexpr int VP = vt_pitch(NT);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* sQ = smem;                        // [NT*16][RP]
-    unsigned char* sG = sQ + NT * 16 * RP;           // dO rows
-    unsigned char* sQt = sG + NT * 16 * RP;          // [64][VP]
-    unsigned char* sGt = sQt + 64 * VP;              // [64][VP]
+    unsigned char* sQt = smem;                       // [64][VP]  Q transposed
+    unsigned char* sGt = sQt + 64 * VP;              // [64][VP]  dO transposed
     float* sL = reinterpret_cast<float*>(sGt + 64 * VP);   // [NT*16] lse
     float* sD = sL + NT * 16;                        // [NT*16] delta
 
@@ -316,8 +327,6 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_mfma_kernel(const AttnArgs a
     const int r0 = split * per;
     const int ntot = max(0, min(per, nall - r0));
 
-    stage_rows<NT, 64 * NW>(sQ, Q, a.ldq, hq, a, a.q, b, g, ntot, tid, r0);
-    stage_rows<NT, 64 * NW>(sG, dO, a.ldo, ho, a, a.q, b, g, ntot, tid, r0);
     stage_rows_t<NT, 64 * NW>(sQt, Q, a.ldq, hq, a, a.q, b, g, ntot, tid, r0);
     stage_rows_t<NT, 64 * NW>(sGt, dO, a.ldo, ho, a, a.q, b, g, ntot, tid, r0);
     for (int i = tid; i < NT * 16; i += 64 * NW) {
@@ -353,10 +362,10 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_mfma_kernel(const AttnArgs a
             for (int u = 0; u < 2; ++u) {
                 const int t = 2 * kk + u;
                 f32x4_t acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sQ, t * 16 + fr, 0, fg), k0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sQ, t * 16 + fr, 1, fg), k1, acc, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sG, t * 16 + fr, 0, fg), v0, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sG, t * 16 + fr, 1, fg), v1, dp, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sQt, t * 16, 0, fr, fg), k0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sQt, t * 16, 1, fr, fg), k1, acc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sGt, t * 16, 0, fr, fg), v0, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sGt, t * 16, 1, fr, fg), v1, dp, 0, 0, 0);
                 const f32x4_t lse = *reinterpret_cast<const f32x4_t*>(sL + t * 16 + fg * 4);
                 const f32x4_t dl = *reinterpret_cast<const f32x4_t*>(sD + t * 16 + fg * 4);
 #pragma unroll
@@ -406,8 +415,8 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_mfma_kernel(const AttnArgs a
 }
 
 template <int NT> constexpr size_t fwd_lds() { return (size_t)NT * 16 * RP + 64 * vt_pitch(NT); }
-template <int NT> constexpr size_t dq_lds() { return (size_t)2 * NT * 16 * RP + 64 * vt_pitch(NT); }
-template <int NT> constexpr size_t dkv_lds() { return (size_t)2 * NT * 16 * RP + 2 * 64 * vt_pitch(NT) + 2 * NT * 16 * 4; }
+template <int NT> constexpr size_t dq_lds() { return (size_t)2 * 64 * vt_pitch(NT); }
+template <int NT> constexpr size_t dkv_lds() { return (size_t)2 * 64 * vt_pitch(NT) + 2 * NT * 16 * 4; }
 
 template <typename KFn>
 static void set_lds(KFn k, size_t bytes) {
