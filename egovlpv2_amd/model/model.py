@@ -140,12 +140,23 @@ class FrozenInTime(nn.Module):
     def set_device(self, device):
         self.device = device
 
+    def _pinned(self, key, shape, dtype):
+        cache = self.__dict__.setdefault('_pin_cache', {})
+        t = cache.get(key)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
+            cache[key] = t
+        return t
+
     def _fork_text(self, fn):
         """Run the (latency-bound, 6-workgroup) text-encoder prefix on a second HIP stream so that it overlaps the video
         blocks; autograd replays each backward node on the stream of its forward, so the overlap holds for backward too.
         Returns a join() that orders the calling stream after the side stream."""
         import os
-        if os.environ.get('EGV_NO_OVERLAP') or not torch.cuda.is_available():
+        # Not under multi-rank DDP: the reducer orders a bucket's all-reduce only after the stream of the LAST gradient that
+        # lands in it, so gradients produced on two streams inside one bucket would race.
+        multi_rank = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if os.environ.get('EGV_NO_OVERLAP') or multi_rank or not torch.cuda.is_available():
             out = fn()
             return out, (lambda: None)
         main = torch.cuda.current_stream()
@@ -382,7 +393,7 @@ class FrozenInTime(nn.Module):
                 w_v2t = F.softmax(ret['sim_v2t'][sl] / temp, dim=1).masked_fill(mask_bool[sl], 0)
                 w_t2v = F.softmax(ret['sim_t2v'][sl] / temp, dim=1).masked_fill(mask_bool[sl], 0)
                 w_dev = torch.stack([w_v2t, w_t2v]).float()
-                w_host = torch.empty(w_dev.shape, dtype=torch.float32, pin_memory=True)
+                w_host = self._pinned('itm_w', w_dev.shape, torch.float32)     # cached: pinned allocation stalls the device
                 w_host.copy_(w_dev, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
@@ -428,14 +439,19 @@ class FrozenInTime(nn.Module):
                     txt_idx[idx] = j
                     neg_log.append((idx, 'text', j))
             dev = data['video'].device
-            vid_idx, txt_idx = vid_idx.to(dev), txt_idx.to(dev)
+            # one pinned staging buffer + one async copy for the three small host tensors (pageable .to() copies block)
+            stage = self._pinned('itm_idx', (3, bsz), torch.int64)
+            stage[0].copy_(vid_idx)
+            stage[1].copy_(txt_idx)
+            stage[2].copy_(itm_labels.long())
+            idx_dev = stage.to(dev, non_blocking=True)
+            vid_idx, txt_idx, labels_dev = idx_dev[0], idx_dev[1], idx_dev[2]
             data_itm = {'video': all_video.index_select(0, vid_idx),
                         'text': {'input_ids': all_text_ids.index_select(0, txt_idx),
                                  'attention_mask': all_text_masks.index_select(0, txt_idx)}}
             ret = self.infer(data_itm, task_names='ITM', ret=ret)
             itm_logits = ret['cross_attn_itm_logits']
-            labels_dev = itm_labels.to(dev)
-            ce_sum = ops.cross_entropy_sum(ops.CastFn.apply(itm_logits, torch.float32).contiguous(), labels_dev.long(), 2, -100)
+            ce_sum = ops.cross_entropy_sum(ops.CastFn.apply(itm_logits, torch.float32).contiguous(), labels_dev.contiguous(), 2, -100)
             tot = gather(torch.stack([ce_sum, torch.full_like(ce_sum, float(bsz))]).reshape(1, 2))
             loss_itm = tot[:, 0].sum() / tot[:, 1].sum()
             loss = loss + 2 * loss_itm
