@@ -677,6 +677,8 @@ extern "C" int egv_attn_fwd(int dtype, const egv_attn_desc* d, void* stream) {
         dim3 grid1(a.nsplit, d->B * d->G, d->H);
         if (dtype == EGV_BF16) hipLaunchKernelGGL(attn1_fwd_kernel<bf16_t>, grid1, dim3(256), 0, st, a);
         else hipLaunchKernelGGL(attn1_fwd_kernel<float>, grid1, dim3(256), 0, st, a);
+    } else if (dtype == EGV_BF16 && a.nsplit > 1 && egv_attn_fwd_mfma(a, d->B, st)) {
+        // short query side against a long key side (text -> image): MFMA kernel per key chunk, partial softmax states
     } else {
         const int nw = pick_nw(d->q_n);
         dim3 grid(((d->q_n + nw * QPW - 1) / (nw * QPW)) * a.nsplit, d->B * d->G, d->H);
@@ -710,6 +712,7 @@ extern "C" int egv_attn_bwd_dq(int dtype, const egv_attn_desc* d, void* stream) 
         dim3 grid1(a.nsplit, d->B * d->G, d->H);
         if (dtype == EGV_BF16) hipLaunchKernelGGL(attn1_dq_kernel<bf16_t>, grid1, dim3(256), 0, st, a);
         else hipLaunchKernelGGL(attn1_dq_kernel<float>, grid1, dim3(256), 0, st, a);
+    } else if (dtype == EGV_BF16 && a.nsplit > 1 && egv_attn_dq_mfma(a, d->B, st)) {
     } else {
         const int nw = pick_nw(d->q_n);
         dim3 grid(((d->q_n + nw * QPW - 1) / (nw * QPW)) * a.nsplit, d->B * d->G, d->H);

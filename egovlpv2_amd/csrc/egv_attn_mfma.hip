@@ -141,14 +141,20 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnArgs a
     const bf16_t* V = reinterpret_cast<const bf16_t*>(a.V);
     bf16_t* O = reinterpret_cast<bf16_t*>(a.O);
     const int hq = a.qoff + h * HD, hk = a.koff + h * HD, hv = a.voff + h * HD, ho = a.ooff + h * HD;
-    const int ntot = a.k.n + a.extra;
+    // keys incl. the extra CLS key; with nsplit > 1 this workgroup covers the chunk [r0, r0 + ntot) of them and writes
+    // partial softmax states (combined by attn_fwd_combine_kernel)
+    const int nall = a.k.n + a.extra;
+    const int split = blockIdx.x % a.nsplit;
+    const int per = a.nsplit > 1 ? ((((nall + a.nsplit - 1) / a.nsplit) + 15) & ~15) : nall;
+    const int r0 = split * per;
+    const int ntot = max(0, min(per, nall - r0));
 
-    stage_rows<NT, 64 * NW>(sK, K, a.ldk, hk, a, a.k, b, g, ntot, tid);
-    stage_rows_t<NT, 64 * NW>(sVt, V, a.ldv, hv, a, a.k, b, g, ntot, tid);
+    stage_rows<NT, 64 * NW>(sK, K, a.ldk, hk, a, a.k, b, g, ntot, tid, r0);
+    stage_rows_t<NT, 64 * NW>(sVt, V, a.ldv, hv, a, a.k, b, g, ntot, tid, r0);
     __syncthreads();
 
     const int nqt = (a.q.n + 15) >> 4;
-    const int t0 = blockIdx.x * tiles_per_wg;
+    const int t0 = (blockIdx.x / a.nsplit) * tiles_per_wg;
     const int t1 = min(nqt, t0 + tiles_per_wg);
     for (int qt = t0 + w; qt < t1; qt += NW) {
         const int q = qt * 16 + fr;
@@ -165,9 +171,9 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnArgs a
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sK, t * 16 + fr, 1, fg), q1, acc, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int key = t * 16 + fg * 4 + r;
+                const int key = t * 16 + fg * 4 + r;              // index inside this chunk; r0 + key is the global key index
                 float v = acc[r] * a.scale;
-                if (a.mask && key >= a.extra && key < ntot) v += a.mask[(long long)b * a.mask_ld + key - a.extra];
+                if (a.mask && r0 + key >= a.extra && key < ntot) v += a.mask[(long long)b * a.mask_ld + r0 + key - a.extra];
                 v = key < ntot ? v : -INFINITY;
                 acc[r] = v;
                 m = fmaxf(m, v);
@@ -197,7 +203,14 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnArgs a
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_t<NT>(sVt, dt * 16 + fr, kk, fg), pf, o[dt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (qv) {
+        if (qv && a.nsplit > 1) {
+            const long long nrows = (long long)gridDim.y * a.q.n;
+            const long long orow = (long long)p * a.q.n + q;
+            float* dst = a.ws + (((long long)split * nrows + orow) * a.H + h) * 66;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4_t*>(dst + 2 + dt * 16 + fg * 4) = o[dt];
+            if (fg == 0) { dst[0] = m; dst[1] = l; }
+        } else if (qv) {
             const float inv = 1.0f / l;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
@@ -227,14 +240,18 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a,
     const bf16_t* dO = reinterpret_cast<const bf16_t*>(a.dO);
     bf16_t* dQ = reinterpret_cast<bf16_t*>(a.dQ);
     const int hq = a.qoff + h * HD, hk = a.koff + h * HD, hv = a.voff + h * HD, ho = a.ooff + h * HD, hdq = a.dqoff + h * HD;
-    const int ntot = a.k.n + a.extra;
+    const int nall = a.k.n + a.extra;
+    const int split = blockIdx.x % a.nsplit;
+    const int per = a.nsplit > 1 ? ((((nall + a.nsplit - 1) / a.nsplit) + 15) & ~15) : nall;
+    const int r0 = split * per;
+    const int ntot = max(0, min(per, nall - r0));
 
-    stage_rows_t<NT, 64 * NW>(sKt, K, a.ldk, hk, a, a.k, b, g, ntot, tid);
-    stage_rows_t<NT, 64 * NW>(sVt, V, a.ldv, hv, a, a.k, b, g, ntot, tid);
+    stage_rows_t<NT, 64 * NW>(sKt, K, a.ldk, hk, a, a.k, b, g, ntot, tid, r0);
+    stage_rows_t<NT, 64 * NW>(sVt, V, a.ldv, hv, a, a.k, b, g, ntot, tid, r0);
     __syncthreads();
 
     const int nqt = (a.q.n + 15) >> 4;
-    const int t0 = blockIdx.x * tiles_per_wg;
+    const int t0 = (blockIdx.x / a.nsplit) * tiles_per_wg;
     const int t1 = min(nqt, t0 + tiles_per_wg);
     for (int qt = t0 + w; qt < t1; qt += NW) {
         const int q = qt * 16 + fr;
@@ -251,7 +268,7 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a,
         for (int e = 0; e < 8; ++e) dl += (float)g0[e] * (float)o0[e] + (float)g1[e] * (float)o1[e];
         dl = grp_sum(dl);
         const float lse = qv ? a.lse[qrow * a.H + h] : 0.f;
-        if (qv && fg == 0) a.delta[qrow * a.H + h] = dl;
+        if (qv && fg == 0 && split == 0) a.delta[qrow * a.H + h] = dl;
 
         bf16x8_t dsf[NT / 2];
 #pragma unroll
@@ -269,7 +286,7 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a,
                 for (int r = 0; r < 4; ++r) {
                     const int key = t * 16 + fg * 4 + r;
                     float v = acc[r] * a.scale;
-                    if (a.mask && key >= a.extra && key < ntot) v += a.mask[(long long)b * a.mask_ld + key - a.extra];
+                    if (a.mask && r0 + key >= a.extra && key < ntot) v += a.mask[(long long)b * a.mask_ld + r0 + key - a.extra];
                     const float pj = key < ntot ? __expf(v - lse) : 0.f;
                     acc[r] = pj * (dp[r] - dl);
                 }
@@ -288,7 +305,13 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a,
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_t<NT>(sKt, dt * 16 + fr, kk, fg), dsf[kk], o[dt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (qv) {
+        if (qv && a.nsplit > 1) {
+            const long long nrows = (long long)gridDim.y * a.q.n;
+            const long long orow = (long long)p * a.q.n + q;
+            float* dst = a.ws + (((long long)split * nrows + orow) * a.H + h) * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4_t*>(dst + dt * 16 + fg * 4) = o[dt] * a.scale;
+        } else if (qv) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
                 st_bf16x4(dQ + qrow * a.lddq + hdq + dt * 16 + fg * 4, o[dt][0] * a.scale, o[dt][1] * a.scale, o[dt][2] * a.scale,
@@ -449,10 +472,13 @@ static inline void own_split(int n_own, int& nw, int& tpw, int& chunks) {
     } while (0)
 
 int egv_attn_fwd_mfma(const AttnArgs& a, int B, hipStream_t st) {
-    const int ntot = a.k.n + a.extra;
+    const int nall = a.k.n + a.extra;
+    const int ntot = a.nsplit > 1 ? ((((nall + a.nsplit - 1) / a.nsplit) + 15) & ~15) : nall;
     if (!aligned_ok(a) || ntot > 224) return 0;
+    if (a.nsplit > 1 && (a.q.n > 64 || !a.ws)) return 0;          // split form: short query side only (text -> image)
     int nw, tpw, chunks;
     own_split(a.q.n, nw, tpw, chunks);
+    chunks *= a.nsplit;
     if (ntot <= 32) EGV_MFMA_LAUNCH(attn_fwd_mfma_kernel, fwd_lds, 2);
     else if (ntot <= 64) EGV_MFMA_LAUNCH(attn_fwd_mfma_kernel, fwd_lds, 4);
     else EGV_MFMA_LAUNCH(attn_fwd_mfma_kernel, fwd_lds, 14);
@@ -460,10 +486,13 @@ int egv_attn_fwd_mfma(const AttnArgs& a, int B, hipStream_t st) {
 }
 
 int egv_attn_dq_mfma(const AttnArgs& a, int B, hipStream_t st) {
-    const int ntot = a.k.n + a.extra;
+    const int nall = a.k.n + a.extra;
+    const int ntot = a.nsplit > 1 ? ((((nall + a.nsplit - 1) / a.nsplit) + 15) & ~15) : nall;
     if (!aligned_ok(a) || (a.lddq % 4) || (a.dqoff % 4) || ntot > 224) return 0;
+    if (a.nsplit > 1 && (a.q.n > 64 || !a.ws)) return 0;
     int nw, tpw, chunks;
     own_split(a.q.n, nw, tpw, chunks);
+    chunks *= a.nsplit;
     if (ntot <= 32) EGV_MFMA_LAUNCH(attn_dq_mfma_kernel, dq_lds, 2);
     else if (ntot <= 64) EGV_MFMA_LAUNCH(attn_dq_mfma_kernel, dq_lds, 4);
     else EGV_MFMA_LAUNCH(attn_dq_mfma_kernel, dq_lds, 14);

@@ -496,7 +496,7 @@ class PlainAttnFn(Function):
             assert t.dim() == 2 and t.stride(1) == 1 and t.shape[1] == D
         O = torch.empty(B * nq, D, dtype=q.dtype, device=q.device)
         lse = torch.empty(B * nq, H, dtype=torch.float32, device=q.device)
-        ns = _nsplit_for(nk)
+        ns = 1 if nk <= 224 else (nk + 223) // 224             # MFMA kernel per 224-key chunk + combine
         ws, nb = _split_ws(0, B, 1, H, nq, ns, q.device)
         d = _mk_desc(q, k, v, O, lse, B, 1, H, _rowset(nq, 0, 0, 1, nq), _rowset(nk, 0, 0, 1, nk), None, scale, mask=mask,
                      nsplit=ns, ws=ws, ws_bytes=nb)
@@ -517,7 +517,7 @@ class PlainAttnFn(Function):
         delta = torch.empty(B * nq, H, dtype=torch.float32, device=q.device)
         qs, ks = _rowset(nq, 0, 0, 1, nq), _rowset(nk, 0, 0, 1, nk)
         kw = dict(mask=mask, dO=dO, dQ=dq, dK=dk, dV=dv, delta=delta)
-        ns = _nsplit_for(nk)
+        ns = 1 if nk <= 224 else (nk + 223) // 224
         ws, nb = _split_ws(1, B, 1, H, nq, ns, q.device)
         d = _mk_desc(q, k, v, O, lse, B, 1, H, qs, ks, None, scale, nsplit=ns, ws=ws, ws_bytes=nb, **kw)
         check(lib.egv_attn_bwd_dq(_dt(q), C.byref(d), _st()), 'egv_attn_bwd_dq')
