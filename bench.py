@@ -94,6 +94,7 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='full', choices=['full', 'dual'])
+    ap.add_argument('--optimizer', action='store_true', help='also time the fused AdamW step + LR schedule (SURVEY.md §8f item 1)')
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--frames', type=int, default=16)
     ap.add_argument('--text-len', type=int, default=32)
@@ -147,12 +148,21 @@ def main():
     np.random.seed(1 + rank)
     torch.manual_seed(1 + rank)
 
+    optimizer = scheduler = None
+    if a.optimizer:
+        from egovlpv2_amd.set_optim_schedule import set_schedule
+        ocfg = {"optimizer": {"type": "AdamW", "args": {"lr": 3e-5, "weight_decay": 0.01, "lr_mult_head": 4, "lr_mult_cross_modal": 4}}}
+        optimizer, scheduler = set_schedule(model, ocfg, {"decay_power": "cosine", "end_lr": 1e-7}, 100000, 10000)
+
     def step():
         ops.invalidate_weight_cache()            # weights are re-cast from the fp32 masters every step, as in training
         for p in model.parameters():
             p.grad = None
         loss, ld, _ = net(data, noun, verb, AllGather_multi.apply, world, args, conf, loss_fn, local, task_names=tasks)
         loss.backward()
+        if optimizer is not None:
+            optimizer.step()
+            scheduler.step()
         return ld
 
     def sync():
@@ -220,7 +230,7 @@ def main():
                "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": ("configs[2] full fusion EgoNCE+MLM+ITM" if a.workload == 'full' else "configs[1] dual encoder EgoNCE")
                           + f", ViT-B/16 TimeSformer + RoBERTa-base, B={a.batch}/GPU, {a.frames}x224^2, {a.text_len} tok",
-                          "global_batch": world * a.batch, "parallelism": f"dp{world}", "timed": "zero_grad + fwd + bwd (+DDP all-reduce), weight cast included"},
+                          "global_batch": world * a.batch, "parallelism": f"dp{world}", "timed": "zero_grad + fwd + bwd (+DDP all-reduce), weight cast included" + (" + fused AdamW step" if a.optimizer else "")},
                "model_tflops": round(value * fpp / 1e12, 1), "mfma_frac_of_peak": round(value * fpp / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
                "losses": losses, "roofline": roof}
         if not a.no_cpu_baseline and world == 1:

@@ -70,6 +70,7 @@ PROTOTYPES = {
     'egv_l2norm_bwd': (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),
     'egv_egonce_fwd': (i32, [vp, vp, vp, i32, f32, i32, i32, vp, vp, vp, vp]),
     'egv_egonce_bwd': (i32, [vp, vp, vp, vp, vp, vp, i32, f32, i32, i32, vp]),
+    'egv_adamw_step': (i32, [vp, vp, i32, i32, f32, f32, f32, f32, f32, f32, f32, vp]),
     'egv_prof_enable': (i32, [i32]),
     'egv_prof_reset': (i32, []),
     'egv_prof_collect': (i32, [C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int), i32]),

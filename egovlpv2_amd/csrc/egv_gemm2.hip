@@ -269,6 +269,9 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    long long* stamps = reinterpret_cast<long long*>(g.colsum);          // debug only (egv_debug_timing)
+    const bool stamp = stamps != nullptr && tid == 0;
+    if (stamp) stamps[blockIdx.x * 8 + 0] = clock64();
     const int nt = g.K / 32;
     auto issue = [&](int kt, int slot) {
         unsigned char* sA = smem + slot * STG;
@@ -281,12 +284,14 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmArgs g) {
 
     const int frag_off = fr * 64 + ((fg ^ (((fr >> 2) & 1) * 3)) * 16);
     int slot = 0, islot = NS - 1;
+    if (stamp) stamps[blockIdx.x * 8 + 1] = clock64();
     for (int kt = 0; kt < nt; ++kt) {
         const int rem = nt - 1 - kt;
         if (rem >= NS - 2) wait_vmcnt<P*(NS - 2)>();
         else if (NS > 3 && rem == 1) wait_vmcnt<P>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
+        if (stamp && kt == 0) stamps[blockIdx.x * 8 + 2] = clock64();
         if (kt + NS - 1 < nt) issue(kt + NS - 1, islot);
         const unsigned char* sA = smem + slot * STG + frag_off;
         const unsigned char* sB = sA + BM * 64;
@@ -312,7 +317,9 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmArgs g) {
     // C accesses are 16-byte vectors forming 128-byte row segments (8 lanes per row) instead of 8-byte scattered ones.
     static_assert(NI == 4, "wave tile must be 64 columns wide");
     constexpr int EP = 68;                                     // floats per LDS slab row (64 + 4 pad)
+    if (stamp) stamps[blockIdx.x * 8 + 3] = clock64();
     __syncthreads();                                           // every wave is done with the operand stages
+    if (stamp) stamps[blockIdx.x * 8 + 4] = clock64();
     float* slab = reinterpret_cast<float*>(smem) + wave * 16 * EP;
     bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
     const GemmEpi& e = g.e;
@@ -384,10 +391,15 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmArgs g) {
             }
         }
     }
+    if (stamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamps[blockIdx.x * 8 + 5] = clock64(); }
 }
+
+static float* g_timing_buf = nullptr;
+extern "C" int egv_debug_timing(void* buf) { g_timing_buf = (float*)buf; return 0; }
 
 template <typename CFG, int NS>
 static void launch_ring(GemmArgs g, hipStream_t st) {
+    g.colsum = g_timing_buf;
     g.tiles_m = (g.M + CFG::BM - 1) / CFG::BM;
     g.tiles_n = (g.N + CFG::BN - 1) / CFG::BN;
     const size_t lds = (size_t)NS * (CFG::BM + CFG::BN) * 64;

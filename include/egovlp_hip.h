@@ -145,6 +145,13 @@ int egv_egonce_fwd(const float* x, const float* sim_v, const float* sim_n, int n
 int egv_egonce_bwd(const float* x, const float* sim_v, const float* sim_n, const float* stats, const float* gout, float* dx,
                    int n, float temperature, int noun, int verb, void* stream);
 
+/* ---- fused multi-tensor AdamW (set_optim_schedule.py:108 -> transformers 4.30 AdamW: eps on sqrt(v) without bias
+ * correction of the denominator, step_size = lr*sqrt(1-b2^t)/(1-b1^t), weight decay p -= lr*wd*p AFTER the update).
+ * table: device array of 32-byte records {float* p; const float* g; float* m; float* v; int n; int pad}, one per tensor;
+ * prefix: device int32[ntensors+1] = running count of 16384-element chunks (one workgroup per chunk). ---- */
+int egv_adamw_step(const void* table, const int* prefix, int ntensors, int nchunks, float lr, float step_size, float beta1,
+                   float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+
 /* ---- instrumentation: HIP-event timing of the GEMM launches on their own stream (bench.py roofline) ---- */
 int egv_prof_enable(int on);
 int egv_prof_reset(void);

@@ -213,3 +213,23 @@ def test_batch_independence_full_size_bf16():
     assert torch.equal(full['video_embeds'][5], single['video_embeds'][0])
     assert torch.equal(full['text_embeds'][5], single['text_embeds'][0])
     assert torch.isfinite(full['video_embeds'].float()).all()
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-3), (torch.bfloat16, 3e-2)])
+def test_long_clip_inference_vs_oracle(dtype, tol):
+    """BASELINE.json configs[3] geometry in the small: 32 frames (33-key time attention), 77 text tokens, inference-only
+    `infer('EgoNCE')` and the `Feature_Extraction` short-circuit of forward() (model.py:375-377) against the oracle."""
+    from oracle import ref_model as O
+    from egovlpv2_amd.config import PathConfig
+    cfg = PathConfig(depth=2, n_fuse=1, frames=32, img=112)
+    B, L = 2, 77
+    sd, data, noun, verb, oc = oracle_setup(cfg, B, L, 9, 31)
+    m = _build(cfg, sd, dtype).eval()
+    with torch.no_grad():
+        r = m.infer(_to_cuda(data), task_names='EgoNCE')
+        feat = m(_to_cuda(data), None, None, None, None, None, None, None, None, task_names='Feature_Extraction')
+        ot = O.compute_text(sd, data['text'], oc)
+        ov = O.compute_video(sd, data['video'], oc)
+    assert rel_err(r['text_embeds'].float(), ot) < tol
+    assert rel_err(r['video_embeds'].float(), ov) < tol
+    assert torch.equal(feat, r['video_embeds'])

@@ -1,0 +1,75 @@
+"""Optimiser row: parameter grouping pinned against the reference's own set_optim_schedule.py
+(tests/golden/optim_groups.json, produced by oracle/gen_golden_optim.py), fused HIP AdamW + schedule against the oracle's
+restatement of transformers-4.30 AdamW."""
+import json
+import os
+
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_grouping_matches_reference():
+    from egovlpv2_amd.set_optim_schedule import group_parameters
+    from egovlpv2_amd.synthetic import param_shapes
+    from egovlpv2_amd.config import PathConfig
+    gold = json.load(open(os.path.join(REPO, 'tests', 'golden', 'optim_groups.json')))
+    named = [(n, torch.nn.Parameter(torch.zeros(1))) for n in param_shapes(PathConfig(frames=4)) if not n.endswith('position_ids')]
+    groups = group_parameters(named, 3e-5, 0.01, 4, 4)
+    assert len(groups) == 6
+    for g, r in zip(groups, gold['groups']):
+        assert g['names'] == r['names']
+        assert g['weight_decay'] == r['weight_decay'] and abs(g['lr'] - r['lr']) < 1e-12
+    assert gold['kw'] == {'lr': 3e-5, 'eps': 1e-8, 'betas': [0.9, 0.98]}
+    # the quirks the reference's substring rules produce
+    decayed = set(groups[0]['names']) | set(groups[4]['names'])
+    assert 'video_model.blocks.0.norm3.weight' in decayed and 'video_model.blocks.0.norm1.weight' not in decayed
+    assert 'video_model.blocks.11.attn.norm_i2t_i.weight' in set(groups[4]['names'])
+
+
+def test_schedule_lambdas():
+    from egovlpv2_amd.set_optim_schedule import cosine_lambda
+    from oracle.ref_optim import cosine_with_warmup
+    f = cosine_lambda(10, 100)
+    for s in (0, 1, 9, 10, 11, 55, 99, 100):
+        assert abs(f(s) - cosine_with_warmup(s, 10, 100)) < 1e-12
+    assert f(0) == 0.0 and abs(f(10) - 1.0) < 1e-12 and f(100) < 1e-12
+
+
+@pytest.mark.gpu
+def test_fused_adamw_matches_oracle():
+    from egovlpv2_amd.set_optim_schedule import set_schedule
+    from oracle.ref_optim import adamw_step, cosine_with_warmup
+    torch.manual_seed(0)
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = torch.nn.Linear(300, 77)                    # decay + no-decay (bias), lr
+            self.norm3 = torch.nn.LayerNorm(77)                         # norm3.weight decays (reference quirk), bias does not
+            self.txt_proj = torch.nn.Linear(77, 20011)                  # head group (lr x 4); > 16384 elements -> several chunks
+            self.cross_modal_x = torch.nn.Linear(33, 5)                 # cross-modal group
+    m = M().cuda()
+    cfg = {"optimizer": {"type": "AdamW", "args": {"lr": 3e-3, "weight_decay": 0.01, "lr_mult_head": 4, "lr_mult_cross_modal": 4}}}
+    opt, sched = set_schedule(m, cfg, {"decay_power": "cosine", "end_lr": 1e-7}, 20, 3)
+    ref = {n: p.detach().double().cpu().clone() for n, p in m.named_parameters()}
+    st = {n: (torch.zeros_like(v), torch.zeros_like(v)) for n, v in ref.items()}
+    groups_of = {}
+    from egovlpv2_amd.set_optim_schedule import group_parameters
+    for g in group_parameters(m.named_parameters(), 3e-3, 0.01, 4, 4):
+        for n in g['names']:
+            groups_of[n] = (g['lr'], g['weight_decay'])
+    for step in range(1, 6):
+        gen = torch.Generator().manual_seed(step)
+        for n, p in m.named_parameters():
+            g = torch.randn(p.shape, generator=gen)
+            p.grad = g.cuda()
+            lam = cosine_with_warmup(step - 1, 3, 20)                   # LambdaLR: lr used at step t is lambda(t-1 steps taken)
+            base_lr, wd = groups_of[n]
+            adamw_step(ref[n], g.double(), st[n][0], st[n][1], step, base_lr * lam, (0.9, 0.98), 1e-8, wd)
+        opt.step()
+        sched.step()
+    for n, p in m.named_parameters():
+        err = (p.detach().double().cpu() - ref[n]).abs().max().item()
+        assert err < 2e-6, (n, err)
