@@ -99,6 +99,7 @@ def main():
     ap.add_argument('--frames', type=int, default=16)
     ap.add_argument('--text-len', type=int, default=32)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--drop-rate', type=float, default=0.1, help='RoBERTa dropout in the train step (yml drop_rate)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gemm-events', action='store_true')
     ap.add_argument('--force-ddp', action='store_true', help='wrap in DDP + RCCL even at world size 1 (test aid)')
@@ -125,7 +126,7 @@ def main():
     from egovlpv2_amd.model.loss import EgoNCE
     from egovlpv2_amd.trainer.trainer_egoclip import AllGather_multi
 
-    cfg = PathConfig(frames=a.frames)
+    cfg = PathConfig(frames=a.frames, drop_rate=a.drop_rate)     # EgoClip_pretrain.yml drop_rate (RoBERTa side, train mode)
     tasks = 'EgoNCE' if a.workload == 'dual' else 'EgoNCE_MLM_ITM'
     dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
     model = FrozenInTime({'model': 'SpaceTimeTransformer', 'num_frames': cfg.frames, 'pretrained': True},
@@ -230,7 +231,7 @@ def main():
                "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": ("configs[2] full fusion EgoNCE+MLM+ITM" if a.workload == 'full' else "configs[1] dual encoder EgoNCE")
                           + f", ViT-B/16 TimeSformer + RoBERTa-base, B={a.batch}/GPU, {a.frames}x224^2, {a.text_len} tok",
-                          "global_batch": world * a.batch, "parallelism": f"dp{world}", "timed": "zero_grad + fwd + bwd (+DDP all-reduce), weight cast included" + (" + fused AdamW step" if a.optimizer else "")},
+                          "global_batch": world * a.batch, "parallelism": f"dp{world}", "drop_rate": a.drop_rate, "timed": "zero_grad + fwd + bwd (+DDP all-reduce), weight cast included" + (" + fused AdamW step" if a.optimizer else "")},
                "model_tflops": round(value * fpp / 1e12, 1), "mfma_frac_of_peak": round(value * fpp / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
                "losses": losses, "roofline": roof}
         if not a.no_cpu_baseline and world == 1:

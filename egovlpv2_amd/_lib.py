@@ -34,6 +34,7 @@ class AttnDesc(C.Structure):
         ('scale', f32),
         ('mask', vp), ('mask_ld', i32),
         ('nsplit', i32), ('ws', vp), ('ws_bytes', i64),
+        ('drop_p', f32), ('drop_seed', C.c_uint),
     ]
 
 
@@ -51,6 +52,7 @@ PROTOTYPES = {
     'egv_colsum': (i32, [i32, vp, i32, i32, i32, vp, f32, vp, vp, vp]),
     'egv_dot': (i32, [i32, vp, vp, i64, vp, f32, vp, vp]),
     'egv_act_bwd': (i32, [i32, vp, vp, vp, i64, i32, vp]),
+    'egv_dropout_add': (i32, [i32, vp, vp, vp, vp, i64, f32, C.c_uint, vp]),
     'egv_cast': (i32, [i32, i32, vp, vp, i64, vp]),
     'egv_cast_transpose': (i32, [vp, vp, i32, i32, vp]),
     'egv_attn_split_workspace_bytes': (i64, [i32, i32, i32, i32, i32, i32]),

@@ -29,7 +29,8 @@ class PathConfig:
     eps_text: float = 1e-5     # roberta-base layer_norm_eps
     eps_model_norm: float = 1e-6   # model.py:154-155
     eps_mlm: float = 1e-12     # BertPredictionHeadTransform with default RobertaConfig (heads.py:41)
-    drop_rate: float = 0.0     # yml drop_rate is 0.1; the HIP path implements p=0
+    drop_rate: float = 0.0     # RoBERTa hidden/attention dropout in train mode (yml drop_rate = 0.1, model.py:135-136);
+                               # 0 here so that parity cases are deterministic -- FrozenInTime(config=yml) passes the yml value
 
     @property
     def n_patches(self) -> int:

@@ -26,8 +26,23 @@ struct AttnArgs {
     float scale;
     const float* mask; int mask_ld;             // additive mask over key index: mask[b*mask_ld + i]
     int G;
-    int nsplit; float* ws;                      // dkv only: split of the query loop + fp32 partial slabs
+    int nsplit; float* ws;                      // split of the other-side loop + fp32 partial slabs
+    float drop_p; unsigned int drop_seed;       // attention-probability dropout (roberta.py:313); 0 = off
 };
+
+// counter-based dropout mask: a pure function of (seed, global query row, global key row, head), so forward, dQ and dK/dV
+// kernels (MFMA or VALU, any tiling) regenerate the same mask.  Returns the multiplier 0 or 1/(1-p).
+__device__ __forceinline__ unsigned int fmix32(unsigned int h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ float drop_mult(const AttnArgs& a, long long qrow, long long krow, int h) {
+    if (a.drop_p <= 0.f) return 1.0f;
+    unsigned int x = a.drop_seed ^ fmix32((unsigned int)qrow * 0x9E3779B1u + (unsigned int)h);
+    x = fmix32(x ^ ((unsigned int)krow * 0x85EBCA77u + 0x165667B1u));
+    const float u = (float)(x >> 8) * (1.0f / 16777216.0f);
+    return u >= a.drop_p ? 1.0f / (1.0f - a.drop_p) : 0.0f;
+}
 
 __device__ __forceinline__ long long rs_row(const RowSet& r, int b, int g, int i) {
     return (long long)b * r.bs + r.base + (long long)g * r.gs + (long long)i * r.is;
@@ -48,6 +63,7 @@ struct egv_attn_desc {
     float scale;
     const float* mask; int mask_ld;
     int nsplit; float* ws; long long ws_bytes;
+    float drop_p; unsigned int drop_seed;
 };
 
 static inline egv::AttnArgs to_args(const egv_attn_desc* d) {
@@ -61,6 +77,7 @@ static inline egv::AttnArgs to_args(const egv_attn_desc* d) {
     a.extra = d->extra; a.extra_bs = d->extra_bs; a.extra_row = d->extra_row;
     a.scale = d->scale; a.mask = d->mask; a.mask_ld = d->mask_ld; a.G = d->G;
     a.nsplit = d->nsplit > 0 ? d->nsplit : 1; a.ws = d->ws;
+    a.drop_p = d->drop_p; a.drop_seed = d->drop_seed;
     return a;
 }
 

@@ -113,9 +113,10 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
                 const float pj = valid ? __expf(s - m_new) : 0.f;
                 const float corr = __expf(m_old - m_new);
                 const float l_new = l_old * corr + wave_sum(pj);
+                const float pd = a.drop_p > 0.f ? pj * drop_mult(a, (long long)p * a.q.n + q0 + i, j - a.extra, h) : pj;
                 float o = sO[(w * QPW + i) * HD + lane] * corr;
 #pragma unroll
-                for (int kk = 0; kk < TK; ++kk) o = fmaf(readlane_f(pj, kk), vcol[kk], o);
+                for (int kk = 0; kk < TK; ++kk) o = fmaf(readlane_f(pd, kk), vcol[kk], o);
                 sO[(w * QPW + i) * HD + lane] = o;
                 if (lane == 0) {
                     sM[(w * QPW + i) * 2] = m_new;
@@ -229,7 +230,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const AttnArgs a) 
                 const float lse = sS[(w * QPW + i) * 2], dl = sS[(w * QPW + i) * 2 + 1];
                 const float s = dot_bcast(qv, krow) + mk;
                 const float pj = valid ? __expf(s - lse) : 0.f;
-                const float dp = dot_bcast(dov, vrow);
+                float dp = dot_bcast(dov, vrow);
+                if (a.drop_p > 0.f) dp *= drop_mult(a, (long long)p * a.q.n + q0 + i, j - a.extra, h);
                 const float ds = pj * (dp - dl);
                 float acc = sDQ[(w * QPW + i) * HD + lane];
 #pragma unroll
@@ -334,8 +336,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const AttnArgs a)
                 dp = fmaf(readlane_f(dov, v * 4 + e), vx[e], dp);
             }
         }
-        const float pj = valid ? __expf(s - lse) : 0.f;
-        const float ds = pj * (dp - dl);
+        const float pj0 = valid ? __expf(s - lse) : 0.f;
+        const float mu = a.drop_p > 0.f ? drop_mult(a, (long long)p * a.q.n + i - a.extra, k0 + lane, h) : 1.0f;
+        const float pj = pj0 * mu;
+        const float ds = pj0 * (dp * mu - dl);
 #pragma unroll
         for (int d = 0; d < HD; ++d) {
             dv[d] = fmaf(pj, readlane_f(dov, d), dv[d]);
@@ -632,6 +636,8 @@ using namespace egv;
 
 static int check_desc(const egv_attn_desc* d, const char* who) {
     EGV_CHECK(d->B > 0 && d->G > 0 && d->H > 0 && d->q_n > 0 && d->k_n > 0, "%s: bad problem shape", who);
+    EGV_CHECK(!(d->drop_p > 0.f) || (d->extra == 0 && d->drop_p < 1.f && d->q_n > 1 && d->k_n > 1),
+              "%s: attention dropout is implemented for plain row sets (no extra CLS row, no single-row problems)", who);
     EGV_CHECK((d->ldq % 4 == 0) && (d->ldk % 4 == 0) && (d->ldv % 4 == 0) && (d->qoff % 4 == 0) && (d->koff % 4 == 0) &&
                   (d->voff % 4 == 0), "%s: leading dims / head offsets must be multiples of 4 elements", who);
     return 0;

@@ -192,6 +192,13 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnArgs a
                 l += e;
             }
         l = grp_sum(l);
+        if (a.drop_p > 0.f) {                         // dropout on the normalised probabilities: l keeps the full sum
+            const long long qid = (long long)p * a.q.n + q;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[t][r] *= drop_mult(a, qid, r0 + t * 16 + fg * 4 + r, h);
+        }
         f32x4_t o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -288,7 +295,8 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a,
                     float v = acc[r] * a.scale;
                     if (a.mask && r0 + key >= a.extra && key < ntot) v += a.mask[(long long)b * a.mask_ld + r0 + key - a.extra];
                     const float pj = key < ntot ? __expf(v - lse) : 0.f;
-                    acc[r] = pj * (dp[r] - dl);
+                    const float mu = a.drop_p > 0.f ? drop_mult(a, (long long)p * a.q.n + q, r0 + key, h) : 1.0f;
+                    acc[r] = pj * (dp[r] * mu - dl);
                 }
                 pr[u] = acc;
             }
@@ -394,8 +402,9 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_mfma_kernel(const AttnArgs a
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float pj = kv ? __expf(acc[r] * a.scale + mk - lse[r]) : 0.f;
-                    acc[r] = pj;
-                    dp[r] = pj * (dp[r] - dl[r]);
+                    const float mu = a.drop_p > 0.f ? drop_mult(a, (long long)p * a.q.n + r0 + t * 16 + fg * 4 + r, key, h) : 1.0f;
+                    acc[r] = pj * mu;
+                    dp[r] = pj * (dp[r] * mu - dl[r]);
                 }
                 pr[u] = acc;
                 dr[u] = dp;

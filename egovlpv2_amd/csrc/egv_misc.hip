@@ -343,6 +343,31 @@ __global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ a
     }
 }
 
+__device__ __forceinline__ unsigned int fmix32_e(unsigned int h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+// y[i] = keep(i)/(1-p) * x[i] + r1[i] + r2[i]   (hidden-state dropout + the residual adds that follow it)
+template <typename T>
+__global__ void dropout_add_kernel(const T* __restrict__ x, const T* __restrict__ r1, const T* __restrict__ r2, T* __restrict__ y,
+                                   long long n, float p, unsigned int seed) {
+    const float inv = 1.0f / (1.0f - p);
+    const long long nv = n / 4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+        float v[4], a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
+        ld4(x + i * 4, v);
+        if (r1) ld4(r1 + i * 4, a);
+        if (r2) ld4(r2 + i * 4, b);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned int h = fmix32_e(seed ^ fmix32_e((unsigned int)(i * 4 + e) * 0x9E3779B1u + 0x7F4A7C15u));
+            const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+            o[e] = (u >= p ? v[e] * inv : 0.f) + a[e] + b[e];
+        }
+        st4(y + i * 4, o);
+    }
+}
+
 }  // namespace egv
 using namespace egv;
 
@@ -474,6 +499,20 @@ extern "C" int egv_act_bwd(int dtype, const void* dy, const void* aux, void* out
         hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3((int)nb), dim3(256), 0, EGV_ST, (const bf16_t*)dy, (const bf16_t*)aux, (bf16_t*)out, n, kind);
     else
         hipLaunchKernelGGL(act_bwd_kernel<float>, dim3((int)nb), dim3(256), 0, EGV_ST, (const float*)dy, (const float*)aux, (float*)out, n, kind);
+    EGV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int egv_dropout_add(int dtype, const void* x, const void* r1, const void* r2, void* y, long long n, float p, unsigned int seed,
+                               void* stream) {
+    EGV_CHECK(n % 4 == 0 && p >= 0.f && p < 1.f, "egv_dropout_add: n %% 4 == 0 and 0 <= p < 1 required");
+    long long nb = (n / 4 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    if (dtype == EGV_BF16)
+        hipLaunchKernelGGL(dropout_add_kernel<bf16_t>, dim3((int)nb), dim3(256), 0, EGV_ST, (const bf16_t*)x, (const bf16_t*)r1, (const bf16_t*)r2, (bf16_t*)y, n, p, seed);
+    else
+        hipLaunchKernelGGL(dropout_add_kernel<float>, dim3((int)nb), dim3(256), 0, EGV_ST, (const float*)x, (const float*)r1, (const float*)r2, (float*)y, n, p, seed);
     EGV_LAUNCH_CHECK();
     return 0;
 }

@@ -371,8 +371,9 @@ def _rowset(bs, base, gs, istride, n):
 
 
 def _mk_desc(Q, K, V, O, lse, B, G, H, qset, kset, extra, scale, mask=None, dO=None, dQ=None, dK=None, dV=None, delta=None,
-             nsplit=1, ws=None, ws_bytes=0):
+             nsplit=1, ws=None, ws_bytes=0, drop_p=0.0, drop_seed=0):
     d = AttnDesc()
+    d.drop_p, d.drop_seed = float(drop_p), int(drop_seed) & 0xFFFFFFFF
     d.Q, d.K, d.V, d.O = _p(Q), _p(K), _p(V), _p(O)
     d.dO, d.dQ, d.dK, d.dV = _p(dO), _p(dQ), _p(dK), _p(dV)
     d.ldq, d.ldk, d.ldv, d.ldo = Q.stride(0), K.stride(0), V.stride(0), O.stride(0)
@@ -489,7 +490,7 @@ class PlainAttnFn(Function):
     (video_transformer.py:159-182).  q [B*nq, D], k/v [B*nk, D] may be column slices (stride(1) == 1)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, B, H, nq, nk, scale, mask, dkv_nsplit):
+    def forward(ctx, q, k, v, B, H, nq, nk, scale, mask, dkv_nsplit, drop_p=0.0, drop_seed=0):
         _need_gpu(q)
         D = H * 64
         for t in (q, k, v):
@@ -499,16 +500,16 @@ class PlainAttnFn(Function):
         ns = 1 if nk <= 224 else (nk + 223) // 224             # MFMA kernel per 224-key chunk + combine
         ws, nb = _split_ws(0, B, 1, H, nq, ns, q.device)
         d = _mk_desc(q, k, v, O, lse, B, 1, H, _rowset(nq, 0, 0, 1, nq), _rowset(nk, 0, 0, 1, nk), None, scale, mask=mask,
-                     nsplit=ns, ws=ws, ws_bytes=nb)
+                     nsplit=ns, ws=ws, ws_bytes=nb, drop_p=drop_p, drop_seed=drop_seed)
         check(lib.egv_attn_fwd(_dt(q), C.byref(d), _st()), 'egv_attn_fwd')
-        ctx.cfg = (B, H, nq, nk, scale, dkv_nsplit)
+        ctx.cfg = (B, H, nq, nk, scale, dkv_nsplit, drop_p, drop_seed)
         ctx.save_for_backward(q, k, v, O, lse, mask)
         return O
 
     @staticmethod
     def backward(ctx, dO):
         q, k, v, O, lse, mask = ctx.saved_tensors
-        B, H, nq, nk, scale, nsplit = ctx.cfg
+        B, H, nq, nk, scale, nsplit, drop_p, drop_seed = ctx.cfg
         D = H * 64
         dO = dO.contiguous()
         dq = torch.empty(B * nq, D, dtype=q.dtype, device=q.device)
@@ -516,7 +517,7 @@ class PlainAttnFn(Function):
         dv = torch.empty(B * nk, D, dtype=q.dtype, device=q.device)
         delta = torch.empty(B * nq, H, dtype=torch.float32, device=q.device)
         qs, ks = _rowset(nq, 0, 0, 1, nq), _rowset(nk, 0, 0, 1, nk)
-        kw = dict(mask=mask, dO=dO, dQ=dq, dK=dk, dV=dv, delta=delta)
+        kw = dict(mask=mask, dO=dO, dQ=dq, dK=dk, dV=dv, delta=delta, drop_p=drop_p, drop_seed=drop_seed)
         ns = 1 if nk <= 224 else (nk + 223) // 224
         ws, nb = _split_ws(1, B, 1, H, nq, ns, q.device)
         d = _mk_desc(q, k, v, O, lse, B, 1, H, qs, ks, None, scale, nsplit=ns, ws=ws, ws_bytes=nb, **kw)
@@ -525,11 +526,44 @@ class PlainAttnFn(Function):
         ws, nb = _dkv_ws(B, 1, H, nk, nsplit, q.device)
         d = _mk_desc(q, k, v, O, lse, B, 1, H, qs, ks, None, scale, nsplit=nsplit, ws=ws, ws_bytes=nb, **kw)
         check(lib.egv_attn_bwd_dkv(_dt(q), C.byref(d), _st()), 'egv_attn_bwd_dkv')
-        return dq, dk, dv, None, None, None, None, None, None, None
+        return dq, dk, dv, None, None, None, None, None, None, None, None, None
 
 
-def plain_attention(q, k, v, B, H, nq, nk, scale, mask=None, dkv_nsplit=1):
-    return PlainAttnFn.apply(q, k, v, B, H, nq, nk, scale, mask, dkv_nsplit)
+def plain_attention(q, k, v, B, H, nq, nk, scale, mask=None, dkv_nsplit=1, drop_p=0.0, drop_seed=0):
+    """drop_p > 0: dropout on the softmax probabilities (roberta.py:313); the keep mask is a pure function of
+    (drop_seed, batch, head, query, key), so the backward kernels regenerate it instead of storing it."""
+    return PlainAttnFn.apply(q, k, v, B, H, nq, nk, scale, mask, dkv_nsplit, drop_p, drop_seed)
+
+
+class DropoutAddFn(Function):
+    """y = dropout(x, p) + r1 + r2 in one pass (RobertaSelfOutput / RobertaOutput: dense -> dropout -> residual add,
+    roberta.py:342, :422, :486-488; embeddings dropout :203 with no residual).  Counter-based mask: element i is kept iff
+    hash(seed, i) >= p, so backward re-derives the mask from the seed."""
+
+    @staticmethod
+    def forward(ctx, x, r1, r2, p, seed):
+        _need_gpu(x)
+        x = x.contiguous()
+        for r in (r1, r2):
+            assert r is None or (r.shape == x.shape and r.dtype == x.dtype and r.is_contiguous())
+        y = torch.empty_like(x)
+        check(lib.egv_dropout_add(_dt(x), _p(x), _p(r1), _p(r2), _p(y), x.numel(), float(p), int(seed) & 0xFFFFFFFF, _st()),
+              'egv_dropout_add')
+        ctx.cfg = (p, seed, r1 is not None, r2 is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, has1, has2 = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        check(lib.egv_dropout_add(_dt(dy), _p(dy), None, None, _p(dx), dy.numel(), float(p), int(seed) & 0xFFFFFFFF, _st()),
+              'egv_dropout_add(bwd)')
+        return dx, (dy if has1 else None), (dy if has2 else None), None, None
+
+
+def dropout_add(x, p, seed, r1=None, r2=None):
+    return DropoutAddFn.apply(x, r1, r2, p, seed)
 
 
 # ---- patch embedding + CLS + positional / temporal embedding ------------------------------------------------

@@ -111,7 +111,8 @@ class FrozenInTime(nn.Module):
             path_config = PathConfig(depth=self.config['num_layers'], n_fuse=self.config['num_fuse_block'],
                                      frames=video_params['num_frames'], dim=embed_dim, heads=self.config['num_heads'],
                                      mlp_ratio=self.config['mlp_ratio'], vocab=self.config['vocab_size'],
-                                     proj_dim=projection_dim, img=video_params.get('img_size', 224))
+                                     proj_dim=projection_dim, img=video_params.get('img_size', 224),
+                                     drop_rate=self.config['drop_rate'])
         self.cfg = path_config
         if self.cfg.head_dim != 64:
             raise NotImplementedError("attention kernels are built for head_dim 64")
@@ -228,11 +229,33 @@ class FrozenInTime(nn.Module):
         return self._lin(x, prefix + '.4')
 
     # ------------------------------------------------------------------ text side
+    def _drop_p(self) -> float:
+        """hidden_dropout_prob = attention_probs_dropout_prob = yml drop_rate (model.py:135-136), train mode only"""
+        return float(self.cfg.drop_rate) if self.training else 0.0
+
+    def _drop_seed(self) -> int:
+        """One 32-bit seed per dropout site and call.  Model-owned counter stream (per rank), so the default CPU / numpy
+        generators -- whose draw order the ITM negative sampling shares with the reference -- are left untouched."""
+        st = self.__dict__.setdefault('_drop_state', None)
+        if st is None:
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+            st = self.__dict__['_drop_state'] = [(0x9E3779B1 * (self.__dict__.get('_drop_base', 0) + 1) + 0x632BE5AB * rank)
+                                                 & 0xFFFFFFFF, 0]
+        st[1] += 1
+        return (st[0] + 0x85EBCA6B * st[1]) & 0xFFFFFFFF
+
+    def seed_dropout(self, seed: int):
+        """restart the dropout mask stream (tests / reproducible runs)"""
+        self.__dict__['_drop_base'] = int(seed)
+        self.__dict__['_drop_state'] = None
+
     def _text_embeddings(self, input_ids):
         e = ops.text_embed(input_ids, self.p('text_model.embeddings.word_embeddings.weight'),
                            self.p('text_model.embeddings.position_embeddings.weight'),
                            self.p('text_model.embeddings.token_type_embeddings.weight'), self.cfg.pad_id, self.compute_dtype)
-        return self._ln(e, 'text_model.embeddings.LayerNorm', self.cfg.eps_text)
+        e = self._ln(e, 'text_model.embeddings.LayerNorm', self.cfg.eps_text)
+        p = self._drop_p()
+        return ops.dropout_add(e, p, self._drop_seed()) if p > 0 else e                  # roberta.py:203
 
     @staticmethod
     def _key_mask(attention_mask):
@@ -245,6 +268,9 @@ class FrozenInTime(nn.Module):
         pfx = f'text_model.encoder.layer.{i}'
         sa = pfx + '.attention.self'
         q, k, v = self._lin(hid, sa + '.query'), self._lin(hid, sa + '.key'), self._lin(hid, sa + '.value')
+        p = self._drop_p()
+        if p > 0:
+            return self._text_layer_dropout(hid, mask, i, B, L, enc, q, k, v, p)
         ctx = ops.plain_attention(q, k, v, B, c.heads, L, L, 1.0 / math.sqrt(c.head_dim), mask=mask)
         if enc is None:
             a = self._lin(ctx, pfx + '.attention.output.dense', res1=hid)           # dense(ctx) + hidden  (:488)
@@ -259,6 +285,31 @@ class FrozenInTime(nn.Module):
         a = self._ln(a, pfx + '.attention.output.LayerNorm', c.eps_text)
         f = ops.mlp(a, self.p(pfx + '.intermediate.dense.weight'), self.p(pfx + '.intermediate.dense.bias'),
                     self.p(pfx + '.output.dense.weight'), self.p(pfx + '.output.dense.bias'), res=a)
+        return self._ln(f, pfx + '.output.LayerNorm', c.eps_text)
+
+    def _text_layer_dropout(self, hid, mask, i, B, L, enc, q, k, v, p):
+        """train-mode RobertaLayer: dropout on the attention probabilities (roberta.py:313) inside the attention kernels and
+        on every dense output before its residual add (:342, :422) as one dropout+add pass; the alpha_t2i gate commutes
+        with the keep mask, so it stays in the GEMM epilogue."""
+        c = self.cfg
+        pfx = f'text_model.encoder.layer.{i}'
+        sc = 1.0 / math.sqrt(c.head_dim)
+        ctx = ops.plain_attention(q, k, v, B, c.heads, L, L, sc, mask=mask, drop_p=p, drop_seed=self._drop_seed())
+        a0 = self._lin(ctx, pfx + '.attention.output.dense')
+        if enc is None:
+            a = ops.dropout_add(a0, p, self._drop_seed(), r1=hid)
+        else:
+            a0 = ops.dropout_add(a0, p, self._drop_seed())
+            ca = pfx + '.crossattention_t2i'
+            cq = self._lin(a0, ca + '.self.query')
+            ck, cv = self._lin(enc, ca + '.self.key'), self._lin(enc, ca + '.self.value')
+            cctx = ops.plain_attention(cq, ck, cv, B, c.heads, L, c.seq, sc, mask=None, drop_p=p, drop_seed=self._drop_seed())
+            y = self._lin(cctx, ca + '.output.dense', gate=self.p(pfx + '.alpha_t2i'))
+            a = ops.dropout_add(y, p, self._drop_seed(), r1=a0, r2=hid)
+        a = self._ln(a, pfx + '.attention.output.LayerNorm', c.eps_text)
+        f = ops.mlp(a, self.p(pfx + '.intermediate.dense.weight'), self.p(pfx + '.intermediate.dense.bias'),
+                    self.p(pfx + '.output.dense.weight'), self.p(pfx + '.output.dense.bias'), res=None)
+        f = ops.dropout_add(f, p, self._drop_seed(), r1=a)
         return self._ln(f, pfx + '.output.LayerNorm', c.eps_text)
 
     # ------------------------------------------------------------------ reference API

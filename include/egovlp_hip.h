@@ -80,6 +80,9 @@ int egv_colsum(int dtype, const void* X, int M, int N, int ld, float* out, float
 int egv_dot(int dtype, const void* a, const void* b, long long n, float* out, float scale, void* workspace, void* stream);
 /* out = dy * act'(aux)  (kind = EGV_ACT_*; aux = forward output for RELU/TANH, pre-activation for GELU) */
 int egv_act_bwd(int dtype, const void* dy, const void* aux, void* out, long long n, int kind, void* stream);
+/* hidden-state dropout fused with the residual adds it feeds (roberta.py:203,342,422): y = keep(i)/(1-p) * x + r1 + r2;
+ * the backward of x is the same call on dy with r1 = r2 = NULL.  mask = counter-based function of (seed, element index). */
+int egv_dropout_add(int dtype, const void* x, const void* r1, const void* r2, void* y, long long n, float p, unsigned int seed, void* stream);
 int egv_cast(int dtype_src, int dtype_dst, const void* src, void* dst, long long n, void* stream);
 /* dst[C][R] (bf16) = src[R][C] (fp32): transposed bf16 compute copy of a weight, so that dgrad runs in the NT form */
 int egv_cast_transpose(const float* src, void* dst, int R, int C, void* stream);
@@ -105,6 +108,8 @@ typedef struct egv_attn_desc {
     float scale;
     const float* mask; int mask_ld;
     int nsplit; float* ws; long long ws_bytes;   /* split of the other-side loop, fp32 partial slabs */
+    float drop_p; unsigned int drop_seed;        /* attention-probability dropout (roberta.py:313): P~ = P * keep/(1-p); the mask is a
+                                                    counter-based function of (seed, query row, key row, head); 0 = off */
 } egv_attn_desc;
 /* nsplit > 1 splits the OTHER side of a launch across workgroups (fp32 partials in ws, combined in a fixed order):
  * needed when one own row meets thousands of other rows (CLS query/key over all S tokens, text<->video cross attention).

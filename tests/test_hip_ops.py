@@ -225,6 +225,91 @@ def test_plain_attention(ops, dtype, nq, nk, masked, nsplit):
     assert _rel(kv.grad, kv64.grad) < _tol(dtype, True)
 
 
+def _attn_keep_mult(ops, dtype, B, H, nq, nk, p, seed):
+    """Recover the kernels' dropout multiplier M[b,h,q,k] (0 or 1/(1-p)): with Q = K = 0 the probabilities are uniform, and
+    with V = identity on a 64-key chunk O[q, d] = M[q, chunk*64 + d] / nk.  The mask is a function of indices only."""
+    D = H * 64
+    z = torch.zeros(B * nq, D, dtype=dtype, device='cuda')
+    zk = torch.zeros(B * nk, D, dtype=dtype, device='cuda')
+    M = torch.zeros(B, H, nq, nk, dtype=torch.float64)
+    for c0 in range(0, nk, 64):
+        n = min(64, nk - c0)
+        v = torch.zeros(B, nk, H, 64)
+        v[:, c0:c0 + n, :, :n] = torch.eye(n).view(1, n, 1, n)
+        o = ops.plain_attention(z, zk, v.reshape(B * nk, D).to(dtype).cuda(), B, H, nq, nk, 1.0, drop_p=p, drop_seed=seed)
+        M[:, :, :, c0:c0 + n] = (o.double().cpu().reshape(B, nq, H, 64).transpose(1, 2) * nk)[..., :n]
+    return M
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('nq,nk,masked,nsplit', [(32, 32, True, 1), (32, 300, False, 1), (300, 32, True, 4)])
+def test_plain_attention_dropout(ops, dtype, nq, nk, masked, nsplit):
+    """roberta.py:313 attention-probability dropout inside the kernels: forward and all three gradients against torch
+    math using the very mask the kernels generate (recovered through the forward itself)."""
+    B, H, p, seed = 2, 2, 0.25, 1234
+    D = H * 64
+    M = _attn_keep_mult(ops, dtype, B, H, nq, nk, p, seed)
+    inv = 1.0 / (1.0 - p)
+    on = (M - inv).abs() < 0.02 * inv
+    assert bool((on | (M.abs() < 1e-6)).all()), "multiplier is 0 or 1/(1-p)"
+    keep = on.double().mean().item()
+    assert abs(keep - (1 - p)) < 0.02, keep
+    M = on.double() * inv
+    assert (M[0] != M[1]).any() and (M[:, 0] != M[:, 1]).any(), "mask must differ per batch row and per head"
+    M2 = _attn_keep_mult(ops, dtype, B, H, nq, nk, p, seed + 1)
+    assert ((M2 > 0) != on).double().mean().item() > 0.2, "mask must depend on the seed"
+
+    q = _rnd((B * nq, D), dtype, 1.0, 1).cuda().requires_grad_(True)
+    kv = _rnd((B * nk, 2 * D), dtype, 1.0, 2).cuda().requires_grad_(True)
+    mask = None
+    if masked:
+        m = torch.ones(B, nk)
+        m[0, nk // 2:] = 0
+        mask = ((1 - m) * torch.finfo(torch.float32).min).cuda()
+    scale = 0.125
+    o = ops.plain_attention(q, kv[:, :D], kv[:, D:], B, H, nq, nk, scale, mask=mask, dkv_nsplit=nsplit, drop_p=p, drop_seed=seed)
+    q64 = q.detach().double().cpu().requires_grad_(True)
+    kv64 = kv.detach().double().cpu().requires_grad_(True)
+    qh = q64.reshape(B, nq, H, 64).transpose(1, 2)
+    kh = kv64[:, :D].reshape(B, nk, H, 64).transpose(1, 2)
+    vh = kv64[:, D:].reshape(B, nk, H, 64).transpose(1, 2)
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    if masked:
+        s = s + mask.double().cpu().view(B, 1, 1, nk)
+    o64 = ((torch.softmax(s, -1) * M) @ vh).transpose(1, 2).reshape(B * nq, D)
+    assert _rel(o, o64) < _tol(dtype)
+    do = _rnd((B * nq, D), dtype, 1.0, 3)
+    o.backward(do.cuda())
+    o64.backward(do.double())
+    assert _rel(q.grad, q64.grad) < _tol(dtype, True)
+    assert _rel(kv.grad, kv64.grad) < _tol(dtype, True)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_dropout_add(ops, dtype):
+    """dense -> dropout -> (+ residuals) of RobertaSelfOutput / RobertaOutput (roberta.py:342, :422, :486-488)."""
+    n, p = (257, 768), 0.1
+    x = _rnd(n, dtype, 1.0, 1).cuda().requires_grad_(True)
+    r1 = _rnd(n, dtype, 1.0, 2).cuda().requires_grad_(True)
+    r2 = _rnd(n, dtype, 1.0, 3).cuda().requires_grad_(True)
+    y = ops.dropout_add(x, p, 77, r1=r1, r2=r2)
+    y0 = ops.dropout_add(x, p, 77)
+    xd = x.detach().double()
+    keep = (y0.detach().double().abs() > 0) | (xd == 0)
+    rate = keep.double().mean().item()
+    assert abs(rate - (1 - p)) < 0.01, rate
+    ref0 = torch.where(keep, xd / (1 - p), torch.zeros_like(xd))
+    assert _rel(y0, ref0) < _tol(dtype)
+    assert _rel(y, ref0 + r1.detach().double() + r2.detach().double()) < _tol(dtype)
+    assert torch.equal(y0, ops.dropout_add(x, p, 77)), "same seed, same mask"
+    other = (ops.dropout_add(x, p, 78).detach().abs() > 0)
+    assert (other != keep).double().mean().item() > 0.05, "mask must depend on the seed"
+    dy = _rnd(n, dtype, 1.0, 4).cuda()
+    y.backward(dy)
+    assert _rel(x.grad, torch.where(keep, dy.double() / (1 - p), torch.zeros_like(xd))) < _tol(dtype)
+    assert torch.equal(r1.grad, dy) and torch.equal(r2.grad, dy)
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_patch_tokens(ops, dtype):
     B, Fr, R, P, D = 2, 3, 64, 16, 128

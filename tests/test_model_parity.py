@@ -4,6 +4,7 @@ vectors produced by the imported reference.  Tolerances:
   bf16 storage (throughput path): 3e-2 relative L2 on embeddings, 2e-2 relative on losses (bf16 rounding of every stored
   activation through the 2x12 layers; see DESIGN.md "Numerics").
 """
+import math
 import types
 
 import numpy as np
@@ -233,3 +234,52 @@ def test_long_clip_inference_vs_oracle(dtype, tol):
     assert rel_err(r['text_embeds'].float(), ot) < tol
     assert rel_err(r['video_embeds'].float(), ov) < tol
     assert torch.equal(feat, r['video_embeds'])
+
+
+def test_train_mode_dropout_fp32():
+    """yml drop_rate = 0.1 in train mode (roberta.py:203, :313, :342, :422).  The masks come from a counter-based generator,
+    so parity with torch's Philox stream is not defined; what is checked: eval() ignores dropout, the mask stream is
+    reproducible and seed dependent, it does not consume the default torch RNG (shared with ITM sampling), and the
+    backward pass uses exactly the forward's masks (central finite difference along the gradient direction)."""
+    import dataclasses
+    g, cfg, B, L, wseed, bseed = load_golden('tiny')
+    tasks = 'EgoNCE_MLM'
+    sd, data, noun, verb, oc = oracle_setup(cfg, B, L, wseed, bseed, tasks=tasks)
+    m0 = _build(cfg, sd, torch.float32, tasks)
+    m = _build(dataclasses.replace(cfg, drop_rate=0.1), sd, torch.float32, tasks)
+
+    def run(model, seed=5):
+        model.seed_dropout(seed)
+        torch.manual_seed(3)
+        loss, ld, _ = _forward(model, data, noun, verb, tasks)
+        return loss, torch.get_rng_state()
+
+    base, rng0 = run(m0)
+    m.eval()
+    with torch.no_grad():
+        ev, _ = run(m)
+    assert float(ev) == float(base), "eval() must not apply dropout"
+    m.train()
+    l1, rng1 = run(m)
+    l2, _ = run(m)
+    l3, _ = run(m, seed=6)
+    assert torch.isfinite(l1) and float(l1) == float(l2), "same dropout seed, same loss"
+    assert float(l1) != float(base) and float(l3) != float(l1)
+    assert torch.equal(rng0, rng1), "dropout must not draw from the default torch generator"
+    l1.backward()
+    params = [p for p in m.parameters() if p.grad is not None]
+    gn = math.sqrt(sum(float(p.grad.double().pow(2).sum()) for p in params))
+    dirs = [p.grad / gn for p in params]
+    eps = 2e-2 / gn
+    vals = []
+    with torch.no_grad():
+        for sgn in (+1, -1):
+            for p, d in zip(params, dirs):
+                p.add_(d, alpha=sgn * eps)
+            from egovlpv2_amd import hipops
+            hipops.invalidate_weight_cache()
+            vals.append(float(run(m)[0].double()))
+            for p, d in zip(params, dirs):
+                p.add_(d, alpha=-sgn * eps)
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(fd - gn) < 2e-2 * gn, (fd, gn)
