@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import copy
 import math
+import os
 
 import numpy as np
 import torch
@@ -87,6 +88,30 @@ def _init_tensor(name: str, shape, gen: torch.Generator, cfg: PathConfig) -> tor
     return t
 
 
+class SelectClipsFn(torch.autograd.Function):
+    """out clip i = sources[plan[i][0]] clip plan[i][1] on flat (clips * rows_per_clip, d) token matrices.  The plan lives on
+    the host (the ITM negatives are drawn there), so forward is one copy per clip and backward adds each clip's gradient
+    into its source in plan order -- deterministic also when a clip is selected more than once."""
+
+    @staticmethod
+    def forward(ctx, plan, rows, *sources):
+        d = sources[0].shape[1]
+        out = torch.empty(len(plan) * rows, d, dtype=sources[0].dtype, device=sources[0].device)
+        for i, (w, j) in enumerate(plan):
+            out[i * rows:(i + 1) * rows].copy_(sources[w][j * rows:(j + 1) * rows])
+        ctx.plan, ctx.rows = plan, rows
+        ctx.shapes = [None if s is None else s.shape for s in sources]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        rows = ctx.rows
+        grads = [None if shp is None else torch.zeros(shp, dtype=g.dtype, device=g.device) for shp in ctx.shapes]
+        for i, (w, j) in enumerate(ctx.plan):
+            grads[w][j * rows:(j + 1) * rows] += g[i * rows:(i + 1) * rows]
+        return (None, None, *grads)
+
+
 class FrozenInTime(nn.Module):
     def __init__(self, video_params, text_params, projection_dim=4096, load_checkpoint=None, projection='minimal',
                  load_temporal_fix='bilinear', config=config, task_names='EgoNCE_ITM_MLM', norm_layer=None, embed_dim=768,
@@ -149,7 +174,7 @@ class FrozenInTime(nn.Module):
             cache[key] = t
         return t
 
-    def _fork_text(self, fn):
+    def _fork_text(self, fn, uses=()):
         """Run the (latency-bound, 6-workgroup) text-encoder prefix on a second HIP stream so that it overlaps the video
         blocks; autograd replays each backward node on the stream of its forward, so the overlap holds for backward too.
         Returns a join() that orders the calling stream after the side stream."""
@@ -165,6 +190,11 @@ class FrozenInTime(nn.Module):
             self._side = torch.cuda.Stream(device=main.device)
         side = self._side
         side.wait_stream(main)
+        # tensors of the calling stream that the side stream reads (token ids, masks): without this the caching allocator may
+        # hand their memory to the calling stream again while side-stream kernels (forward or backward) are still queued
+        for t in uses:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(side)
         with torch.cuda.stream(side):
             out = fn()
 
@@ -344,10 +374,20 @@ class FrozenInTime(nn.Module):
         """model.py:524-530: SpaceTimeTransformer.forward_features (video_model.cls_token / video_model.norm) -> vid_proj."""
         return self._proj_mlp(self._video_features(video_data), 'vid_proj')
 
-    def _fused_stack(self, video, input_ids, attention_mask, need_video_out=True):
+    def _video_prefix(self, video):
+        """model.py:211-243 video side: model-level cls_token, pos/temporal embedding and the depth - n_fuse unfused blocks.
+        Depends on the pixels only (no dropout, no text), which is what lets forward() share it between MLM and ITM."""
+        B = video.shape[0]
+        v = self._patch_tokens(video, 'cls_token')
+        for i in range(self.cfg.depth - self.cfg.n_fuse):
+            v = self._video_block(v, i, B)
+        return v
+
+    def _fused_stack(self, video, input_ids, attention_mask, need_video_out=True, video_prefix=None):
         """model.py:211-271 / :295-357: model-level cls_token, unfused prefix, then fused steps where both sides read the
         other modality's state from BEFORE the step.  With need_video_out=False (MLM branch) the last video block, whose
-        output the reference computes and discards, is skipped."""
+        output the reference computes and discards, is skipped.  video_prefix: the already computed
+        output of _video_prefix for these clips (video is then ignored)."""
         c = self.cfg
         B, L = input_ids.shape
         mask = self._key_mask(attention_mask)
@@ -358,10 +398,8 @@ class FrozenInTime(nn.Module):
             for i in range(n_plain):
                 t = self._text_layer(t, mask, i, B, L)
             return t
-        t, join = self._fork_text(text_prefix)
-        v = self._patch_tokens(video, 'cls_token')
-        for i in range(n_plain):
-            v = self._video_block(v, i, B)
+        t, join = self._fork_text(text_prefix, uses=(input_ids, attention_mask, mask))
+        v = self._video_prefix(video) if video_prefix is None else video_prefix
         join()
         for i in range(n_plain, c.depth):
             last = i == c.depth - 1
@@ -378,14 +416,16 @@ class FrozenInTime(nn.Module):
             self.task_names = task_names
         c = self.cfg
         if 'EgoNCE' in self.task_names:
-            text_embeddings, join = self._fork_text(lambda: self.compute_text(text_data))
+            text_embeddings, join = self._fork_text(lambda: self.compute_text(text_data),
+                                                    uses=(text_data['input_ids'], text_data['attention_mask']))
             video_embeddings = self.compute_video(video_data)
             join()
             if return_embeds:
                 ret.update({'text_embeds': text_embeddings, 'video_embeds': video_embeddings})
         if 'ITM' in self.task_names:
             B, L = text_data['input_ids'].shape
-            v, t = self._fused_stack(video_data, text_data['input_ids'], text_data['attention_mask'])
+            v, t = self._fused_stack(video_data, text_data['input_ids'], text_data['attention_mask'],
+                                     video_prefix=data.get('_video_prefix'))
             vf = self._ln(self._cls_rows(v, B, c.seq), 'norm', c.eps_model_norm)            # self.norm(v)[:, 0]  (:275)
             tf = self._lin(self._cls_rows(t, B, L), 'cross_modal_text_transform')
             vf = self._lin(vf, 'cross_modal_video_transform')
@@ -394,16 +434,17 @@ class FrozenInTime(nn.Module):
             ret.update({'cross_attn_itm_logits': self._lin(torch.cat([ct, cv], dim=-1), 'itm_score.fc')})
         if 'MLM' in self.task_names:
             B, L = data['text_mlm_ids'].shape
-            logits = self._mlm_logits_padded(video_data, data['text_mlm_ids'], text_data['attention_mask'])
+            logits = self._mlm_logits_padded(video_data, data['text_mlm_ids'], text_data['attention_mask'],
+                                             video_prefix=data.get('_video_prefix'))
             ret.update({'cross_attn_mlm_logits': logits.reshape(B, L, -1)[..., :c.vocab]})
             ret['_mlm_logits_padded'] = logits
         return ret
 
-    def _mlm_logits_padded(self, video, mlm_ids, attention_mask):
+    def _mlm_logits_padded(self, video, mlm_ids, attention_mask, video_prefix=None):
         """MLM tail (model.py:360-365, heads.py:38-50); the vocabulary axis is padded to a multiple of 128 so that the
         logits rows stay 16-byte aligned (padded columns are excluded from the CE and get zero gradient)."""
         c = self.cfg
-        _, t = self._fused_stack(video, mlm_ids, attention_mask, need_video_out=False)
+        _, t = self._fused_stack(video, mlm_ids, attention_mask, need_video_out=False, video_prefix=video_prefix)
         t = self._lin(t, 'cross_modal_text_transform')
         t = self._lin(t, 'mlm_score.transform.dense', act='gelu')
         t = self._ln(t, 'mlm_score.transform.LayerNorm', c.eps_mlm)
@@ -450,8 +491,16 @@ class FrozenInTime(nn.Module):
                 ev.record()
             itm_pre = (rank, bsz, w_host, ev)
 
+        # The unfused video prefix (patch embedding + the first depth - n_fuse blocks under the model-level cls_token) is a
+        # function of the pixels alone, and the ITM batch is the MLM batch with some clips swapped for hard negatives
+        # (model.py:449-468).  The reference recomputes it in the ITM pass; here it is computed once and the ITM pass gathers
+        # clip rows from it (same values, and autograd sums both consumers' gradients exactly as the two passes would).
+        share_prefix = ('MLM' in task_names and 'ITM' in task_names and c.depth > c.n_fuse
+                        and not os.environ.get('EGV_NO_PREFIX_SHARING'))
+        v_pre = self._video_prefix(data['video']) if share_prefix else None
+
         if 'MLM' in task_names:                                                                  # :404-422
-            ret = self.infer(data, task_names='MLM', ret=ret)
+            ret = self.infer(dict(data, _video_prefix=v_pre) if share_prefix else data, task_names='MLM', ret=ret)
             logits = ret.pop('_mlm_logits_padded')
             labels = data['text_mlm_labels'].reshape(-1)
             ce_sum = ops.cross_entropy_sum(logits, labels, c.vocab, -100)
@@ -496,10 +545,27 @@ class FrozenInTime(nn.Module):
             stage[1].copy_(txt_idx)
             stage[2].copy_(itm_labels.long())
             idx_dev = stage.to(dev, non_blocking=True)
+            vid_list = vid_idx.tolist()
             vid_idx, txt_idx, labels_dev = idx_dev[0], idx_dev[1], idx_dev[2]
-            data_itm = {'video': all_video.index_select(0, vid_idx),
-                        'text': {'input_ids': all_text_ids.index_select(0, txt_idx),
+            data_itm = {'text': {'input_ids': all_text_ids.index_select(0, txt_idx),
                                  'attention_mask': all_text_masks.index_select(0, txt_idx)}}
+            if share_prefix:
+                lo = rank * bsz
+                remote = sorted({j for j in vid_list if not lo <= j < lo + bsz})
+                v_rem = None
+                if world > 1:
+                    # Clips owned by other ranks go through the prefix here, as in the reference.  With none this step, one
+                    # own clip is still sent through (its rows are never selected, so it contributes exact zeros): every
+                    # parameter is then used the same number of times each step, which DDP(static_graph=True) requires.
+                    rem = remote or [lo]
+                    rem_dev = self._pinned('itm_rem%d' % len(rem), (len(rem),), torch.int64)
+                    rem_dev.copy_(torch.tensor(rem))
+                    v_rem = self._video_prefix(all_video.index_select(0, rem_dev.to(dev, non_blocking=True)))
+                plan = [(0, j - lo) if lo <= j < lo + bsz else (1, remote.index(j)) for j in vid_list]
+                data_itm['video'] = None
+                data_itm['_video_prefix'] = SelectClipsFn.apply(plan, c.seq, v_pre, v_rem)
+            else:
+                data_itm['video'] = all_video.index_select(0, vid_idx)
             ret = self.infer(data_itm, task_names='ITM', ret=ret)
             itm_logits = ret['cross_attn_itm_logits']
             ce_sum = ops.cross_entropy_sum(ops.CastFn.apply(itm_logits, torch.float32).contiguous(), labels_dev.contiguous(), 2, -100)

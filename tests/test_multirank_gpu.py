@@ -1,0 +1,124 @@
+"""Two ranks of the HIP path on ONE GPU (gloo rendezvous, both processes on cuda:0): the world_size-2 semantics of
+FrozenInTime.forward -- global EgoNCE matrix, scalar-gathered MLM/ITM losses, hard negatives owned by the other rank
+(pixels gathered, shared video prefix for own clips) -- against the CPU oracle run under the same process group, and
+DDP(static_graph) gradient averaging over several steps.  fp32 storage; tolerances 1e-3 on losses, 5e-3 on gradients."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+class _HostGather(torch.autograd.Function):
+    """AllGather_multi semantics (trainer_egoclip.py:25-41) staged through the host so that it works on gloo with device
+    tensors: forward = concatenation over ranks, backward = the local slice of the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, t, n_gpu, args):
+        ctx.rank, ctx.b = args.rank, t.shape[0]
+        c = t.detach().cpu().contiguous()
+        out = [torch.empty_like(c) for _ in range(args.world_size)]
+        dist.all_gather(out, c)
+        return torch.cat(out, 0).to(t.device)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[ctx.b * ctx.rank: ctx.b * (ctx.rank + 1)], None, None
+
+
+def _worker(rank, world, port, q, steps):
+    try:
+        sys.path.insert(0, REPO)
+        sys.path.insert(0, os.path.join(REPO, 'tests'))
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(port)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        import types
+        from helpers import load_golden, oracle_setup
+        from oracle import ref_model as O
+        from egovlpv2_amd.model.model import FrozenInTime
+        from egovlpv2_amd.model.loss import EgoNCE
+        from egovlpv2_amd.synthetic import make_batch
+        torch.cuda.set_device(0)
+        _, cfg, B, L, wseed, _ = load_golden('tiny')
+        B = 4                                              # 2 negatives per rank and step
+        sd, _, _, _, oc = oracle_setup(cfg, B, L, wseed, 0, requires_grad=True)
+        m = FrozenInTime({'model': 'SpaceTimeTransformer', 'num_frames': cfg.frames, 'pretrained': True},
+                         {'model': 'roberta-base', 'pretrained': True, 'input': 'text'},
+                         path_config=cfg, task_names='EgoNCE_MLM_ITM', compute_dtype=torch.float32)
+        m.load_state_dict({k: v.detach() for k, v in sd.items()}, strict=True)
+        m = m.cuda()
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        net = DDP(m, device_ids=[0], static_graph=True, gradient_as_bucket_view=True, find_unused_parameters=False)
+        args = types.SimpleNamespace(world_size=world, rank=rank)
+        names = [n for n, _ in m.named_parameters()]
+        worst = {'loss': 0.0, 'grad': 0.0, 'remote': 0, 'no_remote': 0}
+        for step in range(steps):
+            data, noun, verb = make_batch(cfg, B, L, 500 + 10 * step + rank)
+            dev = {'video': data['video'].cuda(), 'text': {k: v.cuda() for k, v in data['text'].items()},
+                   'text_mlm_ids': data['text_mlm_ids'].cuda(), 'text_mlm_labels': data['text_mlm_labels'].cuda()}
+            np.random.seed(40 + step + rank)
+            torch.manual_seed(40 + step + rank)
+            net.zero_grad(set_to_none=True)
+            loss, ld, ret = net(dev, noun.cuda(), verb.cuda(), _HostGather.apply, world, args, {'loss': {'type': 'EgoNCE'}},
+                                EgoNCE(), 0, task_names='EgoNCE_MLM_ITM')
+            loss.backward()
+            torch.cuda.synchronize()
+            # oracle, same rank, same RNG stream, gathers over the same group
+            np.random.seed(40 + step + rank)
+            torch.manual_seed(40 + step + rank)
+            for v in sd.values():
+                v.grad = None
+            oloss, old, oret = O.forward_losses(sd, data, noun, verb, oc, 'EgoNCE_MLM_ITM',
+                                                world={'rank': rank, 'gather': lambda t: _HostGather.apply(t, world, args)})
+            oloss.backward()
+            assert [x for x in ret['_itm_neg_log']] == [x for x in oret['_itm_neg_log']], (ret['_itm_neg_log'], oret['_itm_neg_log'])
+            lo = rank * B
+            rem = [j for (_, kind, j) in ret['_itm_neg_log'] if kind == 'video' and not lo <= j < lo + B]
+            worst['remote' if rem else 'no_remote'] += 1
+            for k in ('EgoNCE', 'loss_mlm', 'loss_itm', 'loss_total'):
+                a, r = float(ld[k]), float(old[k])
+                worst['loss'] = max(worst['loss'], abs(a - r) / abs(r))
+            # DDP averaged the HIP gradients over ranks; average the oracle's the same way
+            for n in names:
+                g = sd[n].grad
+                g = torch.zeros_like(sd[n]) if g is None else g.detach().clone()
+                dist.all_reduce(g)
+                g /= world
+                a = dict(m.named_parameters())[n].grad.double().cpu().reshape(-1)
+                r = g.double().reshape(-1)
+                if n.endswith('.key.bias'):
+                    continue                                    # true gradient is exactly zero (softmax shift invariance)
+                err = (a - r).norm().item() / (r.norm().item() + 1e-6)
+                worst['grad'] = max(worst['grad'], err)
+        q.put((rank, 'ok', worst))
+        dist.destroy_process_group()
+    except Exception as e:                                        # surface the failure in the parent
+        import traceback
+        q.put((rank, 'error', traceback.format_exc()[-3000:]))
+
+
+def test_world2_full_step_vs_oracle():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, 4)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+    for rank, status, info in res:
+        assert status == 'ok', info
+        assert info['loss'] < 1e-3, info
+        assert info['grad'] < 5e-3, info
+    # the negative draws must have exercised the other-rank clip path at least once across ranks and steps
+    assert sum(info['remote'] for _, _, info in res) > 0, res
