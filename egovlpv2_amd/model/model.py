@@ -174,35 +174,43 @@ class FrozenInTime(nn.Module):
             cache[key] = t
         return t
 
-    def _fork_text(self, fn, uses=()):
-        """Run the (latency-bound, 6-workgroup) text-encoder prefix on a second HIP stream so that it overlaps the video
-        blocks; autograd replays each backward node on the stream of its forward, so the overlap holds for backward too.
-        Returns a join() that orders the calling stream after the side stream."""
-        import os
-        # Not under multi-rank DDP: the reducer orders a bucket's all-reduce only after the stream of the LAST gradient that
-        # lands in it, so gradients produced on two streams inside one bucket would race.
-        multi_rank = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        if os.environ.get('EGV_NO_OVERLAP') or multi_rank or not torch.cuda.is_available():
-            out = fn()
-            return out, (lambda: None)
+    def _overlap(self) -> bool:
+        """Two-stream execution (EGV_NO_OVERLAP=1 turns it off).  It composes with DDP: the AccumulateGrad nodes the reducer
+        hooks were created on the calling stream, autograd makes that stream wait for the producing stream before each
+        accumulation, and the reducer orders a bucket's all-reduce after the calling stream at the time the bucket's last
+        hook fires (tests/test_multirank_gpu.py runs both modes against the oracle)."""
+        return not os.environ.get('EGV_NO_OVERLAP') and torch.cuda.is_available()
+
+    def _fork_text(self, fn, uses=(), after=None):
+        """Run text-encoder work (latency-bound: a dozen workgroups per kernel) on a second HIP stream so that it overlaps
+        the video blocks; autograd replays each backward node on the stream of its forward, so the overlap holds for
+        backward too.  The side stream starts after `after` (an event of the calling stream) or, by default, after everything
+        queued on the calling stream so far.  `uses`: tensors allocated on the calling stream that fn reads -- they are
+        recorded on the side stream, otherwise the caching allocator may recycle them while side-stream kernels (forward
+        or backward) are still queued.  Returns (out, join); join() orders the calling stream after fn's work only."""
+        if not self._overlap():
+            return fn(), (lambda: None)
         main = torch.cuda.current_stream()
         if getattr(self, '_side', None) is None or self._side.device != main.device:
             self._side = torch.cuda.Stream(device=main.device)
         side = self._side
-        side.wait_stream(main)
-        # tensors of the calling stream that the side stream reads (token ids, masks): without this the caching allocator may
-        # hand their memory to the calling stream again while side-stream kernels (forward or backward) are still queued
+        if after is None:
+            side.wait_stream(main)
+        else:
+            side.wait_event(after)
         for t in uses:
             if torch.is_tensor(t) and t.is_cuda:
                 t.record_stream(side)
         with torch.cuda.stream(side):
             out = fn()
+            done = torch.cuda.Event()
+            done.record(side)
 
         def join():
-            main.wait_stream(side)
+            torch.cuda.current_stream().wait_event(done)
             for t in (out if isinstance(out, (tuple, list)) else (out,)):
                 if torch.is_tensor(t):
-                    t.record_stream(main)
+                    t.record_stream(torch.cuda.current_stream())
         return out, join
 
     def p(self, name: str) -> torch.Tensor:
@@ -383,29 +391,42 @@ class FrozenInTime(nn.Module):
             v = self._video_block(v, i, B)
         return v
 
-    def _fused_stack(self, video, input_ids, attention_mask, need_video_out=True, video_prefix=None):
+    def _text_prefix(self, input_ids, attention_mask):
+        """embeddings + the depth - n_fuse unfused RoBERTa layers (model.py:247-257); returns (hidden, additive key mask)"""
+        B, L = input_ids.shape
+        mask = self._key_mask(attention_mask)
+        t = self._text_embeddings(input_ids)
+        for i in range(self.cfg.depth - self.cfg.n_fuse):
+            t = self._text_layer(t, mask, i, B, L)
+        return t, mask
+
+    def _fused_stack(self, video, input_ids, attention_mask, need_video_out=True, video_prefix=None, text_prefix=None):
         """model.py:211-271 / :295-357: model-level cls_token, unfused prefix, then fused steps where both sides read the
         other modality's state from BEFORE the step.  With need_video_out=False (MLM branch) the last video block, whose
         output the reference computes and discards, is skipped.  video_prefix: the already computed
-        output of _video_prefix for these clips (video is then ignored)."""
+        output of _video_prefix for these clips (video is then ignored); text_prefix: ((hidden, mask), join) of a
+        _text_prefix already forked by the caller.
+        Both halves of a fused step depend only on the previous step, so the text layer runs on the side stream while the
+        video block runs on the calling stream (events both ways per step)."""
         c = self.cfg
         B, L = input_ids.shape
-        mask = self._key_mask(attention_mask)
         n_plain = c.depth - c.n_fuse
-
-        def text_prefix():
-            t = self._text_embeddings(input_ids)
-            for i in range(n_plain):
-                t = self._text_layer(t, mask, i, B, L)
-            return t
-        t, join = self._fork_text(text_prefix, uses=(input_ids, attention_mask, mask))
+        if text_prefix is None:
+            text_prefix = self._fork_text(lambda: self._text_prefix(input_ids, attention_mask), uses=(input_ids, attention_mask))
+        (t, mask), join = text_prefix
         v = self._video_prefix(video) if video_prefix is None else video_prefix
         join()
+        overlap = self._overlap()
         for i in range(n_plain, c.depth):
             last = i == c.depth - 1
+            ev = None
+            if overlap:
+                ev = torch.cuda.Event()
+                ev.record()                                                   # v (and t, joined above) are ready here
+            t_new, join = self._fork_text(lambda: self._text_layer(t, mask, i, B, L, enc=v), uses=(v, mask), after=ev)
             v_new = None if (last and not need_video_out) else self._video_block(v, i, B, y=t, y_mask=mask, L=L)
-            t = self._text_layer(t, mask, i, B, L, enc=v)
-            v = v_new
+            join()
+            v, t = v_new, t_new
         return v, t
 
     def infer(self, data, video_only=False, return_embeds=True, task_names=None, ret=None):
@@ -425,7 +446,7 @@ class FrozenInTime(nn.Module):
         if 'ITM' in self.task_names:
             B, L = text_data['input_ids'].shape
             v, t = self._fused_stack(video_data, text_data['input_ids'], text_data['attention_mask'],
-                                     video_prefix=data.get('_video_prefix'))
+                                     video_prefix=data.get('_video_prefix'), text_prefix=data.get('_text_prefix'))
             vf = self._ln(self._cls_rows(v, B, c.seq), 'norm', c.eps_model_norm)            # self.norm(v)[:, 0]  (:275)
             tf = self._lin(self._cls_rows(t, B, L), 'cross_modal_text_transform')
             vf = self._lin(vf, 'cross_modal_video_transform')
@@ -435,16 +456,17 @@ class FrozenInTime(nn.Module):
         if 'MLM' in self.task_names:
             B, L = data['text_mlm_ids'].shape
             logits = self._mlm_logits_padded(video_data, data['text_mlm_ids'], text_data['attention_mask'],
-                                             video_prefix=data.get('_video_prefix'))
+                                             video_prefix=data.get('_video_prefix'), text_prefix=data.get('_text_prefix'))
             ret.update({'cross_attn_mlm_logits': logits.reshape(B, L, -1)[..., :c.vocab]})
             ret['_mlm_logits_padded'] = logits
         return ret
 
-    def _mlm_logits_padded(self, video, mlm_ids, attention_mask, video_prefix=None):
+    def _mlm_logits_padded(self, video, mlm_ids, attention_mask, video_prefix=None, text_prefix=None):
         """MLM tail (model.py:360-365, heads.py:38-50); the vocabulary axis is padded to a multiple of 128 so that the
         logits rows stay 16-byte aligned (padded columns are excluded from the CE and get zero gradient)."""
         c = self.cfg
-        _, t = self._fused_stack(video, mlm_ids, attention_mask, need_video_out=False, video_prefix=video_prefix)
+        _, t = self._fused_stack(video, mlm_ids, attention_mask, need_video_out=False, video_prefix=video_prefix,
+                                 text_prefix=text_prefix)
         t = self._lin(t, 'cross_modal_text_transform')
         t = self._lin(t, 'mlm_score.transform.dense', act='gelu')
         t = self._ln(t, 'mlm_score.transform.LayerNorm', c.eps_mlm)
@@ -489,7 +511,16 @@ class FrozenInTime(nn.Module):
                 w_host.copy_(w_dev, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
-            itm_pre = (rank, bsz, w_host, ev)
+            # the gathers of the ITM branch (:429-431) are issued here so that the text stream can start on the ITM
+            # batch while the calling stream is still busy with the MLM pass
+            all_video = gather(data['video']) if world > 1 else data['video']
+            all_text_ids = gather(data['text']['input_ids'])
+            all_text_masks = gather(data['text']['attention_mask'])
+            ev_in = None
+            if torch.cuda.is_available():
+                ev_in = torch.cuda.Event()
+                ev_in.record()
+            itm_pre = (rank, bsz, w_host, ev, all_video, all_text_ids, all_text_masks, ev_in)
 
         # The unfused video prefix (patch embedding + the first depth - n_fuse blocks under the model-level cls_token) is a
         # function of the pixels alone, and the ITM batch is the MLM batch with some clips swapped for hard negatives
@@ -497,10 +528,16 @@ class FrozenInTime(nn.Module):
         # clip rows from it (same values, and autograd sums both consumers' gradients exactly as the two passes would).
         share_prefix = ('MLM' in task_names and 'ITM' in task_names and c.depth > c.n_fuse
                         and not os.environ.get('EGV_NO_PREFIX_SHARING'))
-        v_pre = self._video_prefix(data['video']) if share_prefix else None
+        v_pre = None
+        data_mlm = data
+        if share_prefix:
+            am = data['text']['attention_mask']
+            txt_mlm = self._fork_text(lambda: self._text_prefix(data['text_mlm_ids'], am), uses=(data['text_mlm_ids'], am))
+            v_pre = self._video_prefix(data['video'])                       # overlaps the MLM text prefix
+            data_mlm = dict(data, _video_prefix=v_pre, _text_prefix=txt_mlm)
 
         if 'MLM' in task_names:                                                                  # :404-422
-            ret = self.infer(dict(data, _video_prefix=v_pre) if share_prefix else data, task_names='MLM', ret=ret)
+            ret = self.infer(data_mlm, task_names='MLM', ret=ret)
             logits = ret.pop('_mlm_logits_padded')
             labels = data['text_mlm_labels'].reshape(-1)
             ce_sum = ops.cross_entropy_sum(logits, labels, c.vocab, -100)
@@ -513,10 +550,7 @@ class FrozenInTime(nn.Module):
             loss_dict.update({'loss_mlm': loss_mlm})
 
         if 'ITM' in task_names:                                                                  # :426-483
-            rank, bsz, w_host, ev = itm_pre
-            all_video = gather(data['video'])
-            all_text_ids = gather(data['text']['input_ids'])
-            all_text_masks = gather(data['text']['attention_mask'])
+            rank, bsz, w_host, ev, all_video, all_text_ids, all_text_masks, ev_in = itm_pre
             pos_len = bsz // 2
             itm_labels = torch.cat([torch.ones(pos_len), torch.zeros(bsz - pos_len)])
             itm_labels = itm_labels[torch.randperm(itm_labels.size(0))]
@@ -547,8 +581,16 @@ class FrozenInTime(nn.Module):
             idx_dev = stage.to(dev, non_blocking=True)
             vid_list = vid_idx.tolist()
             vid_idx, txt_idx, labels_dev = idx_dev[0], idx_dev[1], idx_dev[2]
-            data_itm = {'text': {'input_ids': all_text_ids.index_select(0, txt_idx),
-                                 'attention_mask': all_text_masks.index_select(0, txt_idx)}}
+            if share_prefix:
+                def text_itm():            # runs on the text stream: it only needs the gathered ids, not the MLM pass
+                    ti = stage[1].to(dev, non_blocking=True)
+                    ids, am = all_text_ids.index_select(0, ti), all_text_masks.index_select(0, ti)
+                    return self._text_prefix(ids, am) + (ids, am)
+                out, join = self._fork_text(text_itm, uses=(all_text_ids, all_text_masks), after=ev_in)
+                data_itm = {'text': {'input_ids': out[2], 'attention_mask': out[3]}, '_text_prefix': ((out[0], out[1]), join)}
+            else:
+                data_itm = {'text': {'input_ids': all_text_ids.index_select(0, txt_idx),
+                                     'attention_mask': all_text_masks.index_select(0, txt_idx)}}
             if share_prefix:
                 lo = rank * bsz
                 remote = sorted({j for j in vid_list if not lo <= j < lo + bsz})

@@ -1,7 +1,7 @@
 """Two ranks of the HIP path on ONE GPU (gloo rendezvous, both processes on cuda:0): the world_size-2 semantics of
 FrozenInTime.forward -- global EgoNCE matrix, scalar-gathered MLM/ITM losses, hard negatives owned by the other rank
 (pixels gathered, shared video prefix for own clips) -- against the CPU oracle run under the same process group, and
-DDP(static_graph) gradient averaging over several steps.  fp32 storage; tolerances 1e-3 on losses, 5e-3 on gradients."""
+DDP(static_graph) gradient averaging over several steps, with and without the second (text) stream.  fp32 storage; tolerances 1e-3 on losses, 5e-3 on gradients."""
 import os
 import sys
 
@@ -32,8 +32,10 @@ class _HostGather(torch.autograd.Function):
         return g[ctx.b * ctx.rank: ctx.b * (ctx.rank + 1)], None, None
 
 
-def _worker(rank, world, port, q, steps):
+def _worker(rank, world, port, q, steps, overlap):
     try:
+        if not overlap:
+            os.environ['EGV_NO_OVERLAP'] = '1'
         sys.path.insert(0, REPO)
         sys.path.insert(0, os.path.join(REPO, 'tests'))
         os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -104,11 +106,12 @@ def _worker(rank, world, port, q, steps):
         q.put((rank, 'error', traceback.format_exc()[-3000:]))
 
 
-def test_world2_full_step_vs_oracle():
+@pytest.mark.parametrize('overlap', [True, False])
+def test_world2_full_step_vs_oracle(overlap):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29900 + (os.getpid() % 90)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, 4)) for r in range(2)]
+    port = 29900 + (os.getpid() % 90) + (100 if overlap else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, 3, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=900) for _ in procs]
