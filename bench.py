@@ -190,17 +190,29 @@ def main():
     for _ in range(a.warmup):
         ld = step()
     sync()
-    use_events = not a.no_gemm_events
-    if use_events:
-        ops.prof_reset()
-        ops.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         ld = step()
     sync()
     dt = time.perf_counter() - t0
+    # Per-kernel durations for the roofline object: the same K steps once more with one HIP event pair around every GEMM
+    # launch.  This pass runs single-stream (EGV_NO_OVERLAP=1): in the timed pass above text-side and weight-gradient
+    # kernels share the CUs with the kernel being timed, so an event pair there measures co-scheduling, not the kernel.
+    # The event pass is not part of `value`.
+    use_events = not a.no_gemm_events
     if use_events:
+        prev = os.environ.get('EGV_NO_OVERLAP')
+        os.environ['EGV_NO_OVERLAP'] = '1'
+        step()
+        sync()
+        ops.prof_reset()
+        ops.prof_enable(True)
+        for _ in range(a.steps):
+            step()
+        sync()
         ops.prof_enable(False)
+        if prev is None:
+            os.environ.pop('EGV_NO_OVERLAP', None)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -219,6 +231,15 @@ def main():
             e[0] += fl
             e[1] += ms
             e[2] += 1
+        if os.environ.get('EGV_BENCH_SHAPES'):           # per (kernel kind, FLOPs) breakdown on stderr: which shapes run slow in-step
+            by = {}
+            for fl, ms, kd in recs:
+                e = by.setdefault((kd, fl), [0.0, 0])
+                e[0] += ms
+                e[1] += 1
+            for (kd, fl), (ms, n) in sorted(by.items(), key=lambda kv: -kv[1][0])[:40]:
+                print(f"shape kind={kd} gflop={fl / 1e9:9.2f} n/step={n / a.steps:6.1f} ms/step={ms / a.steps:7.3f} "
+                      f"avg_us={ms / n * 1e3:8.1f} TF={fl * n / (ms * 1e-3) / 1e12 if ms else 0:7.1f}", file=sys.stderr)
         tot_ms = sum(e[1] for e in agg.values())
         dom = max(agg, key=lambda k: agg[k][1])
         fl, ms, n = agg[dom]

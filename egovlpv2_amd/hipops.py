@@ -11,6 +11,7 @@ version (``compute_weight``) -- the cast kernel is part of the timed step.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 from torch.autograd import Function
@@ -177,6 +178,41 @@ def dot(a, b):
     return out
 
 
+# ---- weight-gradient stream -----------------------------------------------------------------------------
+_wg_streams = {}
+
+
+def _wgrad_fork(M, fn, uses):
+    """dW = dy^T x and dx = dy W of one layer are independent; run the weight-gradient GEMM(s) `fn` on a companion stream
+    of the current stream so that the two grids fill each other's tail waves and prologue/epilogue bubbles (a 768x768
+    layer is 594 tiles on 512 resident slots: the last wave is 16% full).  The companion starts after everything queued
+    on the current stream so far; `uses` (current-stream tensors fn reads) are recorded on it.  Returns (out, join):
+    join() orders the current stream after fn, to be called before the gradients are handed back to autograd.
+    EGV_NO_OVERLAP=1 (or a small problem) runs fn inline."""
+    if M < 4096 or os.environ.get('EGV_NO_OVERLAP'):
+        return fn(), (lambda: None)
+    cur = torch.cuda.current_stream()
+    key = (cur.device.index, cur.cuda_stream)
+    st = _wg_streams.get(key)
+    if st is None:
+        st = _wg_streams[key] = torch.cuda.Stream(device=cur.device)
+    st.wait_stream(cur)
+    for t in uses:
+        if t is not None:
+            t.record_stream(st)
+    with torch.cuda.stream(st):
+        out = fn()
+        done = torch.cuda.Event()
+        done.record(st)
+
+    def join():
+        cur.wait_event(done)
+        for t in (out if isinstance(out, (tuple, list)) else (out,)):
+            if torch.is_tensor(t):
+                t.record_stream(cur)
+    return out, join
+
+
 # ---- Linear (+bias, activation, gate, residuals) --------------------------------------------------------
 class LinearFn(Function):
     """y = gate * act(x W^T + b) + res1 + res2   (gate requires act == none; its pre-gate value is saved)."""
@@ -220,19 +256,20 @@ class LinearFn(Function):
             dz = torch.empty_like(dy2)
             check(lib.egv_act_bwd(_dt(dy2), _p(dy2), _p(pre), _p(dz), dy2.numel(), L.ACT_GELU, _st()), 'egv_act_bwd')
         dx = dw = db = dg = None
-        if ctx.needs_input_grad[0]:
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_b and ctx.needs_input_grad[2]
+
+        def weight_grads():
+            if need_w:
+                return wgrad(dz, x2, M, N, K, gate=gate, bias=True) if need_b else (wgrad(dz, x2, M, N, K, gate=gate), None)
+            return None, (colsum(dz, M, N, gate=gate) if need_b else None)
+        (dw, db), join = _wgrad_fork(M if (need_x and need_w) else 0, weight_grads, (dz, x2))
+        if need_x:
             dx = torch.empty(M, K, dtype=dy2.dtype, device=dy2.device)
             dgrad(dz, weight, dx, M, N, K, gate=gate)
             dx = dx.reshape(ctx.xshape)
-        if ctx.needs_input_grad[1]:
-            if has_b and ctx.needs_input_grad[2]:
-                dw, db = wgrad(dz, x2, M, N, K, gate=gate, bias=True)
-            else:
-                dw = wgrad(dz, x2, M, N, K, gate=gate)
-        elif has_b and ctx.needs_input_grad[2]:
-            db = colsum(dz, M, N, gate=gate)
         if has_g and ctx.needs_input_grad[3]:
             dg = dot(dy2, pre)
+        join()
         dr1 = dy if has_r1 and ctx.needs_input_grad[4] else None
         dr2 = dy if has_r2 and ctx.needs_input_grad[5] else None
         return dx, dw, db, dg, dr1, dr2, None
@@ -276,15 +313,18 @@ class MlpFn(Function):
         dy2 = dy.reshape(M, N)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
+        (dw2, db2), join2 = _wgrad_fork(M, lambda: wgrad(dy2, h, M, N, Hd, bias=True), (dy2, h))
         dpre = torch.empty(M, Hd, dtype=dy2.dtype, device=dy2.device)
         dgrad(dy2, w2, dpre, M, N, Hd, aux=pre, dact=L.ACT_GELU)
-        dw2, db2 = wgrad(dy2, h, M, N, Hd, bias=True)
-        dw1, db1 = wgrad(dpre, x2, M, Hd, K, bias=True)
+        need_x = ctx.needs_input_grad[0]
+        (dw1, db1), join1 = _wgrad_fork(M if need_x else 0, lambda: wgrad(dpre, x2, M, Hd, K, bias=True), (dpre, x2))
         dx = None
-        if ctx.needs_input_grad[0]:
+        if need_x:
             dx = torch.empty(M, K, dtype=dy2.dtype, device=dy2.device)
             dgrad(dpre, w1, dx, M, Hd, K)
             dx = dx.reshape(ctx.xshape)
+        join2()
+        join1()
         return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None)
 
 
