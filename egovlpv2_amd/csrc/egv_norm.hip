@@ -255,8 +255,41 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
     }
 }
 
+// dst[C,R] (T2) = transpose(src[R,C] (T1, row pitch ld)) through a padded 64x64 LDS tile
+template <typename T1, typename T2>
+__global__ __launch_bounds__(256) void transpose_kernel(const T1* __restrict__ src, T2* __restrict__ dst, int R, int Cc, int ld) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < Cc) ? Elem<T1>::ld(src + (size_t)r * ld + c) : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < Cc && r < R) Elem<T2>::st(dst + (size_t)c * R + r, tile[tx][i]);
+    }
+}
+
 }  // namespace egv
 using namespace egv;
+
+extern "C" int egv_transpose(int dtype_src, int dtype_dst, const void* src, void* dst, int R, int Cc, int ld, void* stream) {
+    EGV_CHECK(R > 0 && Cc > 0 && ld >= Cc, "egv_transpose: bad shape R=%d C=%d ld=%d", R, Cc, ld);
+    const dim3 grid((Cc + 63) / 64, (R + 63) / 64);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype_src == EGV_BF16 && dtype_dst == EGV_BF16)
+        hipLaunchKernelGGL((transpose_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, R, Cc, ld);
+    else if (dtype_src == EGV_F32 && dtype_dst == EGV_BF16)
+        hipLaunchKernelGGL((transpose_kernel<float, bf16_t>), grid, dim3(256), 0, st, (const float*)src, (bf16_t*)dst, R, Cc, ld);
+    else if (dtype_src == EGV_F32 && dtype_dst == EGV_F32)
+        hipLaunchKernelGGL((transpose_kernel<float, float>), grid, dim3(256), 0, st, (const float*)src, (float*)dst, R, Cc, ld);
+    else
+        EGV_CHECK(false, "egv_transpose: unsupported dtype pair %d -> %d", dtype_src, dtype_dst);
+    EGV_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int egv_cast_transpose(const float* src, void* dst, int R, int Cc, void* stream) {
     hipLaunchKernelGGL(cast_transpose_kernel, dim3((Cc + 63) / 64, (R + 63) / 64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src,
@@ -303,10 +336,15 @@ extern "C" int egv_layernorm_bwd(int dtype, const void* dy, const void* x, const
                            (const float*)add, (float*)dx, partial, M, D, rpb);
     EGV_LAUNCH_CHECK();
     // partial layout [nb2][2][D]: columns 0..D-1 = dgamma, D..2D-1 = dbeta
-    hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 63) / 64), dim3(1024), 0, st, (const float*)partial, dgamma, nb2, D,
-                       2 * D, 1.0f, (const float*)nullptr);
-    hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 63) / 64), dim3(1024), 0, st, (const float*)partial + D, dbeta, nb2, D,
-                       2 * D, 1.0f, (const float*)nullptr);
+    if (dbeta == dgamma + D) {                  // caller keeps [dgamma ; dbeta] in one buffer: one reduction over 2D columns
+        hipLaunchKernelGGL(colsum_partials_kernel, dim3((2 * D + 63) / 64), dim3(1024), 0, st, (const float*)partial, dgamma, nb2,
+                           2 * D, 2 * D, 1.0f, (const float*)nullptr);
+    } else {
+        hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 63) / 64), dim3(1024), 0, st, (const float*)partial, dgamma, nb2, D,
+                           2 * D, 1.0f, (const float*)nullptr);
+        hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 63) / 64), dim3(1024), 0, st, (const float*)partial + D, dbeta, nb2, D,
+                           2 * D, 1.0f, (const float*)nullptr);
+    }
     EGV_LAUNCH_CHECK();
     return 0;
 }

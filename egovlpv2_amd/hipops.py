@@ -357,7 +357,16 @@ class VocabLinearFn(Function):
         dy = dy.contiguous()
         w = compute_weight(weight, dy.dtype)
         dx = torch.empty(M, K, dtype=dy.dtype, device=dy.device)
-        gemm(dy, w, dx, a_trans=0, b_trans=1, M=M, N=K, K=V, lda=Vp, ldb=K, ldc=K)
+        if dy.dtype == torch.bfloat16 and M % 8 == 0:
+            # dx = dy W reduces over the 50265 vocabulary entries with only M x K = 256 x 768 outputs: 12 tiles for a plain
+            # GEMM.  The split-K weight-gradient kernel is the right shape for it: dx^T[K,M] = W^T[K,V] dy^T[V,M] is a
+            # "weight gradient" with W as the row operand and dy^T as the column operand, reduced over V in ~40 slabs.
+            dyT = torch.empty(V, M, dtype=dy.dtype, device=dy.device)
+            check(lib.egv_transpose(L.EGV_BF16, L.EGV_BF16, _p(dy), _p(dyT), M, V, Vp, _st()), 'egv_transpose(dy)')
+            dxT = wgrad(w, dyT, V, K, M)
+            check(lib.egv_transpose(L.EGV_F32, L.EGV_BF16, _p(dxT), _p(dx), K, M, M, _st()), 'egv_transpose(dx)')
+        else:
+            gemm(dy, w, dx, a_trans=0, b_trans=1, M=M, N=K, K=V, lda=Vp, ldb=K, ldc=K)
         dw, db = wgrad(dy, x2, M, V, K, ldy=Vp, bias=True)
         return dx.reshape(ctx.xshape), dw, db, None
 
@@ -393,8 +402,8 @@ class LayerNormFn(Function):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         dx = torch.empty_like(x2)
-        dg = torch.empty(D, dtype=torch.float32, device=x2.device)
-        db = torch.empty(D, dtype=torch.float32, device=x2.device)
+        gb = torch.empty(2, D, dtype=torch.float32, device=x2.device)     # [dgamma ; dbeta]: one reduction launch
+        dg, db = gb[0], gb[1]
         ws = workspace(lib.egv_layernorm_bwd_workspace_bytes(M, D), x2.device)
         check(lib.egv_layernorm_bwd(_dt(x2), _p(dy2), _p(x2), _p(stats), _p(gamma), None, _p(dx), _p(dg), _p(db), M, D,
                                     _p(ws), _st()), 'egv_layernorm_bwd')

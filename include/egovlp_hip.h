@@ -86,6 +86,9 @@ int egv_dropout_add(int dtype, const void* x, const void* r1, const void* r2, vo
 int egv_cast(int dtype_src, int dtype_dst, const void* src, void* dst, long long n, void* stream);
 /* dst[C][R] (bf16) = src[R][C] (fp32): transposed bf16 compute copy of a weight, so that dgrad runs in the NT form */
 int egv_cast_transpose(const float* src, void* dst, int R, int C, void* stream);
+/* dst[C][R] (dtype_dst) = src[R][C] (dtype_src, row pitch ld elements); pairs bf16->bf16, f32->bf16, f32->f32.  Used by the
+   MLM decoder's input gradient (heads.py:44-50 backward): dlogits^T and dx^T feed / leave the split-K weight-gradient kernel. */
+int egv_transpose(int dtype_src, int dtype_dst, const void* src, void* dst, int R, int C, int ld, void* stream);
 
 /* ---- grouped attention, head_dim 64 (video_transformer.py:35-39,117-150,155-182; roberta.py:257-327) ----
  * Query rows and key rows are affine row sets of token matrices:
