@@ -101,7 +101,10 @@ __device__ __forceinline__ bf16x8_t ld_frag_global(const bf16_t* p, bool valid) 
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
-__device__ __forceinline__ unsigned int pack2(float a, float b) { return (unsigned int)f2bf(a) | ((unsigned int)f2bf(b) << 16); }
+__device__ __forceinline__ unsigned int pack2(float a, float b) { return pack_bf16x2(a, b); }
+
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 
 __device__ __forceinline__ bf16x8_t pack8(const f32x4_t& a, const f32x4_t& b) {
     u32x4_t v = {pack2(a[0], a[1]), pack2(a[2], a[3]), pack2(b[0], b[1]), pack2(b[2], b[3])};
@@ -126,9 +129,13 @@ __device__ __forceinline__ void st_bf16x4(bf16_t* p, float a, float b, float c, 
 // forward.  NT = 16-row tiles of the key side (even).  grid (own chunks, problems, heads), NW waves,
 // TPW own tiles per wave per workgroup.
 // ------------------------------------------------------------------------------------------------
-template <int NT, int NW>
+// FL: bit 0 = additive key mask present, bit 1 = probability dropout on; the video-side launches (neither) get a loop
+// without the per-element conditionals.  Scores are kept in the log2 domain (scale * log2(e) folded into one multiply).
+template <int NT, int NW, int FL>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnArgs a, int tiles_per_wg) {
     constexpr int VP = vt_pitch(NT);
+    constexpr bool MASK = (FL & 1) != 0, DROP = (FL & 2) != 0;
+    const float sc2 = a.scale * LOG2E;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sK = smem;                       // [NT*16][RP]
     unsigned char* sVt = smem + NT * 16 * RP;       // [64][VP]
@@ -167,16 +174,25 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnArgs a
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sK, t * 16 + fr, 0, fg), q0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sK, t * 16 + fr, 1, fg), q1, acc, 0, 0, 0);
+            if (t * 16 < ntot) {                                      // uniform: tiles past the last key are never touched
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sK, t * 16 + fr, 0, fg), q0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sK, t * 16 + fr, 1, fg), q1, acc, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = t * 16 + fg * 4 + r;              // index inside this chunk; r0 + key is the global key index
-                float v = acc[r] * a.scale;
-                if (a.mask && r0 + key >= a.extra && key < ntot) v += a.mask[(long long)b * a.mask_ld + r0 + key - a.extra];
-                v = key < ntot ? v : -INFINITY;
-                acc[r] = v;
-                m = fmaxf(m, v);
+                for (int r = 0; r < 4; ++r) {
+                    const int key = t * 16 + fg * 4 + r;              // index inside this chunk; r0 + key is the global key index
+                    float v = acc[r] * sc2;
+                    if (MASK) {
+                        if (a.mask && r0 + key >= a.extra && key < ntot) v += a.mask[(long long)b * a.mask_ld + r0 + key - a.extra] * LOG2E;
+                    }
+                    acc[r] = v;
+                }
+                if (t * 16 + 16 > ntot) {                             // uniform: only the last, partial tile pays for the select
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = (t * 16 + fg * 4 + r < ntot) ? acc[r] : -INFINITY;
+                }
+                m = fmaxf(m, fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
+            } else {
+                acc = f32x4_t{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
             }
             s[t] = acc;
             if (t & 1) __builtin_amdgcn_sched_barrier(0);
@@ -184,30 +200,39 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnArgs a
         m = grp_max(m);
         float l = 0.f;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t) {
+            if (t * 16 < ntot) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __expf(s[t][r] - m);
-                s[t][r] = e;
-                l += e;
+                for (int r = 0; r < 4; ++r) {
+                    const float e = exp2_fast(s[t][r] - m);
+                    s[t][r] = e;
+                    l += e;
+                }
+            } else {
+                s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             }
+        }
         l = grp_sum(l);
-        if (a.drop_p > 0.f) {                         // dropout on the normalised probabilities: l keeps the full sum
-            const long long qid = (long long)p * a.q.n + q;
+        if (DROP) {                                   // dropout on the normalised probabilities: l keeps the full sum
+            if (a.drop_p > 0.f) {
+                const long long qid = (long long)p * a.q.n + q;
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+                for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s[t][r] *= drop_mult(a, qid, r0 + t * 16 + fg * 4 + r, h);
+                    for (int r = 0; r < 4; ++r) s[t][r] *= drop_mult(a, qid, r0 + t * 16 + fg * 4 + r, h);
+            }
         }
         f32x4_t o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < NT / 2; ++kk) {
-            const bf16x8_t pf = pack8(s[2 * kk], s[2 * kk + 1]);
+            if (kk * 32 < ntot) {
+                const bf16x8_t pf = pack8(s[2 * kk], s[2 * kk + 1]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_t<NT>(sVt, dt * 16 + fr, kk, fg), pf, o[dt], 0, 0, 0);
+                for (int dt = 0; dt < 4; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_t<NT>(sVt, dt * 16 + fr, kk, fg), pf, o[dt], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (qv && a.nsplit > 1) {
@@ -216,13 +241,13 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnArgs a
             float* dst = a.ws + (((long long)split * nrows + orow) * a.H + h) * 66;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4_t*>(dst + 2 + dt * 16 + fg * 4) = o[dt];
-            if (fg == 0) { dst[0] = m; dst[1] = l; }
+            if (fg == 0) { dst[0] = m * LN2; dst[1] = l; }
         } else if (qv) {
             const float inv = 1.0f / l;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
                 st_bf16x4(O + qrow * a.ldo + ho + dt * 16 + fg * 4, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
-            if (a.lse && fg == 0) a.lse[qrow * a.H + h] = m + __logf(l);
+            if (a.lse && fg == 0) a.lse[qrow * a.H + h] = m * LN2 + __logf(l);
         }
     }
 }
@@ -230,9 +255,11 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnArgs a
 // ------------------------------------------------------------------------------------------------
 // backward, query-owned: dQ and delta = rowsum(dO * O)
 // ------------------------------------------------------------------------------------------------
-template <int NT, int NW>
+template <int NT, int NW, int FL>
 __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a, int tiles_per_wg) {
     constexpr int VP = vt_pitch(NT);
+    constexpr bool MASK = (FL & 1) != 0, DROP = (FL & 2) != 0;
+    const float sc2 = a.scale * LOG2E;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sKt = smem;                      // [64][VP]  K transposed (A operand of S^T via transposing reads, and of dQ^T)
     unsigned char* sVt = sKt + 64 * VP;             // [64][VP]  V transposed (A operand of dP^T via transposing reads)
@@ -274,7 +301,7 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a,
 #pragma unroll
         for (int e = 0; e < 8; ++e) dl += (float)g0[e] * (float)o0[e] + (float)g1[e] * (float)o1[e];
         dl = grp_sum(dl);
-        const float lse = qv ? a.lse[qrow * a.H + h] : 0.f;
+        const float lse2 = qv ? a.lse[qrow * a.H + h] * LOG2E : 0.f;
         if (qv && fg == 0 && split == 0) a.delta[qrow * a.H + h] = dl;
 
         bf16x8_t dsf[NT / 2];
@@ -285,18 +312,29 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a,
             for (int u = 0; u < 2; ++u) {
                 const int t = 2 * kk + u;
                 f32x4_t acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sKt, t * 16, 0, fr, fg), q0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sKt, t * 16, 1, fr, fg), q1, acc, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sVt, t * 16, 0, fr, fg), g0, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sVt, t * 16, 1, fr, fg), g1, dp, 0, 0, 0);
+                if (t * 16 < ntot) {                                  // uniform: dead key tiles contribute dS = 0
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sKt, t * 16, 0, fr, fg), q0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sKt, t * 16, 1, fr, fg), q1, acc, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sVt, t * 16, 0, fr, fg), g0, dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sVt, t * 16, 1, fr, fg), g1, dp, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = t * 16 + fg * 4 + r;
-                    float v = acc[r] * a.scale;
-                    if (a.mask && r0 + key >= a.extra && key < ntot) v += a.mask[(long long)b * a.mask_ld + r0 + key - a.extra];
-                    const float pj = key < ntot ? __expf(v - lse) : 0.f;
-                    const float mu = a.drop_p > 0.f ? drop_mult(a, (long long)p * a.q.n + q, r0 + key, h) : 1.0f;
-                    acc[r] = pj * (dp[r] * mu - dl);
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = t * 16 + fg * 4 + r;
+                        float v = acc[r] * sc2 - lse2;
+                        if (MASK) {
+                            if (a.mask && r0 + key >= a.extra && key < ntot) v += a.mask[(long long)b * a.mask_ld + r0 + key - a.extra] * LOG2E;
+                        }
+                        const float pj = exp2_fast(v);
+                        float dpv = dp[r];
+                        if (DROP) {
+                            if (a.drop_p > 0.f) dpv *= drop_mult(a, (long long)p * a.q.n + q, r0 + key, h);
+                        }
+                        acc[r] = pj * (dpv - dl);
+                    }
+                    if (t * 16 + 16 > ntot) {                         // uniform: the partial tile zeroes its padding keys
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[r] = (t * 16 + fg * 4 + r < ntot) ? acc[r] : 0.f;
+                    }
                 }
                 pr[u] = acc;
             }
@@ -308,9 +346,11 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a,
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < NT / 2; ++kk) {
+            if (kk * 32 < ntot) {
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_t<NT>(sKt, dt * 16 + fr, kk, fg), dsf[kk], o[dt], 0, 0, 0);
+                for (int dt = 0; dt < 4; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_t<NT>(sKt, dt * 16 + fr, kk, fg), dsf[kk], o[dt], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (qv && a.nsplit > 1) {
@@ -331,9 +371,11 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a,
 // ------------------------------------------------------------------------------------------------
 // backward, key-owned: dK, dV.  own = keys (no extra), other = queries [extra CLS query ; row set], NT query tiles.
 // ------------------------------------------------------------------------------------------------
-template <int NT, int NW>
+template <int NT, int NW, int FL>
 __global__ __launch_bounds__(64 * NW) void attn_dkv_mfma_kernel(const AttnArgs a, int tiles_per_wg) {
     constexpr int VP = vt_pitch(NT);
+    constexpr bool MASK = (FL & 1) != 0, DROP = (FL & 2) != 0;
+    const float sc2 = a.scale * LOG2E;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sQt = smem;                       // [64][VP]  Q transposed
     unsigned char* sGt = sQt + 64 * VP;              // [64][VP]  dO transposed
@@ -364,7 +406,7 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_mfma_kernel(const AttnArgs a
         float l = INFINITY, d = 0.f;                 // padded query rows: exp(s - inf) = 0
         if (i < ntot) {
             const long long row = other_row(a, a.q, b, g, r0 + i);
-            l = a.lse[row * a.H + h];
+            l = a.lse[row * a.H + h] * LOG2E;          // log2 domain, like the scores
             d = a.delta[row * a.H + h];
         }
         sL[i] = l;
@@ -384,7 +426,9 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_mfma_kernel(const AttnArgs a
         const bf16x8_t v0 = ld_frag_global(V + krow * a.ldv + hv + fg * 8, kv);
         const bf16x8_t v1 = ld_frag_global(V + krow * a.ldv + hv + 32 + fg * 8, kv);
         float mk = 0.f;
-        if (a.mask && kv) mk = a.mask[(long long)b * a.mask_ld + key];
+        if (MASK) {
+            if (a.mask && kv) mk = a.mask[(long long)b * a.mask_ld + key] * LOG2E;
+        }
         bf16x8_t pf[NT / 2], df[NT / 2];
 #pragma unroll
         for (int kk = 0; kk < NT / 2; ++kk) {
@@ -393,18 +437,25 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_mfma_kernel(const AttnArgs a
             for (int u = 0; u < 2; ++u) {
                 const int t = 2 * kk + u;
                 f32x4_t acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sQt, t * 16, 0, fr, fg), k0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sQt, t * 16, 1, fr, fg), k1, acc, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sGt, t * 16, 0, fr, fg), v0, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sGt, t * 16, 1, fr, fg), v1, dp, 0, 0, 0);
-                const f32x4_t lse = *reinterpret_cast<const f32x4_t*>(sL + t * 16 + fg * 4);
-                const f32x4_t dl = *reinterpret_cast<const f32x4_t*>(sD + t * 16 + fg * 4);
+                if (t * 16 < ntot) {                                  // uniform: dead query tiles contribute nothing
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sQt, t * 16, 0, fr, fg), k0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sQt, t * 16, 1, fr, fg), k1, acc, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sGt, t * 16, 0, fr, fg), v0, dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sGt, t * 16, 1, fr, fg), v1, dp, 0, 0, 0);
+                    const f32x4_t lse = *reinterpret_cast<const f32x4_t*>(sL + t * 16 + fg * 4);
+                    const f32x4_t dl = *reinterpret_cast<const f32x4_t*>(sD + t * 16 + fg * 4);
+                    // columns of padding keys (kv false) hold finite garbage; they are never stored.  Padding query rows of
+                    // the partial tile have lse = +inf in sL, i.e. p = 0.
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pj = kv ? __expf(acc[r] * a.scale + mk - lse[r]) : 0.f;
-                    const float mu = a.drop_p > 0.f ? drop_mult(a, (long long)p * a.q.n + r0 + t * 16 + fg * 4 + r, key, h) : 1.0f;
-                    acc[r] = pj * mu;
-                    dp[r] = pj * (dp[r] * mu - dl[r]);
+                    for (int r = 0; r < 4; ++r) {
+                        const float pj = exp2_fast(acc[r] * sc2 + mk - lse[r]);
+                        float mu = 1.0f;
+                        if (DROP) {
+                            if (a.drop_p > 0.f) mu = drop_mult(a, (long long)p * a.q.n + r0 + t * 16 + fg * 4 + r, key, h);
+                        }
+                        acc[r] = DROP ? pj * mu : pj;
+                        dp[r] = pj * ((DROP ? dp[r] * mu : dp[r]) - dl[r]);
+                    }
                 }
                 pr[u] = acc;
                 dr[u] = dp;
@@ -418,10 +469,12 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_mfma_kernel(const AttnArgs a
         for (int dt = 0; dt < 4; ++dt) ov[dt] = ok[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < NT / 2; ++kk) {
+            if (kk * 32 < ntot) {
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                ov[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_t<NT>(sGt, dt * 16 + fr, kk, fg), pf[kk], ov[dt], 0, 0, 0);
-                ok[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_t<NT>(sQt, dt * 16 + fr, kk, fg), df[kk], ok[dt], 0, 0, 0);
+                for (int dt = 0; dt < 4; ++dt) {
+                    ov[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_t<NT>(sGt, dt * 16 + fr, kk, fg), pf[kk], ov[dt], 0, 0, 0);
+                    ok[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_t<NT>(sQt, dt * 16 + fr, kk, fg), df[kk], ok[dt], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -475,9 +528,15 @@ static inline void own_split(int n_own, int& nw, int& tpw, int& chunks) {
     do {                                                                                                     \
         const size_t lds = LDSFN<NTV>();                                                                     \
         dim3 grid(chunks, B * a.G, a.H);                                                                     \
-        if (nw == 4) { set_lds(KERNEL<NTV, 4>, lds); hipLaunchKernelGGL((KERNEL<NTV, 4>), grid, dim3(256), lds, st, a, tpw); } \
-        else if (nw == 2) { set_lds(KERNEL<NTV, 2>, lds); hipLaunchKernelGGL((KERNEL<NTV, 2>), grid, dim3(128), lds, st, a, tpw); } \
-        else { set_lds(KERNEL<NTV, 1>, lds); hipLaunchKernelGGL((KERNEL<NTV, 1>), grid, dim3(64), lds, st, a, tpw); } \
+        if (a.mask || a.drop_p > 0.f) {                                                                      \
+            if (nw == 4) { set_lds(KERNEL<NTV, 4, 3>, lds); hipLaunchKernelGGL((KERNEL<NTV, 4, 3>), grid, dim3(256), lds, st, a, tpw); } \
+            else if (nw == 2) { set_lds(KERNEL<NTV, 2, 3>, lds); hipLaunchKernelGGL((KERNEL<NTV, 2, 3>), grid, dim3(128), lds, st, a, tpw); } \
+            else { set_lds(KERNEL<NTV, 1, 3>, lds); hipLaunchKernelGGL((KERNEL<NTV, 1, 3>), grid, dim3(64), lds, st, a, tpw); } \
+        } else {                                                                                             \
+            if (nw == 4) { set_lds(KERNEL<NTV, 4, 0>, lds); hipLaunchKernelGGL((KERNEL<NTV, 4, 0>), grid, dim3(256), lds, st, a, tpw); } \
+            else if (nw == 2) { set_lds(KERNEL<NTV, 2, 0>, lds); hipLaunchKernelGGL((KERNEL<NTV, 2, 0>), grid, dim3(128), lds, st, a, tpw); } \
+            else { set_lds(KERNEL<NTV, 1, 0>, lds); hipLaunchKernelGGL((KERNEL<NTV, 1, 0>), grid, dim3(64), lds, st, a, tpw); } \
+        }                                                                                                    \
     } while (0)
 
 int egv_attn_fwd_mfma(const AttnArgs& a, int B, hipStream_t st) {

@@ -18,11 +18,12 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
 // round-to-nearest-even, NaN preserved (same rounding torch uses for float -> bfloat16)
-__device__ __forceinline__ unsigned short f2bf(float f) {
-    unsigned int u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+// (gfx950 has the conversion in hardware: v_cvt_pk_bf16_f32, one instruction per pair)
+typedef __attribute__((ext_vector_type(2))) float egv_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 egv_bf16x2_t;
+__device__ __forceinline__ unsigned short f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(egv_f32x2_t{lo, hi}, egv_bf16x2_t));
 }
 
 template <typename T> struct Elem;
@@ -53,8 +54,8 @@ __device__ __forceinline__ void st4(float* p, const float (&o)[4]) {
 }
 __device__ __forceinline__ void st4(bf16_t* p, const float (&o)[4]) {
     u32x2_t v;
-    v[0] = (unsigned int)f2bf(o[0]) | ((unsigned int)f2bf(o[1]) << 16);
-    v[1] = (unsigned int)f2bf(o[2]) | ((unsigned int)f2bf(o[3]) << 16);
+    v[0] = pack_bf16x2(o[0], o[1]);
+    v[1] = pack_bf16x2(o[2], o[3]);
     *reinterpret_cast<u32x2_t*>(p) = v;
 }
 

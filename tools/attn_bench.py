@@ -1,0 +1,34 @@
+"""Micro-benchmark of the divided space/time attention core on the hot-path shape (run on the GPU box)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from egovlpv2_amd import hipops as ops
+from egovlpv2_amd._lib import lib
+
+def timeit(fn, n=20):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+B, Fr, N, H = 8, 16, 196, 12
+S = 1 + Fr * N
+qkv = torch.randn(B * S, 3 * H * 64, device='cuda').bfloat16().requires_grad_(True)
+do = torch.randn(B * S, H * 64, device='cuda').bfloat16()
+for mode in ('space', 'time'):
+    for dbg in [int(x) for x in os.environ.get('DBG', '0').split(',')]:
+        try:
+            lib.egv_debug_attn(dbg)
+        except Exception:
+            pass
+        f = lambda: ops.divided_attention(qkv.detach(), B, Fr, N, H, mode)
+        t_f = timeit(f)
+        o = ops.divided_attention(qkv, B, Fr, N, H, mode)
+        def fb():
+            qkv.grad = None
+            o.backward(do, retain_graph=True)
+        t_b = timeit(fb)
+        print(f"{mode} dbg={dbg}: fwd {t_f:7.1f} us   bwd {t_b:7.1f} us", flush=True)
+lib.egv_debug_attn(0)
