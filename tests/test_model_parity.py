@@ -283,3 +283,32 @@ def test_train_mode_dropout_fp32():
                 p.add_(d, alpha=-sgn * eps)
     fd = (vals[0] - vals[1]) / (2 * eps)
     assert abs(fd - gn) < 2e-2 * gn, (fd, gn)
+
+
+def test_egomcq_validation_scores_vs_oracle_fp32():
+    """EgoMCQ scoring path of _valid_epoch (trainer_egoclip.py:216-246): 1 question x 5 candidate clips -> VTC cosine, VTM
+    match probability and their sum, against the oracle's dual and fused encoders.  1e-3 relative."""
+    from oracle import ref_model as O
+    from egovlpv2_amd.trainer.validate import egomcq_scores
+    from egovlpv2_amd.synthetic import make_batch
+    g, cfg, B, L, wseed, bseed = load_golden('tiny')
+    sd, _, _, _, oc = oracle_setup(cfg, B, L, wseed, bseed)
+    m = _build(cfg, sd, torch.float32).eval()
+    b1, b2 = 2, 5
+    clips, _, _ = make_batch(cfg, b1 * b2, L, 77)
+    qs, _, _ = make_batch(cfg, b1, L, 78)
+    video = clips['video'].reshape(b1, b2, *clips['video'].shape[1:])
+    data = {'video': video.cuda(), 'text': {k: v.cuda() for k, v in qs['text'].items()}}
+    got = egomcq_scores(m, data)
+    with torch.no_grad():
+        te = O.compute_text(sd, qs['text'], oc).reshape(b1, 1, -1)
+        ve = O.compute_video(sd, clips['video'], oc).reshape(b1, b2, -1)
+        vtc = (torch.nn.functional.normalize(te, dim=-1) @ torch.nn.functional.normalize(ve, dim=-1).transpose(1, 2)).squeeze(1)
+        ids = torch.repeat_interleave(qs['text']['input_ids'], b2, dim=0)
+        am = torch.repeat_interleave(qs['text']['attention_mask'], b2, dim=0)
+        lg = O.itm_logits(sd, clips['video'], ids, am, oc)
+        vtm = torch.softmax(lg, dim=1)[:, 1].reshape(b1, b2)
+    assert rel_err(got['vtc'], vtc) < 1e-3
+    assert rel_err(got['vtm'], vtm) < 1e-3
+    assert rel_err(got['ensemble'], vtc + vtm) < 1e-3
+    assert torch.equal(got['ensemble'].argmax(1).cpu(), (vtc + vtm).argmax(1))

@@ -73,3 +73,44 @@ def test_fused_adamw_matches_oracle():
     for n, p in m.named_parameters():
         err = (p.detach().double().cpu() - ref[n]).abs().max().item()
         assert err < 2e-6, (n, err)
+
+
+@pytest.mark.gpu
+def test_checkpoint_resume_continues_fused_adamw(tmp_path):
+    """base_trainer.py:412-495 format with the HIP optimiser: save after 2 steps, resume into a fresh model/optimiser,
+    one more step on both -> identical parameters (state keys 'step'/'exp_avg'/'exp_avg_sq' as in HF AdamW)."""
+    from egovlpv2_amd.set_optim_schedule import set_schedule
+    from egovlpv2_amd.utils.checkpoint import save_checkpoint, resume_checkpoint
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(16, 8)
+            self.norm = torch.nn.LayerNorm(8)
+            self.itm_score = torch.nn.Linear(8, 2)
+    ocfg = {"optimizer": {"type": "AdamW", "args": {"lr": 3e-3, "weight_decay": 0.01, "lr_mult_head": 4, "lr_mult_cross_modal": 4}}}
+    ycfg = {"decay_power": "cosine", "end_lr": 1e-7}
+
+    def grads(m, step):
+        gen = torch.Generator().manual_seed(step)
+        for p in m.parameters():
+            p.grad = torch.randn(p.shape, generator=gen).cuda()
+    torch.manual_seed(0)
+    m1 = Tiny().cuda()
+    o1, s1 = set_schedule(m1, ocfg, ycfg, 20, 3)
+    for step in (1, 2):
+        grads(m1, step); o1.step(); s1.step()
+    path = str(tmp_path / 'ck.pth')
+    save_checkpoint(path, m1, o1, s1, epoch=3, monitor_best=1.5, config=ocfg)
+    ck = torch.load(path, map_location='cpu', weights_only=False)
+    st0 = next(iter(ck['optimizer']['state'].values()))
+    assert set(st0.keys()) == {'step', 'exp_avg', 'exp_avg_sq'}
+    m2 = Tiny().cuda()
+    o2, s2 = set_schedule(m2, ocfg, ycfg, 20, 3)
+    start, best = resume_checkpoint(path, m2, o2, s2, config=ocfg, map_location='cuda')
+    assert (start, best) == (4, 1.5)
+    for m, o, s in ((m1, o1, s1), (m2, o2, s2)):
+        grads(m, 3); o.step(); s.step()
+    torch.cuda.synchronize()
+    for a, b in zip(m1.parameters(), m2.parameters()):
+        assert torch.equal(a, b)

@@ -1,2 +1,1 @@
-python -m pytest tests/test_model_parity.py -m gpu -x -q 2>&1 | grep -v Warn | tail -3
-for i in 1 2; do timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d['roofline']['achieved'], {k[:18]:v['tflops'] for k,v in d['roofline']['all_gemm'].items() if v['ms_per_step']>5})"; done
+python -m pytest tests/test_optimizer.py tests/test_model_parity.py -m gpu -x -q -k "checkpoint or egomcq" 2>&1 | grep -v Warn | tail -8
