@@ -304,7 +304,9 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a,
         const float lse2 = qv ? a.lse[qrow * a.H + h] * LOG2E : 0.f;
         if (qv && fg == 0 && split == 0) a.delta[qrow * a.H + h] = dl;
 
-        bf16x8_t dsf[NT / 2];
+        f32x4_t o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < NT / 2; ++kk) {
             f32x4_t pr[2];
@@ -338,18 +340,11 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a,
                 }
                 pr[u] = acc;
             }
-            dsf[kk] = pack8(pr[0], pr[1]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        f32x4_t o[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < NT / 2; ++kk) {
-            if (kk * 32 < ntot) {
+            if (kk * 32 < ntot) {                                     // dQ^T += K^T dS^T for this pair of key tiles
+                const bf16x8_t dsf = pack8(pr[0], pr[1]);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_t<NT>(sKt, dt * 16 + fr, kk, fg), dsf[kk], o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_t<NT>(sKt, dt * 16 + fr, kk, fg), dsf, o[dt], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -429,7 +424,9 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_mfma_kernel(const AttnArgs a
         if (MASK) {
             if (a.mask && kv) mk = a.mask[(long long)b * a.mask_ld + key] * LOG2E;
         }
-        bf16x8_t pf[NT / 2], df[NT / 2];
+        f32x4_t ov[4], ok[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) ov[dt] = ok[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < NT / 2; ++kk) {
             f32x4_t pr[2], dr[2];
@@ -460,20 +457,13 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_mfma_kernel(const AttnArgs a
                 pr[u] = acc;
                 dr[u] = dp;
             }
-            pf[kk] = pack8(pr[0], pr[1]);
-            df[kk] = pack8(dr[0], dr[1]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        f32x4_t ov[4], ok[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) ov[dt] = ok[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < NT / 2; ++kk) {
-            if (kk * 32 < ntot) {
+            if (kk * 32 < ntot) {                                     // dV^T += dO^T P, dK^T += Q^T dS for this pair of query tiles
+                const bf16x8_t pf = pack8(pr[0], pr[1]);
+                const bf16x8_t df = pack8(dr[0], dr[1]);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    ov[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_t<NT>(sGt, dt * 16 + fr, kk, fg), pf[kk], ov[dt], 0, 0, 0);
-                    ok[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_t<NT>(sQt, dt * 16 + fr, kk, fg), df[kk], ok[dt], 0, 0, 0);
+                    ov[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_t<NT>(sGt, dt * 16 + fr, kk, fg), pf, ov[dt], 0, 0, 0);
+                    ok[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_t<NT>(sQt, dt * 16 + fr, kk, fg), df, ok[dt], 0, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);

@@ -459,7 +459,7 @@ def _split_ws(which, B, G, H, n_own, nsplit, device):
 
 def _nsplit_for(n_other):
     """split count for launches whose other side is too long for one workgroup / the MFMA kernels (<= 224 rows)"""
-    return 1 if n_other <= 224 else max(2, min(32, n_other // 96))
+    return 1 if n_other <= 224 else max(2, min(32, n_other // 384))     # 8 splits at S = 3137: the combine pass stays short
 
 
 class DividedAttnFn(Function):
