@@ -439,3 +439,82 @@ def test_linear_large_tiles_bf16(ops, shape):
     assert _rel(x.grad, x64.grad) < _tol(dtype, True)
     assert _rel(w.grad, w64.grad) < _tol(dtype, True)
     assert _rel(b.grad, b64.grad) < _tol(dtype, True)
+
+
+# ---- BASELINE.json full sizes (B=8, 16 x 224^2: M = 8 * 3137 = 25096 token rows), checked on samples ------------------------
+FULL_M = 8 * (1 + 16 * 196)
+
+
+@pytest.mark.parametrize('N,K,epi', [(2304, 768, 'bias'), (768, 768, 'res'), (3072, 768, 'gelu'), (768, 3072, 'res')])
+def test_full_size_linear_sampled_rows_bf16(ops, N, K, epi):
+    """The four hot Linear shapes at the full token count: forward, input gradient and weight gradient.  Rows are sampled
+    (first / last rows of 256-row tiles, the ragged last tile of 8 rows, random ones) and compared with fp64 math on the same
+    bf16 inputs; sampled weight-gradient entries (each a reduction over all rows) and the bias gradient against fp64."""
+    M = FULL_M
+    x = _rnd((M, K), torch.bfloat16, 1.0, 1).cuda().requires_grad_(True)
+    w = _rnd((N, K), torch.float32, 0.05, 2).cuda().requires_grad_(True)
+    b = _rnd((N,), torch.float32, 0.5, 3).cuda().requires_grad_(True)
+    res = _rnd((M, N), torch.bfloat16, 1.0, 4).cuda() if epi == 'res' else None
+    y = ops.linear(x, w, b, act='gelu' if epi == 'gelu' else 'none', res1=res)
+    rows = torch.tensor(sorted({0, 1, 255, 256, 4095, 12543, 12544, M - 9, M - 8, M - 1} |
+                               set(torch.randint(0, M, (40,), generator=torch.Generator().manual_seed(5)).tolist())))
+    xs = x.detach()[rows.cuda()].double().cpu()
+    w64 = w.detach().to(torch.bfloat16).double().cpu()
+    z = xs @ w64.t() + b.detach().double().cpu()
+    ref = gelu64(z) if epi == 'gelu' else z
+    if res is not None:
+        ref = ref + res[rows.cuda()].double().cpu()
+    assert _rel(y.detach()[rows.cuda()], ref) < 6e-3
+    dy = _rnd((M, N), torch.bfloat16, 1.0, 6).cuda()
+    y.backward(dy)
+    dys = dy[rows.cuda()].double().cpu()
+    dz = dys * (0.5 * (1 + torch.erf(z / math.sqrt(2))) + z * torch.exp(-0.5 * z * z) / math.sqrt(2 * math.pi)) if epi == 'gelu' else dys
+    if epi == 'gelu':                       # the kernel rounds dz to bf16 before the two backward GEMMs
+        dz = dz.to(torch.bfloat16).double()
+    assert _rel(x.grad[rows.cuda()], dz @ w64) < 2e-2
+    # weight gradient on sampled entries (each one reduces over all 25096 rows) and the whole bias gradient, fp64 reference
+    if epi != 'gelu':
+        g = torch.Generator().manual_seed(7)
+        ns = torch.cat([torch.tensor([0, N - 1, 127, 128]), torch.randint(0, N, (60,), generator=g)])
+        ks = torch.cat([torch.tensor([0, K - 1, 31, 32]), torch.randint(0, K, (60,), generator=g)])
+        want = (dy[:, ns.cuda()].double() * x.detach()[:, ks.cuda()].double()).sum(0).cpu()
+        got = w.grad[ns.cuda(), ks.cuda()].double().cpu()
+        assert _rel(got, want) < 1e-4
+        assert _rel(b.grad, dy.double().sum(0)) < 1e-4
+
+
+def test_full_size_divided_attention_sampled_problems_bf16(ops):
+    """Space and time attention at B=8, 16 frames, 196 patches, 12 heads: sampled (sample, frame/patch, head) problems against
+    fp64 softmax attention on the same bf16 qkv, plus the frame-permutation equivariance of space attention (patch rows of a
+    frame only see that frame and the CLS row, so permuting whole frames permutes the patch outputs)."""
+    B, Fr, N, H = 8, 16, 196, 12
+    S, D = 1 + Fr * N, H * 64
+    qkv = _rnd((B * S, 3 * D), torch.bfloat16, 1.0, 1).cuda()
+    q64 = qkv.double().cpu().reshape(B, S, 3, H, 64)
+    gen = torch.Generator().manual_seed(2)
+    for mode in ('space', 'time'):
+        o = ops.divided_attention(qkv, B, Fr, N, H, mode).double().cpu().reshape(B, S, H, 64)
+        for _ in range(6):
+            b, h = int(torch.randint(0, B, (1,), generator=gen)), int(torch.randint(0, H, (1,), generator=gen))
+            if mode == 'space':
+                f = int(torch.randint(0, Fr, (1,), generator=gen))
+                rows = torch.arange(1 + f * N, 1 + (f + 1) * N)
+            else:
+                n = int(torch.randint(0, N, (1,), generator=gen))
+                rows = 1 + n + N * torch.arange(Fr)
+            keys = torch.cat([torch.zeros(1, dtype=torch.long), rows])
+            q, k, v = q64[b, rows, 0, h], q64[b, keys, 1, h], q64[b, keys, 2, h]
+            ref = torch.softmax(q @ k.t() * 0.125, -1) @ v
+            assert _rel(o[b, rows, h], ref) < 6e-3, (mode, b, h)
+        b, h = 3, 7                                            # the CLS query sees all S keys
+        ref = torch.softmax(q64[b, :1, 0, h] @ q64[b, :, 1, h].t() * 0.125, -1) @ q64[b, :, 2, h]
+        assert _rel(o[b, :1, h], ref) < 6e-3
+    # equivariance: swap frames 2 and 9 of every sample
+    perm = torch.arange(S)
+    a, c = torch.arange(1 + 2 * N, 1 + 3 * N), torch.arange(1 + 9 * N, 1 + 10 * N)
+    perm[a], perm[c] = c, a
+    qp = qkv.reshape(B, S, 3 * D)[:, perm.cuda()].reshape(B * S, 3 * D).contiguous()
+    o1 = ops.divided_attention(qkv, B, Fr, N, H, 'space').reshape(B, S, D)
+    o2 = ops.divided_attention(qp, B, Fr, N, H, 'space').reshape(B, S, D)
+    assert torch.equal(o2[:, 1:], o1[:, perm.cuda()][:, 1:]), "patch rows: bitwise equal under a frame permutation"
+    assert _rel(o2[:, 0], o1[:, 0]) < 6e-3                     # CLS row: same value, different summation order
