@@ -60,8 +60,55 @@ __global__ __launch_bounds__(256) void adamw_kernel(const OptChunk* __restrict__
     }
 }
 
+// ---- multi-tensor weight preparation: bf16 W and W^T copies of many fp32 [R, C] weights in one launch -----------------
+struct CastRec {          // 32 bytes, one per tensor; R and C are multiples of 64
+    const float* src;
+    bf16_t* dst;          // [R, C] bf16
+    bf16_t* dst_t;        // [C, R] bf16
+    int R, C;
+};
+
+__global__ __launch_bounds__(256) void cast_weights_kernel(const CastRec* __restrict__ table, const int* __restrict__ prefix, int ntensors) {
+    __shared__ float tile[64][65];
+    const int c = blockIdx.x;
+    int lo = 0, hi = ntensors;                       // largest t with prefix[t] <= c
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= c) lo = mid; else hi = mid;
+    }
+    const CastRec rec = table[lo];
+    const int t = c - prefix[lo], tiles_c = rec.C >> 6;
+    const int r0 = (t / tiles_c) << 6, c0 = (t % tiles_c) << 6;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;          // 16 lanes x 4 floats per 64-wide row, 16 rows per pass
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = ty + i * 16;
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(rec.src + (size_t)(r0 + r) * rec.C + c0 + tx * 4);
+        u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *reinterpret_cast<u32x2_t*>(rec.dst + (size_t)(r0 + r) * rec.C + c0 + tx * 4) = o;
+        tile[r][tx * 4 + 0] = v[0]; tile[r][tx * 4 + 1] = v[1]; tile[r][tx * 4 + 2] = v[2]; tile[r][tx * 4 + 3] = v[3];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cc = ty + i * 16;                                  // column of the source tile = row of the transposed copy
+        u32x2_t o = {pack_bf16x2(tile[tx * 4 + 0][cc], tile[tx * 4 + 1][cc]), pack_bf16x2(tile[tx * 4 + 2][cc], tile[tx * 4 + 3][cc])};
+        *reinterpret_cast<u32x2_t*>(rec.dst_t + (size_t)(c0 + cc) * rec.R + r0 + tx * 4) = o;
+    }
+}
+
 }  // namespace egv
 using namespace egv;
+
+// table: device array of {const float* src; bf16* dst; bf16* dst_t; int R; int C} (32 bytes per tensor, R % 64 == C % 64 == 0,
+// pointers 16-byte aligned); prefix: device int32[ntensors + 1], prefix[t] = number of 64x64 tiles before tensor t.
+extern "C" int egv_cast_weights(const void* table, const int* prefix, int ntensors, int ntiles, void* stream) {
+    EGV_CHECK(table && prefix && ntensors > 0 && ntiles > 0, "egv_cast_weights: empty table");
+    hipLaunchKernelGGL(cast_weights_kernel, dim3(ntiles), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const CastRec*)table,
+                       prefix, ntensors);
+    EGV_LAUNCH_CHECK();
+    return 0;
+}
 
 // table: device array of {float* p; const float* g; float* m; float* v; int n; int pad} (32 bytes, one per tensor, pointers
 // 16-byte aligned); prefix: device int32[ntensors + 1], prefix[t] = number of 16384-element chunks before tensor t.

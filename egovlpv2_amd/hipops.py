@@ -114,6 +114,50 @@ def compute_weight_t(w: torch.Tensor, dtype: torch.dtype):
     return out
 
 
+_wprep = {}
+
+
+def prepare_weights(weights, dtype: torch.dtype):
+    """One launch that makes the bf16 W and W^T compute copies of every listed fp32 [R, C] weight (R, C multiples of 64) and
+    seeds the two caches above, so that the forward/backward of the step finds them ready.  Weights that do not qualify are
+    left to the lazy per-tensor path.  A no-op when the copies of the current parameter versions already exist."""
+    if dtype != torch.bfloat16:
+        return
+    ws = [w for w in weights if w.dim() == 2 and w.dtype == torch.float32 and w.is_contiguous() and w.is_cuda
+          and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0]
+    if not ws:
+        return
+    e0 = _wcache.get(id(ws[0]))
+    if e0 is not None and e0[0] == ws[0]._version and e0[2] is ws[0] and all(
+            (c := _wcache.get(id(w))) is not None and c[0] == w._version and c[2] is w for w in ws):
+        return
+    import numpy as np
+    key = tuple(id(w) for w in ws)
+    ent = _wprep.get(key)
+    ptrs = [w.data_ptr() for w in ws]
+    if ent is None or ent['ptrs'] != ptrs:
+        outs = [(torch.empty(w.shape, dtype=dtype, device=w.device), torch.empty(w.shape[1], w.shape[0], dtype=dtype, device=w.device))
+                for w in ws]
+        arr = np.zeros(len(ws), dtype=[('s', '<u8'), ('d', '<u8'), ('t', '<u8'), ('R', '<i4'), ('C', '<i4')])
+        arr['s'] = ptrs
+        arr['d'] = [o[0].data_ptr() for o in outs]
+        arr['t'] = [o[1].data_ptr() for o in outs]
+        arr['R'] = [w.shape[0] for w in ws]
+        arr['C'] = [w.shape[1] for w in ws]
+        prefix = np.zeros(len(ws) + 1, dtype=np.int32)
+        prefix[1:] = np.cumsum([(w.shape[0] // 64) * (w.shape[1] // 64) for w in ws])
+        dev = ws[0].device
+        pin = torch.from_numpy(arr.view(np.uint8).copy()).pin_memory()
+        pre = torch.from_numpy(prefix).pin_memory()
+        ent = _wprep[key] = {'ptrs': ptrs, 'outs': outs, 'table': pin.to(dev, non_blocking=True), 'prefix': pre.to(dev, non_blocking=True),
+                             'ntiles': int(prefix[-1]), 'pins': (pin, pre), 'refs': ws}
+    check(lib.egv_cast_weights(_p(ent['table']), _p(ent['prefix']), len(ws), ent['ntiles'], _st()), 'egv_cast_weights')
+    ev, st = _cast_event(), _st()
+    for w, (o, ot) in zip(ws, ent['outs']):
+        _wcache[id(w)] = (w._version, o, w, st, ev)
+        _wtcache[id(w)] = (w._version, ot, w, st, ev)
+
+
 def dgrad(dz, weight, dx, M, N, K, gate=None, aux=None, dact=0):
     """dx[M,K] = gate * (dz[M,N] @ W[N,K]) * act'(aux): NT form on the transposed bf16 copy when available, else the
     generic kernel reading W as a [reduction, out] operand."""

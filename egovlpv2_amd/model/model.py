@@ -213,6 +213,17 @@ class FrozenInTime(nn.Module):
                     t.record_stream(torch.cuda.current_stream())
         return out, join
 
+    def _prepare_weights(self):
+        """bf16 mode: one launch per step makes the W / W^T compute copies of every Linear weight (hipops.prepare_weights);
+        embeddings, 1-D tensors and shapes that are not multiples of 64 keep the lazy per-tensor path."""
+        if self.compute_dtype != torch.bfloat16:
+            return
+        lst = self.__dict__.get('_gemm_weights')
+        if lst is None:
+            lst = self.__dict__['_gemm_weights'] = [p for n, p in self.named_parameters()
+                                                    if p.dim() == 2 and n.endswith('.weight') and 'embeddings' not in n]
+        ops.prepare_weights(lst, self.compute_dtype)
+
     def p(self, name: str) -> torch.Tensor:
         if self._P is None:
             self._P = dict(self.named_parameters())
@@ -432,6 +443,7 @@ class FrozenInTime(nn.Module):
     def infer(self, data, video_only=False, return_embeds=True, task_names=None, ret=None):
         """model.py:189-367.  (The reference's mutable default ``ret={}`` is replaced by a fresh dict.)"""
         ret = {} if ret is None else ret
+        self._prepare_weights()
         text_data, video_data = data['text'], data['video']
         if task_names is not None:
             self.task_names = task_names

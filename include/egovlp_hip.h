@@ -153,6 +153,11 @@ int egv_egonce_fwd(const float* x, const float* sim_v, const float* sim_n, int n
 int egv_egonce_bwd(const float* x, const float* sim_v, const float* sim_n, const float* stats, const float* gout, float* dx,
                    int n, float temperature, int noun, int verb, void* stream);
 
+/* bf16 W [R,C] and W^T [C,R] compute copies of many fp32 master weights in ONE launch (the per-step weight preparation of
+   the bf16 mode; replaces ~400 per-tensor cast launches).  table: device array of 32-byte records
+   {const float* src; void* dst; void* dst_t; int R; int C} with R % 64 == C % 64 == 0; prefix: device int32[ntensors + 1],
+   prefix[t] = number of 64x64 tiles before tensor t; ntiles = prefix[ntensors]. */
+int egv_cast_weights(const void* table, const int* prefix, int ntensors, int ntiles, void* stream);
 /* ---- fused multi-tensor AdamW (set_optim_schedule.py:108 -> transformers 4.30 AdamW: eps on sqrt(v) without bias
  * correction of the denominator, step_size = lr*sqrt(1-b2^t)/(1-b1^t), weight decay p -= lr*wd*p AFTER the update).
  * table: device array of 32-byte records {float* p; const float* g; float* m; float* v; int n; int pad}, one per tensor;

@@ -518,3 +518,24 @@ def test_full_size_divided_attention_sampled_problems_bf16(ops):
     o2 = ops.divided_attention(qp, B, Fr, N, H, 'space').reshape(B, S, D)
     assert torch.equal(o2[:, 1:], o1[:, perm.cuda()][:, 1:]), "patch rows: bitwise equal under a frame permutation"
     assert _rel(o2[:, 0], o1[:, 0]) < 6e-3                     # CLS row: same value, different summation order
+
+
+def test_prepare_weights_matches_per_tensor_casts(ops):
+    """egv_cast_weights (one launch for all Linear weights of a step) must produce exactly the copies the lazy per-tensor
+    path makes, and seed both caches; non-qualifying tensors are left alone."""
+    shapes = [(768, 768), (2304, 768), (768, 3072), (4096, 768), (64, 64), (130, 768)]
+    ws = [_rnd(s, torch.float32, 0.3, i).cuda() for i, s in enumerate(shapes)]
+    ops.invalidate_weight_cache()
+    lazy = [(ops.compute_weight(w, torch.bfloat16).clone(), ops.compute_weight_t(w, torch.bfloat16)) for w in ws]
+    lazy = [(a, None if t is None else t.clone()) for a, t in lazy]
+    ops.invalidate_weight_cache()
+    ops.prepare_weights(ws, torch.bfloat16)
+    for w, (a, t), s in zip(ws, lazy, shapes):
+        assert torch.equal(ops.compute_weight(w, torch.bfloat16), a), s
+        if t is not None:
+            assert torch.equal(ops.compute_weight_t(w, torch.bfloat16), t), s
+    assert torch.equal(lazy[0][0], ws[0].to(torch.bfloat16))
+    ws[1].add_(1.0)                                            # a new parameter version must be re-cast
+    ops.prepare_weights(ws, torch.bfloat16)
+    assert torch.equal(ops.compute_weight(ws[1], torch.bfloat16), ws[1].to(torch.bfloat16))
+    assert torch.equal(ops.compute_weight_t(ws[1], torch.bfloat16), ws[1].to(torch.bfloat16).t().contiguous())
