@@ -63,6 +63,7 @@ PROTOTYPES = {
     'egv_attn_bwd_dkv_workspace_bytes': (i64, [i32, i32, i32, i32, i32]),
     'egv_attn_bwd_dkv': (i32, [i32, C.POINTER(AttnDesc), vp]),
     'egv_im2col': (i32, [i32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    'egv_im2col_u8': (i32, [i32, vp, vp, i32, i32, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), vp]),
     'egv_assemble_tokens': (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     'egv_assemble_tokens_bwd_workspace_bytes': (i64, [i32, i32, i32]),
     'egv_assemble_tokens_bwd': (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),

@@ -29,6 +29,33 @@ __global__ void im2col_kernel(const float* __restrict__ video, T* __restrict__ o
     }
 }
 
+// The same patch rows from uint8 clips: (x / 255 - mean[c]) / std[c] applied while patchifying, i.e. the ToTensor +
+// Normalize of the reference's input transform (data_loader/transforms.py:17-19) moved onto the device -- the host then
+// ships 1 byte per pixel instead of 4.  One thread moves 4 consecutive pixels (4-byte read).
+template <typename T>
+__global__ void im2col_u8_kernel(const unsigned char* __restrict__ video, T* __restrict__ out, int BF, int C, int H, int W, int P,
+                                 float m0, float m1, float m2, float s0, float s1, float s2) {
+    const int gw = W / P, gh = H / P;
+    const int rowlen = C * P * P;
+    const long long total = (long long)BF * C * H * (W / 4);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x4 = (int)(i % (W / 4));
+        long long r = i / (W / 4);
+        const int y = (int)(r % H); r /= H;
+        const int c = (int)(r % C);
+        const int bf = (int)(r / C);
+        const int x = x4 * 4;
+        const unsigned int px4 = *reinterpret_cast<const unsigned int*>(video + (((long long)bf * C + c) * H + y) * W + x);
+        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), inv = 1.0f / (c == 0 ? s0 : (c == 1 ? s1 : s2));
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ((float)((px4 >> (8 * e)) & 0xffu) * (1.0f / 255.0f) - mean) * inv;
+        const int py = y / P, ph = y % P, px = x / P, pw = x % P;
+        const long long orow = ((long long)bf * gh + py) * gw + px;
+        st4(out + orow * rowlen + (c * P + ph) * P + pw, v);
+    }
+}
+
 // K1 (post): tokens[b, 0] = cls + pos[0];  tokens[b, 1 + f*N + n] = patch[(b*F + f)*N + n] + pos[1 + n] + temporal[f]
 // (video_transformer.py:360-371 / model.py:217-231).  One wave per output row.
 template <typename T>
@@ -380,6 +407,23 @@ extern "C" int egv_im2col(int dtype, const float* video, void* out, int BF, int 
     if (blocks > 8192) blocks = 8192;
     if (dtype == EGV_BF16) hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(blocks), dim3(256), 0, EGV_ST, video, (bf16_t*)out, BF, C, H, W, P);
     else hipLaunchKernelGGL(im2col_kernel<float>, dim3(blocks), dim3(256), 0, EGV_ST, video, (float*)out, BF, C, H, W, P);
+    EGV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int egv_im2col_u8(int dtype, const unsigned char* video, void* out, int BF, int C, int H, int W, int P, const float* mean3,
+                             const float* std3, void* stream) {
+    EGV_CHECK(C == 3 && W % 4 == 0 && P % 4 == 0 && H % P == 0 && W % P == 0, "egv_im2col_u8: unsupported geometry C=%d H=%d W=%d P=%d", C, H, W, P);
+    EGV_CHECK(mean3 && std3 && std3[0] > 0.f && std3[1] > 0.f && std3[2] > 0.f, "egv_im2col_u8: mean/std (host float[3]) required");
+    const long long total = (long long)BF * C * H * (W / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    if (dtype == EGV_BF16)
+        hipLaunchKernelGGL(im2col_u8_kernel<bf16_t>, dim3(blocks), dim3(256), 0, EGV_ST, video, (bf16_t*)out, BF, C, H, W, P, mean3[0], mean3[1],
+                           mean3[2], std3[0], std3[1], std3[2]);
+    else
+        hipLaunchKernelGGL(im2col_u8_kernel<float>, dim3(blocks), dim3(256), 0, EGV_ST, video, (float*)out, BF, C, H, W, P, mean3[0], mean3[1],
+                           mean3[2], std3[0], std3[1], std3[2]);
     EGV_LAUNCH_CHECK();
     return 0;
 }

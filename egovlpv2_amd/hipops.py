@@ -667,6 +667,9 @@ def dropout_add(x, p, seed, r1=None, r2=None):
 
 
 # ---- patch embedding + CLS + positional / temporal embedding ------------------------------------------------
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)     # data_loader/transforms.py:17-18 defaults
+
+
 class PatchTokensFn(Function):
     """video (B,F,3,H,W) fp32 -> tokens (B, 1+F*N, D): Conv2d(k=s=P) as im2col + MFMA GEMM (+bias), then CLS concat
     and pos/temporal embedding (video_transformer.py:78-83,356-371)."""
@@ -679,10 +682,16 @@ class PatchTokensFn(Function):
         P = conv_w.shape[-1]
         N = (Hh // P) * (Ww // P)
         Kp = Cc * P * P
-        video = video.contiguous().float()
         dt = L.EGV_BF16 if dtype == torch.bfloat16 else L.EGV_F32
         patches = torch.empty(B * Fr * N, Kp, dtype=dtype, device=video.device)
-        check(lib.egv_im2col(dt, _p(video), _p(patches), B * Fr, Cc, Hh, Ww, P, _st()), 'egv_im2col')
+        if video.dtype == torch.uint8:
+            # raw clips: ToTensor + Normalize (data_loader/transforms.py:17-19) happen inside the patchify kernel
+            video = video.contiguous()
+            mean, std = (C.c_float * 3)(*IMAGENET_MEAN), (C.c_float * 3)(*IMAGENET_STD)
+            check(lib.egv_im2col_u8(dt, _p(video), _p(patches), B * Fr, Cc, Hh, Ww, P, mean, std, _st()), 'egv_im2col_u8')
+        else:
+            video = video.contiguous().float()
+            check(lib.egv_im2col(dt, _p(video), _p(patches), B * Fr, Cc, Hh, Ww, P, _st()), 'egv_im2col')
         w = compute_weight(conv_w, dtype).reshape(D, Kp)
         emb = torch.empty(B * Fr * N, D, dtype=dtype, device=video.device)
         gemm(patches, w, emb, M=B * Fr * N, N=D, K=Kp, lda=Kp, ldb=Kp, ldc=D, bias=conv_b)

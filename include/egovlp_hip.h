@@ -126,6 +126,10 @@ int egv_attn_bwd_dkv(int dtype, const egv_attn_desc* d, void* stream);
 
 /* ---- patch embedding pre/post (video_transformer.py:78-83,356-371; model.py:212-231,296-317) ---- */
 int egv_im2col(int dtype, const float* video, void* out, int BF, int C, int H, int W, int P, void* stream);
+/* The same patch matrix from uint8 clips [BF][3][H][W]: (x/255 - mean[c]) / std[c] while patchifying = ToTensor + Normalize of
+   the reference's input transform (data_loader/transforms.py:17-19) on the device.  mean3 / std3: HOST float[3]. */
+int egv_im2col_u8(int dtype, const unsigned char* video, void* out, int BF, int C, int H, int W, int P, const float* mean3,
+                  const float* std3, void* stream);
 int egv_assemble_tokens(int dtype, const void* patch, const float* cls, const float* pos, const float* temporal,
                         void* out, int B, int F, int N, int D, void* stream);
 long long egv_assemble_tokens_bwd_workspace_bytes(int F, int N, int D);

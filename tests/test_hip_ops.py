@@ -539,3 +539,24 @@ def test_prepare_weights_matches_per_tensor_casts(ops):
     ops.prepare_weights(ws, torch.bfloat16)
     assert torch.equal(ops.compute_weight(ws[1], torch.bfloat16), ws[1].to(torch.bfloat16))
     assert torch.equal(ops.compute_weight_t(ws[1], torch.bfloat16), ws[1].to(torch.bfloat16).t().contiguous())
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_patch_tokens_from_uint8_clips(ops, dtype):
+    """uint8 clips through egv_im2col_u8 == the reference's host-side ToTensor + Normalize (data_loader/transforms.py:17-19)
+    followed by the float path."""
+    B, Fr, H, P, D = 2, 3, 32, 16, 64
+    g = torch.Generator().manual_seed(1)
+    u8 = torch.randint(0, 256, (B, Fr, 3, H, H), generator=g, dtype=torch.uint8)
+    mean = torch.tensor(ops.IMAGENET_MEAN).view(1, 1, 3, 1, 1)
+    std = torch.tensor(ops.IMAGENET_STD).view(1, 1, 3, 1, 1)
+    ref_in = (u8.float() / 255.0 - mean) / std
+    N = (H // P) ** 2
+    w = _rnd((D, 3, P, P), torch.float32, 0.05, 2).cuda()
+    b = _rnd((D,), torch.float32, 0.1, 3).cuda()
+    cls = _rnd((1, 1, D), torch.float32, 1.0, 4).cuda()
+    pos = _rnd((1, 1 + N, D), torch.float32, 1.0, 5).cuda()
+    tem = _rnd((1, Fr, D), torch.float32, 1.0, 6).cuda()
+    a = ops.patch_tokens(u8.cuda(), w, b, cls, pos, tem, dtype)
+    r = ops.patch_tokens(ref_in.cuda(), w, b, cls, pos, tem, dtype)
+    assert _rel(a, r) < (1e-6 if dtype == torch.float32 else 4e-3)
