@@ -465,6 +465,44 @@ def layernorm(x, gamma, beta, eps):
     return LayerNormFn.apply(x, gamma, beta, eps)
 
 
+class LayerNormSkipFn(Function):
+    """(LayerNorm(x), x) for the pre-norm residual pattern  out = x + f(LayerNorm(x)):  the second output is x itself, to
+    be used for the skip connection.  Both gradients then arrive at this one node and the LayerNorm backward kernel adds the
+    skip gradient while it writes dx -- instead of autograd launching a separate full-size add."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _need_gpu(x)
+        assert x.dim() == 2 and x.is_contiguous()
+        M, D = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+        check(lib.egv_layernorm_fwd(_dt(x), _p(x), _p(y), _p(gamma), _p(beta), _p(stats), M, D, float(eps), _st()),
+              'egv_layernorm_fwd')
+        ctx.save_for_backward(x, gamma, stats)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        x2, gamma, stats = ctx.saved_tensors
+        M, D = x2.shape
+        if dy is None:                                   # only the skip path was used
+            return dskip, None, None, None
+        dy2 = dy.contiguous()
+        add = None if dskip is None else dskip.contiguous()
+        dx = torch.empty_like(x2)
+        gb = torch.empty(2, D, dtype=torch.float32, device=x2.device)
+        dg, db = gb[0], gb[1]
+        ws = workspace(lib.egv_layernorm_bwd_workspace_bytes(M, D), x2.device)
+        check(lib.egv_layernorm_bwd(_dt(x2), _p(dy2), _p(x2), _p(stats), _p(gamma), _p(add), _p(dx), _p(dg), _p(db), M, D,
+                                    _p(ws), _st()), 'egv_layernorm_bwd')
+        return dx, dg, db, None
+
+
+def layernorm_skip(x, gamma, beta, eps):
+    return LayerNormSkipFn.apply(x, gamma, beta, eps)
+
+
 # ---- attention ---------------------------------------------------------------------------------------
 def _rowset(bs, base, gs, istride, n):
     return (int(bs), int(base), int(gs), int(istride), int(n))

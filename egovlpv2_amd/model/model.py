@@ -233,6 +233,9 @@ class FrozenInTime(nn.Module):
         return ops.linear(x, self.p(prefix + '.weight'), self.p(prefix + '.bias') if bias else None, act=act, gate=gate,
                           res1=res1, res2=res2)
 
+    def _ln_skip(self, x, prefix, eps):
+        return ops.layernorm_skip(x, self.p(prefix + '.weight'), self.p(prefix + '.bias'), eps)
+
     def _ln(self, x, prefix, eps):
         return ops.layernorm(x, self.p(prefix + '.weight'), self.p(prefix + '.bias'), eps)
 
@@ -251,23 +254,27 @@ class FrozenInTime(nn.Module):
         c = self.cfg
         pfx = f'video_model.blocks.{i}'
         Fr, N, H = c.frames, c.n_patches, c.heads
-        qkv = self._lin(self._ln(x, pfx + '.norm3', c.eps_video), pfx + '.timeattn.qkv')
+        # pre-norm residuals: _ln_skip returns (LayerNorm(x), x) so that the skip gradient is added inside the LN backward kernel
+        h, xs = self._ln_skip(x, pfx + '.norm3', c.eps_video)
+        qkv = self._lin(h, pfx + '.timeattn.qkv')
         t_ctx = ops.divided_attention(qkv, B, Fr, N, H, 'time')
-        tr = self._lin(t_ctx, pfx + '.timeattn.proj', res1=x)                        # time_residual = x + t   (:218)
+        tr = self._lin(t_ctx, pfx + '.timeattn.proj', res1=xs)                       # time_residual = x + t   (:218)
         qkv = self._lin(self._ln(tr, pfx + '.norm1', c.eps_video), pfx + '.attn.qkv')
         s_ctx = ops.divided_attention(qkv, B, Fr, N, H, 'space')
         if y is None:
-            sr = self._lin(s_ctx, pfx + '.attn.proj', res1=x)                        # space_residual = x + s  (:222)
+            sr = self._lin(s_ctx, pfx + '.attn.proj', res1=xs)                       # space_residual = x + s  (:222)
         else:
             a = pfx + '.attn'
             s = self._lin(s_ctx, a + '.proj')
             kv = self._lin(y, a + '.qkv_text_i2t')                                    # (B*L, 2D) = [k | v]   (:159-164)
-            q = self._lin(self._ln(s, a + '.norm_i2t_i', c.eps_video), a + '.qkv_i2t')
+            hs, ss = self._ln_skip(s, a + '.norm_i2t_i', c.eps_video)
+            q = self._lin(hs, a + '.qkv_i2t')
             o = ops.plain_attention(q, kv[:, :c.dim], kv[:, c.dim:], B, H, c.seq, L, c.head_dim ** -0.5, mask=y_mask)
             # x + (s + alpha * proj_i2t(o))   (:185, :222)
-            sr = self._lin(o, a + '.proj_i2t', gate=self.p(a + '.alpha_i2t'), res1=s, res2=x)
-        return ops.mlp(self._ln(sr, pfx + '.norm2', c.eps_video), self.p(pfx + '.mlp.fc1.weight'), self.p(pfx + '.mlp.fc1.bias'),
-                       self.p(pfx + '.mlp.fc2.weight'), self.p(pfx + '.mlp.fc2.bias'), res=sr)
+            sr = self._lin(o, a + '.proj_i2t', gate=self.p(a + '.alpha_i2t'), res1=ss, res2=xs)
+        h2, srs = self._ln_skip(sr, pfx + '.norm2', c.eps_video)
+        return ops.mlp(h2, self.p(pfx + '.mlp.fc1.weight'), self.p(pfx + '.mlp.fc1.bias'),
+                       self.p(pfx + '.mlp.fc2.weight'), self.p(pfx + '.mlp.fc2.bias'), res=srs)
 
     def _cls_rows(self, x, B, rows_per_sample):
         return x.reshape(B, rows_per_sample, -1)[:, 0].contiguous()
