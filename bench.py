@@ -126,6 +126,11 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    # EGV_BENCH_REHEARSAL=1 (test aid, never a measurement): all ranks share GPU 0 and rendezvous over gloo, so that the
+    # world_size > 1 code path (DDP, gathers, other-rank negatives, max-over-ranks timing) can be run on a 1-GPU box.
+    rehearsal = bool(os.environ.get('EGV_BENCH_REHEARSAL'))
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     use_dist = world > 1 or a.force_ddp
@@ -133,7 +138,10 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29517')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from egovlpv2_amd import hipops as ops
     from egovlpv2_amd.config import PathConfig
