@@ -312,3 +312,27 @@ def test_egomcq_validation_scores_vs_oracle_fp32():
     assert rel_err(got['vtm'], vtm) < 1e-3
     assert rel_err(got['ensemble'], vtc + vtm) < 1e-3
     assert torch.equal(got['ensemble'].argmax(1).cpu(), (vtc + vtm).argmax(1))
+
+
+@pytest.mark.parametrize('B', [1, 3])
+def test_odd_batch_sizes_vs_oracle_fp32(B):
+    """ragged cases of the three-loss step: B = 1 (no ITM positive at all: pos_len = B // 2 = 0) and B = 3; losses vs the
+    oracle under the same RNG seeds (1e-3), identical negative draws."""
+    from oracle import ref_model as O
+    from egovlpv2_amd.synthetic import make_batch
+    g, cfg, _, L, wseed, _ = load_golden('tiny')
+    sd, _, _, _, oc = oracle_setup(cfg, 2, L, wseed, 0)
+    data, noun, verb = make_batch(cfg, B, L, 90 + B)
+    m = _build(cfg, sd, torch.float32)
+    np.random.seed(5)
+    torch.manual_seed(5)
+    loss, ld, ret = _forward(m, data, noun, verb, 'EgoNCE_MLM_ITM')
+    loss.backward()
+    np.random.seed(5)
+    torch.manual_seed(5)
+    with torch.no_grad():
+        oloss, old, oret = O.forward_losses(sd, data, noun, verb, oc, 'EgoNCE_MLM_ITM')
+    assert ret['_itm_neg_log'] == oret['_itm_neg_log']
+    for k in ('EgoNCE', 'loss_mlm', 'loss_itm', 'loss_total'):
+        assert abs(float(ld[k]) - float(old[k])) <= 1e-3 * abs(float(old[k])), (k, float(ld[k]), float(old[k]))
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
