@@ -9,7 +9,11 @@ pids=()
 for f in egv_gemm.hip egv_gemm2.hip egv_norm.hip egv_attn.hip egv_attn_mfma.hip egv_misc.hip egv_optim.hip; do
   o=build/${f%.hip}.o
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ egv_common.h -nt "$o" ] || [ egv_attn.h -nt "$o" ] || [ egv_gemm.h -nt "$o" ]; then
-    hipcc $FLAGS -c "$f" -o "$o" &
+    # attention: keep MFMA accumulators in VGPRs (they feed the softmax VALU code directly; the default AGPR form costs an
+    # accvgpr copy per accumulator register, ~15-20 % of the loop's instructions)
+    EXTRA=""
+    if [ "$f" = "egv_attn_mfma.hip" ]; then EXTRA="-mllvm -amdgpu-mfma-vgpr-form"; fi
+    hipcc $FLAGS $EXTRA -c "$f" -o "$o" &
     pids+=($!)
   fi
 done

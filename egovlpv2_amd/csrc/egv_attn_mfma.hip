@@ -187,6 +187,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnArgs a
                     acc[r] = v;
                 }
                 if (t * 16 + 16 > ntot) {                             // uniform: only the last, partial tile pays for the select
+                    asm volatile("" ::: "memory");                    // keep this a scalar branch (no if-conversion into 56 selects)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[r] = (t * 16 + fg * 4 + r < ntot) ? acc[r] : -INFINITY;
                 }
@@ -334,6 +335,7 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a,
                         acc[r] = pj * (dpv - dl);
                     }
                     if (t * 16 + 16 > ntot) {                         // uniform: the partial tile zeroes its padding keys
+                        asm volatile("" ::: "memory");
 #pragma unroll
                         for (int r = 0; r < 4; ++r) acc[r] = (t * 16 + fg * 4 + r < ntot) ? acc[r] : 0.f;
                     }
