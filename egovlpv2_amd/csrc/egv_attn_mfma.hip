@@ -16,6 +16,9 @@
 // Every output row is written exactly once as 8-byte packed bf16 (4 consecutive head columns per lane).
 #include "egv_attn.h"
 
+#ifndef EGV_KK_BARRIER
+#define EGV_KK_BARRIER
+#endif
 namespace egv {
 
 constexpr int RP = 144;                       // row pitch (bytes) of row-major tiles: 64 bf16 + 16 B pad
@@ -103,6 +106,12 @@ __device__ __forceinline__ bf16x8_t ld_frag_global(const bf16_t* p, bool valid) 
 
 __device__ __forceinline__ unsigned int pack2(float a, float b) { return pack_bf16x2(a, b); }
 
+// NL > 0: the number of live 16-row tiles of the other side is known at compile time (NL - 1 full tiles + one possibly partial
+// tile); the unrolled per-tile code then carries no liveness branches at all.  NL == 0: decided at run time from ntot.
+template <int NL> __device__ __forceinline__ bool tile_live(int t, int ntot) { if constexpr (NL > 0) return t < NL; else return t * 16 < ntot; }
+template <int NL> __device__ __forceinline__ bool tile_partial(int t, int ntot) { if constexpr (NL > 0) return t == NL - 1; else return t * 16 + 16 > ntot; }
+template <int NL> __device__ __forceinline__ bool pair_live(int kk, int ntot) { if constexpr (NL > 0) return 2 * kk < NL; else return kk * 32 < ntot; }
+
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 
@@ -131,7 +140,7 @@ __device__ __forceinline__ void st_bf16x4(bf16_t* p, float a, float b, float c, 
 // ------------------------------------------------------------------------------------------------
 // FL: bit 0 = additive key mask present, bit 1 = probability dropout on; the video-side launches (neither) get a loop
 // without the per-element conditionals.  Scores are kept in the log2 domain (scale * log2(e) folded into one multiply).
-template <int NT, int NW, int FL>
+template <int NT, int NW, int FL, int NL = 0>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnArgs a, int tiles_per_wg) {
     constexpr int VP = vt_pitch(NT);
     constexpr bool MASK = (FL & 1) != 0, DROP = (FL & 2) != 0;
@@ -170,23 +179,61 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnArgs a
         const bf16x8_t q0 = ld_frag_global(Q + qrow * a.ldq + hq + fg * 8, qv);
         const bf16x8_t q1 = ld_frag_global(Q + qrow * a.ldq + hq + 32 + fg * 8, qv);
         f32x4_t s[NT];
-        float m = -INFINITY;
+        float m = -INFINITY, l = 0.f;
+        if constexpr (!MASK) {
+            // pass A: all QK^T MFMAs back to back (no VALU reads an accumulator before the whole batch has issued)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+                if (tile_live<NL>(t, ntot)) {                                  // uniform: tiles past the last key are never touched
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sK, t * 16 + fr, 0, fg), q0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sK, t * 16 + fr, 1, fg), q1, acc, 0, 0, 0);
+                }
+                s[t] = acc;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // pass B: row maximum of the raw scores (the scale is positive, so it commutes with max)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (tile_live<NL>(t, ntot)) {
+                    if (tile_partial<NL>(t, ntot)) {                         // uniform: only the last, partial tile pays for the select
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s[t][r] = (t * 16 + fg * 4 + r < ntot) ? s[t][r] : -INFINITY;
+                    }
+                    m = fmaxf(m, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+                }
+            }
+            m = grp_max(m) * sc2;
+            // pass C: p = exp2(score * scale * log2e - m): one FMA and one v_exp_f32 per element
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (tile_live<NL>(t, ntot)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = exp2_fast(fmaf(s[t][r], sc2, -m));
+                        s[t][r] = e;
+                        l += e;
+                    }
+                } else {
+                    s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        } else {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-            if (t * 16 < ntot) {                                      // uniform: tiles past the last key are never touched
+            if (tile_live<NL>(t, ntot)) {                                      // uniform: tiles past the last key are never touched
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sK, t * 16 + fr, 0, fg), q0, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_row(sK, t * 16 + fr, 1, fg), q1, acc, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = t * 16 + fg * 4 + r;              // index inside this chunk; r0 + key is the global key index
                     float v = acc[r] * sc2;
-                    if (MASK) {
-                        if (a.mask && r0 + key >= a.extra && key < ntot) v += a.mask[(long long)b * a.mask_ld + r0 + key - a.extra] * LOG2E;
-                    }
+                    if (a.mask && r0 + key >= a.extra && key < ntot) v += a.mask[(long long)b * a.mask_ld + r0 + key - a.extra] * LOG2E;
                     acc[r] = v;
                 }
-                if (t * 16 + 16 > ntot) {                             // uniform: only the last, partial tile pays for the select
+                if (tile_partial<NL>(t, ntot)) {                             // uniform: only the last, partial tile pays for the select
                     asm volatile("" ::: "memory");                    // keep this a scalar branch (no if-conversion into 56 selects)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[r] = (t * 16 + fg * 4 + r < ntot) ? acc[r] : -INFINITY;
@@ -199,10 +246,9 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnArgs a
             if (t & 1) __builtin_amdgcn_sched_barrier(0);
         }
         m = grp_max(m);
-        float l = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            if (t * 16 < ntot) {
+            if (tile_live<NL>(t, ntot)) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float e = exp2_fast(s[t][r] - m);
@@ -212,6 +258,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnArgs a
             } else {
                 s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             }
+        }
         }
         l = grp_sum(l);
         if (DROP) {                                   // dropout on the normalised probabilities: l keeps the full sum
@@ -228,13 +275,13 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnArgs a
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < NT / 2; ++kk) {
-            if (kk * 32 < ntot) {
+            if (pair_live<NL>(kk, ntot)) {
                 const bf16x8_t pf = pack8(s[2 * kk], s[2 * kk + 1]);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_t<NT>(sVt, dt * 16 + fr, kk, fg), pf, o[dt], 0, 0, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            EGV_KK_BARRIER
         }
         if (qv && a.nsplit > 1) {
             const long long nrows = (long long)gridDim.y * a.q.n;
@@ -256,7 +303,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnArgs a
 // ------------------------------------------------------------------------------------------------
 // backward, query-owned: dQ and delta = rowsum(dO * O)
 // ------------------------------------------------------------------------------------------------
-template <int NT, int NW, int FL>
+template <int NT, int NW, int FL, int NL = 0>
 __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a, int tiles_per_wg) {
     constexpr int VP = vt_pitch(NT);
     constexpr bool MASK = (FL & 1) != 0, DROP = (FL & 2) != 0;
@@ -315,7 +362,7 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a,
             for (int u = 0; u < 2; ++u) {
                 const int t = 2 * kk + u;
                 f32x4_t acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-                if (t * 16 < ntot) {                                  // uniform: dead key tiles contribute dS = 0
+                if (tile_live<NL>(t, ntot)) {                                  // uniform: dead key tiles contribute dS = 0
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sKt, t * 16, 0, fr, fg), q0, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sKt, t * 16, 1, fr, fg), q1, acc, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sVt, t * 16, 0, fr, fg), g0, dp, 0, 0, 0);
@@ -334,7 +381,7 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a,
                         }
                         acc[r] = pj * (dpv - dl);
                     }
-                    if (t * 16 + 16 > ntot) {                         // uniform: the partial tile zeroes its padding keys
+                    if (tile_partial<NL>(t, ntot)) {                         // uniform: the partial tile zeroes its padding keys
                         asm volatile("" ::: "memory");
 #pragma unroll
                         for (int r = 0; r < 4; ++r) acc[r] = (t * 16 + fg * 4 + r < ntot) ? acc[r] : 0.f;
@@ -342,13 +389,13 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a,
                 }
                 pr[u] = acc;
             }
-            if (kk * 32 < ntot) {                                     // dQ^T += K^T dS^T for this pair of key tiles
+            if (pair_live<NL>(kk, ntot)) {                                     // dQ^T += K^T dS^T for this pair of key tiles
                 const bf16x8_t dsf = pack8(pr[0], pr[1]);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_t<NT>(sKt, dt * 16 + fr, kk, fg), dsf, o[dt], 0, 0, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            EGV_KK_BARRIER
         }
         if (qv && a.nsplit > 1) {
             const long long nrows = (long long)gridDim.y * a.q.n;
@@ -368,7 +415,7 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a,
 // ------------------------------------------------------------------------------------------------
 // backward, key-owned: dK, dV.  own = keys (no extra), other = queries [extra CLS query ; row set], NT query tiles.
 // ------------------------------------------------------------------------------------------------
-template <int NT, int NW, int FL>
+template <int NT, int NW, int FL, int NL = 0>
 __global__ __launch_bounds__(64 * NW) void attn_dkv_mfma_kernel(const AttnArgs a, int tiles_per_wg) {
     constexpr int VP = vt_pitch(NT);
     constexpr bool MASK = (FL & 1) != 0, DROP = (FL & 2) != 0;
@@ -436,7 +483,7 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_mfma_kernel(const AttnArgs a
             for (int u = 0; u < 2; ++u) {
                 const int t = 2 * kk + u;
                 f32x4_t acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-                if (t * 16 < ntot) {                                  // uniform: dead query tiles contribute nothing
+                if (tile_live<NL>(t, ntot)) {                                  // uniform: dead query tiles contribute nothing
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sQt, t * 16, 0, fr, fg), k0, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sQt, t * 16, 1, fr, fg), k1, acc, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_tr<NT>(sGt, t * 16, 0, fr, fg), v0, dp, 0, 0, 0);
@@ -459,7 +506,7 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_mfma_kernel(const AttnArgs a
                 pr[u] = acc;
                 dr[u] = dp;
             }
-            if (kk * 32 < ntot) {                                     // dV^T += dO^T P, dK^T += Q^T dS for this pair of query tiles
+            if (pair_live<NL>(kk, ntot)) {                                     // dV^T += dO^T P, dK^T += Q^T dS for this pair of query tiles
                 const bf16x8_t pf = pack8(pr[0], pr[1]);
                 const bf16x8_t df = pack8(dr[0], dr[1]);
 #pragma unroll
@@ -468,7 +515,7 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_mfma_kernel(const AttnArgs a
                     ok[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_t<NT>(sQt, dt * 16 + fr, kk, fg), df, ok[dt], 0, 0, 0);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            EGV_KK_BARRIER
         }
         if (kv && a.nsplit > 1) {
             // fp32 partials: ws[split][P * k.n own rows][H][2][64]  (summed by attn_dkv_reduce_kernel)
@@ -516,18 +563,18 @@ static inline void own_split(int n_own, int& nw, int& tpw, int& chunks) {
     chunks = (tiles + tpw - 1) / tpw;
 }
 
-#define EGV_MFMA_LAUNCH(KERNEL, LDSFN, NTV)                                                                  \
+#define EGV_MFMA_LAUNCH(KERNEL, LDSFN, NTV, NLV)                                                                 \
     do {                                                                                                     \
         const size_t lds = LDSFN<NTV>();                                                                     \
         dim3 grid(chunks, B * a.G, a.H);                                                                     \
         if (a.mask || a.drop_p > 0.f) {                                                                      \
-            if (nw == 4) { set_lds(KERNEL<NTV, 4, 3>, lds); hipLaunchKernelGGL((KERNEL<NTV, 4, 3>), grid, dim3(256), lds, st, a, tpw); } \
-            else if (nw == 2) { set_lds(KERNEL<NTV, 2, 3>, lds); hipLaunchKernelGGL((KERNEL<NTV, 2, 3>), grid, dim3(128), lds, st, a, tpw); } \
-            else { set_lds(KERNEL<NTV, 1, 3>, lds); hipLaunchKernelGGL((KERNEL<NTV, 1, 3>), grid, dim3(64), lds, st, a, tpw); } \
+            if (nw == 4) { set_lds(KERNEL<NTV, 4, 3, NLV>, lds); hipLaunchKernelGGL((KERNEL<NTV, 4, 3, NLV>), grid, dim3(256), lds, st, a, tpw); } \
+            else if (nw == 2) { set_lds(KERNEL<NTV, 2, 3, NLV>, lds); hipLaunchKernelGGL((KERNEL<NTV, 2, 3, NLV>), grid, dim3(128), lds, st, a, tpw); } \
+            else { set_lds(KERNEL<NTV, 1, 3, NLV>, lds); hipLaunchKernelGGL((KERNEL<NTV, 1, 3, NLV>), grid, dim3(64), lds, st, a, tpw); } \
         } else {                                                                                             \
-            if (nw == 4) { set_lds(KERNEL<NTV, 4, 0>, lds); hipLaunchKernelGGL((KERNEL<NTV, 4, 0>), grid, dim3(256), lds, st, a, tpw); } \
-            else if (nw == 2) { set_lds(KERNEL<NTV, 2, 0>, lds); hipLaunchKernelGGL((KERNEL<NTV, 2, 0>), grid, dim3(128), lds, st, a, tpw); } \
-            else { set_lds(KERNEL<NTV, 1, 0>, lds); hipLaunchKernelGGL((KERNEL<NTV, 1, 0>), grid, dim3(64), lds, st, a, tpw); } \
+            if (nw == 4) { set_lds(KERNEL<NTV, 4, 0, NLV>, lds); hipLaunchKernelGGL((KERNEL<NTV, 4, 0, NLV>), grid, dim3(256), lds, st, a, tpw); } \
+            else if (nw == 2) { set_lds(KERNEL<NTV, 2, 0, NLV>, lds); hipLaunchKernelGGL((KERNEL<NTV, 2, 0, NLV>), grid, dim3(128), lds, st, a, tpw); } \
+            else { set_lds(KERNEL<NTV, 1, 0, NLV>, lds); hipLaunchKernelGGL((KERNEL<NTV, 1, 0, NLV>), grid, dim3(64), lds, st, a, tpw); } \
         }                                                                                                    \
     } while (0)
 
@@ -539,9 +586,10 @@ int egv_attn_fwd_mfma(const AttnArgs& a, int B, hipStream_t st) {
     int nw, tpw, chunks;
     own_split(a.q.n, nw, tpw, chunks);
     chunks *= a.nsplit;
-    if (ntot <= 32) EGV_MFMA_LAUNCH(attn_fwd_mfma_kernel, fwd_lds, 2);
-    else if (ntot <= 64) EGV_MFMA_LAUNCH(attn_fwd_mfma_kernel, fwd_lds, 4);
-    else EGV_MFMA_LAUNCH(attn_fwd_mfma_kernel, fwd_lds, 14);
+    if (ntot <= 32) EGV_MFMA_LAUNCH(attn_fwd_mfma_kernel, fwd_lds, 2, 0);
+    else if (ntot <= 64) EGV_MFMA_LAUNCH(attn_fwd_mfma_kernel, fwd_lds, 4, 0);
+    else if (ntot > 192 && ntot <= 208 && a.nsplit == 1) EGV_MFMA_LAUNCH(attn_fwd_mfma_kernel, fwd_lds, 14, 13);     // 196 patches + CLS: 13 live tiles known at compile time (-20 % on the forward; measured slower on the two backward kernels)
+    else EGV_MFMA_LAUNCH(attn_fwd_mfma_kernel, fwd_lds, 14, 0);
     return 1;
 }
 
@@ -553,9 +601,9 @@ int egv_attn_dq_mfma(const AttnArgs& a, int B, hipStream_t st) {
     int nw, tpw, chunks;
     own_split(a.q.n, nw, tpw, chunks);
     chunks *= a.nsplit;
-    if (ntot <= 32) EGV_MFMA_LAUNCH(attn_dq_mfma_kernel, dq_lds, 2);
-    else if (ntot <= 64) EGV_MFMA_LAUNCH(attn_dq_mfma_kernel, dq_lds, 4);
-    else EGV_MFMA_LAUNCH(attn_dq_mfma_kernel, dq_lds, 14);
+    if (ntot <= 32) EGV_MFMA_LAUNCH(attn_dq_mfma_kernel, dq_lds, 2, 0);
+    else if (ntot <= 64) EGV_MFMA_LAUNCH(attn_dq_mfma_kernel, dq_lds, 4, 0);
+    else EGV_MFMA_LAUNCH(attn_dq_mfma_kernel, dq_lds, 14, 0);
     return 1;
 }
 
@@ -567,8 +615,8 @@ int egv_attn_dkv_mfma(const AttnArgs& a, int B, hipStream_t st) {
     int nw, tpw, chunks;
     own_split(a.k.n, nw, tpw, chunks);
     chunks *= a.nsplit;
-    if (ntot <= 32) EGV_MFMA_LAUNCH(attn_dkv_mfma_kernel, dkv_lds, 2);
-    else if (ntot <= 64) EGV_MFMA_LAUNCH(attn_dkv_mfma_kernel, dkv_lds, 4);
-    else EGV_MFMA_LAUNCH(attn_dkv_mfma_kernel, dkv_lds, 14);
+    if (ntot <= 32) EGV_MFMA_LAUNCH(attn_dkv_mfma_kernel, dkv_lds, 2, 0);
+    else if (ntot <= 64) EGV_MFMA_LAUNCH(attn_dkv_mfma_kernel, dkv_lds, 4, 0);
+    else EGV_MFMA_LAUNCH(attn_dkv_mfma_kernel, dkv_lds, 14, 0);
     return 1;
 }
