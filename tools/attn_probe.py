@@ -18,3 +18,15 @@ for nq in (16, 64, 112, 208):
     q = torch.randn(B * nq, D, device='cuda').bfloat16()
     t = timeit(lambda: ops.plain_attention(q, k, v, B, H, nq, nk, 0.125))
     print(f"nq={nq:4d} ({nq // 16} q-tiles per problem): fwd {t:7.1f} us", flush=True)
+
+print("backward (dQ kernel + dK/dV kernel):")
+for nq in (64, 112, 208):
+    q = torch.randn(B * nq, D, device='cuda').bfloat16().requires_grad_(True)
+    kk = k.clone().requires_grad_(True)
+    vv = v.clone().requires_grad_(True)
+    o = ops.plain_attention(q, kk, vv, B, H, nq, nk, 0.125)
+    do = torch.randn_like(o)
+    def fb():
+        q.grad = kk.grad = vv.grad = None
+        o.backward(do, retain_graph=True)
+    print(f"nq={nq:4d}: bwd {timeit(fb):7.1f} us", flush=True)
