@@ -82,6 +82,31 @@ __device__ __forceinline__ float dgelu_f(float x) {
     return cdf + x * pdf;
 }
 
+// GELU / GELU' for the bf16 storage mode: Phi(x) from the Abramowitz-Stegun 7.1.26 rational form of erf (absolute error
+// < 1.5e-7, far below the 2^-9 rounding of the bf16 value that is stored).  The negative tail is formed without
+// cancellation (Phi(x<0) = q, Phi(x>=0) = 1 - q) and the same exp(-x^2/2) serves the density in the derivative; about half
+// the VALU work of erff + expf, which matters in the fc1 / fc2-dgrad epilogues (64 values per thread per tile).
+__device__ __forceinline__ float phi_tail_q(float x, float& e) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);      // exp(-x^2 / 2)
+    return 0.5f * p * t * e;                                            // = 0.5 * erfc(|x| / sqrt 2)
+}
+__device__ __forceinline__ float gelu_fast_f(float x) {
+    float e;
+    const float q = phi_tail_q(x, e);
+    return x * (x < 0.f ? q : 1.0f - q);
+}
+__device__ __forceinline__ float dgelu_fast_f(float x) {
+    float e;
+    const float q = phi_tail_q(x, e);
+    return (x < 0.f ? q : 1.0f - q) + x * 0.39894228040143267794f * e;
+}
+
 // bijective XCD-aware remap of a linear workgroup id (cdna_hip_programming.md §5 template):
 // consecutive logical tiles land on the same XCD (= same L2) instead of round-robin over the 8 XCDs.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -360,7 +360,10 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmArgs g) {
                     u32x4_t o = {pack2f(v[0], v[1]), pack2f(v[2], v[3]), pack2f(v[4], v[5]), pack2f(v[6], v[7])};
                     *reinterpret_cast<u32x4_t*>(PRE + ro) = o;
                 }
-                if (e.act) {
+                if (e.act == 1) {                                  // GELU: bf16-mode fast form (egv_common.h)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = gelu_fast_f(v[k]);
+                } else if (e.act) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] = apply_act(v[k], e.act);
                 }
@@ -378,7 +381,14 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmArgs g) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { v[2 * k] += __uint_as_float(r[k] << 16); v[2 * k + 1] += __uint_as_float(r[k] & 0xffff0000u); }
                 }
-                if (e.dact) {
+                if (e.dact == 1) {
+                    const u32x4_t r = *reinterpret_cast<const u32x4_t*>(AUX + ro);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[2 * k] *= dgelu_fast_f(__uint_as_float(r[k] << 16));
+                        v[2 * k + 1] *= dgelu_fast_f(__uint_as_float(r[k] & 0xffff0000u));
+                    }
+                } else if (e.dact) {
                     const u32x4_t r = *reinterpret_cast<const u32x4_t*>(AUX + ro);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
