@@ -71,7 +71,7 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, OutT* C, int m
     }
     if (e.act) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], e.act);
+        for (int r = 0; r < 4; ++r) v[r] = (sizeof(T) == 2 && e.act == 1) ? gelu_fast_f(v[r]) : apply_act(v[r], e.act);   // bf16 mode: the same GELU form in every kernel
     }
     if (e.gate) {
 #pragma unroll
@@ -102,7 +102,7 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, OutT* C, int m
             for (int r = 0; r < 4; ++r)
                 if (n + r < g.N) x[r] = Elem<T>::ld(AUX + ro + r);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= apply_dact(x[r], e.dact);
+        for (int r = 0; r < 4; ++r) v[r] *= (sizeof(T) == 2 && e.dact == 1) ? dgelu_fast_f(x[r]) : apply_dact(x[r], e.dact);
     }
     const size_t co = (size_t)m * g.ldc + n;
     if (full && g.c_vec_ok) st4(C + co, v);

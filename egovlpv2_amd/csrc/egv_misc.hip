@@ -361,7 +361,7 @@ __global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ a
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float d = 1.0f;
-            if (kind == 1) d = dgelu_f(a[e]);
+            if (kind == 1) d = sizeof(T) == 2 ? dgelu_fast_f(a[e]) : dgelu_f(a[e]);
             else if (kind == 2) d = a[e] > 0.f ? 1.0f : 0.0f;
             else if (kind == 3) d = 1.0f - a[e] * a[e];
             o[e] = g[e] * d;
