@@ -282,6 +282,7 @@ def main():
                # out the dead MLM video block and the ITM video prefix shared with the MLM pass (same values, computed once)
                "model_tflops": round(value * fpp / 1e12, 1), "executed_tflops": round(value * fpx / 1e12, 1),
                "mfma_frac_of_peak": round(value * fpx / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
+               "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
                "losses": losses, "roofline": roof}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, a.text_len, a.workload)
