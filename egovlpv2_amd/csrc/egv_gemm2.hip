@@ -404,7 +404,7 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmArgs g) {
     if (stamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamps[blockIdx.x * 8 + 5] = clock64(); }
 }
 
-static float* g_timing_buf = nullptr;
+float* g_timing_buf = nullptr;
 extern "C" int egv_debug_timing(void* buf) { g_timing_buf = (float*)buf; return 0; }
 
 template <typename CFG, int NS>
@@ -591,6 +591,8 @@ static inline double wave_eff(int M, int N, int bm, int bn, int nz) {
     return useful * (double)tiles / (double)(rounds * 256);
 }
 
+int egv_gemm3_launch(const egv::GemmArgs& g, hipStream_t st);
+
 int egv_gemm2_launch(const GemmArgs& g, int a_trans, int b_trans, int out_f32, int nz, hipStream_t st) {
     if (!((a_trans == 0 && b_trans == 0) || (a_trans == 1 && b_trans == 1))) return 0;
     if (g.M < 128 || g.N < 64) return 0;
@@ -612,6 +614,8 @@ int egv_gemm2_launch(const GemmArgs& g, int a_trans, int b_trans, int out_f32, i
     const bool useA = wave_eff(g.M, g.N, 256, 256, nz) >= wave_eff(g.M, g.N, 256, 128, nz) * 0.98;
     if (!a_trans) {
         (void)useA;
+        static const int pp = getenv("EGV_GEMM_PP") ? atoi(getenv("EGV_GEMM_PP")) : 1;     // persistent ping-pong kernel (egv_gemm3.hip) for large grids; 0 = ring kernels only
+        if (pp && (long long)((g.M + 255) / 256) * ((g.N + 255) / 256) >= 64 && egv_gemm3_launch(g, st)) return 1;
         static const int force = getenv("EGV_GEMM_CFG") ? atoi(getenv("EGV_GEMM_CFG")) : 0;     // experiments only
         const long long tb = (long long)((g.M + 255) / 256) * ((g.N + 127) / 128);
         if (force == 1 && tb <= 128) return 0;                  // experiment: generic 128x128 kernel for small grids

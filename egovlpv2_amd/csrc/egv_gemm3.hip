@@ -1,0 +1,511 @@
+// Persistent ping-pong MFMA GEMM for gfx950 (bf16 storage, fp32 accumulate): forward and dgrad of the large Linear layers
+// of the EgoVLPv2 hot path (M = B*S = 25 096 video tokens; SURVEY.md K2/K5/K7/K9: qkv, proj, fc1, fc2 and their dgrads).
+//
+//   C[M,N] = epilogue( A[M,K] * B[N,K]^T ),  both operands K-contiguous (NT form).
+//
+// Structure (cdna_hip_programming.md "256^2 8-phase template", rebuilt for short-K / output-heavy shapes):
+//   * one workgroup per CU (grid = #CUs), 8 waves = 2 (M) x 4 (N), 256 x 256 output tile, wave tile 128 x 64 =
+//     8 x 4 v_mfma_f32_16x16x32_bf16 accumulators (128 VGPRs), K step 64;
+//   * PERSISTENT: a workgroup walks tiles t = first, first + gridDim, ...; the staging cursor runs 5 phases ahead of the
+//     compute cursor and simply continues into the next tile (no prologue bubble per tile);
+//   * a K-tile (256 x 64 of A, 256 x 64 of B = 64 KB, two buffers = 128 KB LDS) is staged as four 16 KB UNITS chosen by
+//     WHEN they are read, not by where they sit in the tile:  U0 = A rows read in phase 0 (sub-tile 0 of both wave rows),
+//     U1 = B rows read in phase 0, U2 = B rows read in phase 1, U3 = A rows read in phase 2.  Every unit is staged by all
+//     8 waves with 2 global_load_lds_dwordx4 each (1 KiB per wave instruction), exactly one unit per phase, 5 phases
+//     (6 for U0) before its read.  The wait at the end of every phase's load segment is a COUNTED s_waitcnt vmcnt(N) that
+//     leaves the four youngest units (and whatever epilogue traffic is younger) in flight: nothing is ever drained;
+//   * 4 phases per K-tile, each = {ds_read sub-tile fragments ; stage one unit ; vmcnt(N) ; barrier ; 16 MFMAs (one
+//     64 x 32 quadrant of the wave tile over K = 64) ; barrier}.  The two wave rows run staggered by one barrier
+//     (ping-pong): while waves 0-3 are in their MFMA segment, waves 4-7 (same SIMDs) are in their LDS/DMA segment;
+//   * LDS image of a unit: 128 rows x 128 B, 16-byte chunk c of row r stored at chunk c ^ (r & 7) (XOR applied on the
+//     per-lane SOURCE address of the DMA and on the fragment read): conflict-free ds_read_b128;
+//   * the B rows of a wave are permuted when staged (operand row q of fragment (t, j') holds column t*32 + (q>>2)*8 + j'*4 +
+//     (q&3) of the wave's 64) so that a lane's accumulators of fragments (t,0), (t,1) are 8 CONSECUTIVE output columns and the
+//     four lane groups of a row cover 64 contiguous bytes: the epilogue is register-only with 16-byte loads / stores;
+//   * DEFERRED, QUADRANT-WISE EPILOGUE: the finished tile's quadrant q is converted and stored in the load segment of phase q
+//     of the NEXT tile's first K-tile, right before that quadrant's accumulators are re-initialised -- the epilogue's VALU
+//     work and stores run beside the other wave row's MFMAs instead of stalling the matrix pipe.  Bias (and the residual)
+//     are not added in the epilogue at all: they are the C operand of a tile's first MFMAs, loaded one tile (two phases)
+//     ahead, so their latency is never exposed.
+// Requirements (checked by the launcher, otherwise the 256x128 ring kernel of egv_gemm2.hip takes the call):
+//   K % 64 == 0, K >= 192, N % 64 == 0, 16-byte aligned pointers / leading dims, byte offsets < 2^31, scale == 1.
+#include "egv_gemm.h"
+#include <cstdlib>
+
+namespace egv {
+
+typedef __attribute__((address_space(3))) void* lptr3_t;
+
+template <int N> __device__ __forceinline__ void pp_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+constexpr int PP_UNIT = 16384;            // bytes per staged unit
+constexpr int PP_BUF = 4 * PP_UNIT;       // bytes per K-tile buffer
+constexpr int PP_LDS = 2 * PP_BUF + 16384; // + 1 KiB per wave of dummy DMA target (DMAs issued past the last tile) + 1 KiB per wave: the tile's 256 bias values
+
+struct PPTile {
+    int m0, n0;
+};
+__device__ __forceinline__ PPTile pp_tile(int t, int tiles_n) {
+    PPTile r;
+    r.m0 = (t / tiles_n) * 256;
+    r.n0 = (t % tiles_n) * 256;
+    return r;
+}
+
+// K-tile kinds: what else (besides the 2 DMA instructions of a phase) a wave puts on the vector-memory queue in each phase
+// decides the count of the phase's s_waitcnt.
+enum { PP_PLAIN = 0, PP_LAST = 1, PP_FIRST_CHAIN = 2, PP_FIRST_COLD = 3, PP_SECOND_CHAIN = 4, PP_SECOND_COLD = 5 };
+
+// extra vector-memory operations issued in phase p of a K-tile of kind `kind` (NSQ stores per quadrant epilogue, NX operand
+// loads per quadrant, 1 bias DMA per tile)
+__host__ __device__ constexpr int pp_extra(int kind, int p, int NSQ, int NX, int x1k) {
+    if (kind == PP_LAST) return p == 1 ? 1 : (p >= 2 ? NX : 0);
+    if (kind == PP_FIRST_CHAIN) return ((p & 1) ? 0 : 2 * NSQ) + (p < 2 ? NX : 0);
+    if (kind == PP_FIRST_COLD) return (x1k == 1 && p < 2) ? NX : 0;
+    return 0;
+}
+__host__ __device__ constexpr int pp_prev_kind(int kind) {
+    return kind == PP_FIRST_CHAIN ? PP_LAST : kind == PP_SECOND_CHAIN ? PP_FIRST_CHAIN : kind == PP_SECOND_COLD ? PP_FIRST_COLD : PP_PLAIN;
+}
+// operations younger than the unit staged 4 phases ago, at the wait of phase p: the DMAs of the last 4 phases + the extras
+__host__ __device__ constexpr int pp_nwait(int kind, int p, int NSQ, int NX, int x1k) {
+    int n = 8;
+    for (int q = 0; q <= p; ++q) n += pp_extra(kind, q, NSQ, NX, x1k);
+    if (kind != PP_FIRST_COLD)                      // before a cold first K-tile there is only the prologue (nothing younger)
+        for (int q = p + 1; q < 4; ++q) n += pp_extra(pp_prev_kind(kind), q, NSQ, NX, x1k);
+    return n;
+}
+
+// Epilogue kinds are compile-time (register budget):
+//   X1K : 0 none, 1 residual res1 added (forward of proj / fc2), 2 activation-derivative operand aux multiplied (dgrad)
+//   PREK: also store the pre-activation (fc1) -- doubles the stores of a tile
+//   ACTK: e.act may be non-zero
+template <int X1K, bool PREK, bool ACTK, bool STAMPS = false>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntiles) {
+    constexpr int NSQ = PREK ? 8 : 4;
+    constexpr int NX = X1K ? 4 : 0;
+    constexpr unsigned int OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = wave_id();
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int KT = g.K >> 6;
+    const GemmEpi& e = g.e;
+
+    // ---- tile walk: workgroup w takes tiles first, first + G, ... of an order in which the 32 workgroups of one XCD (w % 8)
+    // hold 32 CONSECUTIVE tiles of every round (m-major): they share A panels through that XCD's L2.
+    const int G = gridDim.x;
+    const int wg = blockIdx.x;
+    const int per_xcd = G >> 3;                                   // G % 8 == 0 (launcher)
+    const int first = (wg & 7) * per_xcd + (wg >> 3);
+    const int my_tiles = first < ntiles ? (ntiles - 1 - first) / G + 1 : 0;
+    if (my_tiles == 0) return;
+
+    // ---- staging geometry of this lane: unit row rho = (p*8 + wave)*8 + (lane>>3), source chunk (lane&7) ^ (lane>>3)
+    const int srow = lane >> 3;
+    const int schunk = ((lane & 7) ^ srow) * 8;                   // element offset inside the 64-wide K-tile
+    unsigned int soff[4][2];                                      // byte offsets (from A / B) of this lane's source rows: [unit][piece]
+    auto set_stage_tile = [&](int t) {
+        const PPTile tl = pp_tile(t, g.tiles_n);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int rho = (p * 8 + wave) * 8 + srow;            // 0..127
+            // A units: rho -> tile row (rho>>6)*128 + sub*64 + (rho&63)
+            const int ra0 = min(tl.m0 + (rho >> 6) * 128 + (rho & 63), g.M - 1);
+            const int ra1 = min(tl.m0 + (rho >> 6) * 128 + 64 + (rho & 63), g.M - 1);
+            soff[0][p] = (unsigned int)(ra0 * g.lda + schunk) * 2u;
+            soff[3][p] = (unsigned int)(ra1 * g.lda + schunk) * 2u;
+            // B units: rho = wc'*32 + j'*16 + q -> column wc'*64 + sub*32 + (q>>2)*8 + j'*4 + (q&3)
+            const int wcp = rho >> 5, jp = (rho >> 4) & 1, q = rho & 15;
+            const int cb0 = min(tl.n0 + wcp * 64 + (q >> 2) * 8 + jp * 4 + (q & 3), g.N - 1);
+            const int cb1 = min(tl.n0 + wcp * 64 + 32 + (q >> 2) * 8 + jp * 4 + (q & 3), g.N - 1);
+            soff[1][p] = (unsigned int)(cb0 * g.ldb + schunk) * 2u;
+            soff[2][p] = (unsigned int)(cb1 * g.ldb + schunk) * 2u;
+        }
+    };
+    // staging cursor: units are issued in the fixed order U0(kt) U1(kt) U2(kt) U3(kt) U0(kt+1) ... across tiles
+    int s_tile_seq = 0;                                           // which of my tiles the cursor is in
+    int s_kt = 0;                                                 // K-tile inside that tile
+    int s_gkt = 0;                                                // global K-tile count (buffer parity)
+    set_stage_tile(first);
+
+    // LDS-DMA issued from inline asm: the compiler then keeps no LDS-DMA bookkeeping of its own (with the builtin it drains
+    // vmcnt(0) ahead of the first ds_read after every epilogue); every wait for staged data is one of the counted
+    // pp_wait_vmcnt below.  M0 (the DMA's LDS base) is saved / restored inside the statement (cdna_hip_programming.md 5.7).
+    const unsigned int lds0 = (unsigned int)(unsigned long long)(lptr3_t)smem;
+    const unsigned int dummy_lds = lds0 + 2 * PP_BUF + wave * 1024;
+    auto glds = [&](const void* base, unsigned int voff, unsigned int lds_dst) {
+        unsigned int keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(base), "s"(lds_dst)
+                     : "memory");
+    };
+    auto stage_unit = [&](int u) {                                // u is a compile-time constant at every call site
+        const unsigned int live = s_tile_seq < my_tiles ? ~0u : 0u;   // past my last tile: harmless DMAs into the dummy slab keep
+                                                                       // the vmcnt arithmetic uniform
+        const unsigned int dst = lds0 + (s_gkt & 1) * PP_BUF + u * PP_UNIT + wave * 1024;
+        const void* base = (u == 0 || u == 3) ? g.A : g.B;
+        const unsigned int koff = (unsigned int)s_kt * 128u;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const unsigned int voff = (soff[u][p] + koff) & live;
+            const unsigned int d = dummy_lds + ((dst + p * 8192 - dummy_lds) & live);
+            glds(base, voff, __builtin_amdgcn_readfirstlane(d));
+        }
+    };
+    auto advance_cursor = [&]() {                                 // after U3 of a K-tile was issued
+        ++s_gkt;
+        if (++s_kt == KT) {
+            s_kt = 0;
+            ++s_tile_seq;
+            if (s_tile_seq < my_tiles) set_stage_tile(first + s_tile_seq * G);
+        }
+    };
+
+    // ---- fragment read offsets (bytes inside a K-tile buffer)
+    const int swz0 = ((0 * 4 + fg) ^ (fr & 7)) * 16, swz1 = ((1 * 4 + fg) ^ (fr & 7)) * 16;
+    const int a_base = (wr * 64 + fr) * 128;                      // + i*2048 ; unit U0 (sub 0) / U3 (sub 1)
+    const int b_base = (wc * 32 + fr) * 128;                      // + j'*2048 ; unit U1 (sub 0) / U2 (sub 1)
+
+    // ---- epilogue operands: buffer descriptors (range = whole matrix; offset 2^31 is out of range by construction: such
+    // loads return 0 and such stores are dropped, so rows / columns outside the matrix need no branches)
+    auto mk = [&](const void* p, long long bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, p ? (int)bytes : 0, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rs_c = mk(g.C, (long long)g.M * g.ldc * 2);
+    const __amdgpu_buffer_rsrc_t rs_pre = mk(e.pre, (long long)g.M * e.ldr * 2);
+    const __amdgpu_buffer_rsrc_t rs_x = mk(X1K == 1 ? e.res1 : e.aux, (long long)g.M * e.ldr * 2);
+    const __amdgpu_buffer_rsrc_t rs_bias = mk(e.bias, (long long)g.N * 4);
+    const float gate = e.gate ? *e.gate : 1.0f;
+
+    // quadrant q (= the phase that computes it): (s, t) = (0,0) (0,1) (1,1) (1,0)
+    // element (s, i, t) of a lane: row m0 + wr*128 + s*64 + i*16 + fr, columns n0 + wc*64 + t*32 + fg*8 .. +7.
+    // Byte offset = per-lane constant + a wave-uniform term (one v_add per access, nothing kept per tile).  Rows >= M fall
+    // outside the descriptor's range by themselves; columns >= N (N % 64 == 0: both halves of a lane agree) are sent there.
+    const int lane_col = wc * 64 + fg * 8;
+    const unsigned int lane_c = (unsigned int)((wr * 128 + fr) * g.ldc + lane_col) * 2u;
+    const unsigned int lane_r = (unsigned int)((wr * 128 + fr) * e.ldr + lane_col) * 2u;
+    // stores: a lane pair (rows fr, fr^8) trades halves so that ONE store instruction writes 8 CONSECUTIVE rows x 128 contiguous bytes (the
+    // wave's whole 64-column slab of a row) instead of 16 rows x 64: the CU's store path is issue-bound on lines per instruction
+    // (measured: 12.4k -> 8.7k cycles for the 128 KB of a tile).  Lane (fr, fg): row (fr & 7) [+8 for the second store of
+    // a pair], columns (fr >> 3)*32 + fg*8.
+    // (the per-lane parts are recomputed from the lane id at every use -- `opaque_lane` hides it from hoisting -- because
+    // hipcc otherwise keeps them in registers across the whole K loop and spills; a spill reload is a vector-memory operation
+    // that would break the counted waits)
+    auto opaque_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
+    auto p_off = [&](const PPTile& tl, int s, int i, int second, bool out) -> unsigned int {
+        const int l = opaque_lane();
+        const int fr_ = l & 15, fg_ = l >> 4;
+        const int ld = out ? g.ldc : e.ldr;
+        const int pair_col = wc * 64 + (fr_ >> 3) * 32 + fg_ * 8;
+        const unsigned int lane_part = (__umul24((unsigned int)(wr * 128 + (fr_ & 7)), (unsigned int)ld) + (unsigned int)pair_col) * 2u;
+        const unsigned int sterm = (unsigned int)((tl.m0 + s * 64 + i * 16 + second * 8) * ld + tl.n0) * 2u;
+        return (tl.n0 + pair_col < g.N) ? lane_part + sterm : OOB;
+    };
+    // (a, b) of this lane = (t = 0, t = 1) vectors of its row  ->  (first, second) store vectors
+    auto pair_swap = [&](u32x4_t t0, u32x4_t t1, u32x4_t& first, u32x4_t& second) {
+        const bool odd = fr & 8;                                  // upper half of the 16-lane row
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned int send = odd ? t0[k] : t1[k];
+            const unsigned int got = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)send, 0x128, 0xF, 0xF, false);   // row_ror:8 = lane ^ 8 inside each 16-lane row
+            first[k] = odd ? got : t0[k];
+            second[k] = odd ? t1[k] : got;
+        }
+    };
+    auto q_off = [&](const PPTile& tl, bool valid, int s, int i, int t, bool out) -> unsigned int {
+        const int ld = out ? g.ldc : e.ldr;
+        const unsigned int sterm = (unsigned int)((tl.m0 + s * 64 + i * 16) * ld + tl.n0 + t * 32) * 2u;
+        return (valid && tl.n0 + lane_col < g.N) ? (out ? lane_c : lane_r) + sterm : OOB;
+    };
+
+    // bias of the tile whose accumulators are initialised next: one LDS-DMA per wave and tile (256 fp32 values = 1 KiB) into the
+    // wave's own slab, issued in the last K-tile of the previous tile; no register is held and no compiler-visible load exists
+    // in the main loop (hipcc would cover a pending one with vmcnt(0) at the loop headers)
+    const unsigned int bias_lds = lds0 + 2 * PP_BUF + 8192 + wave * 1024;
+    const float* bias_slab = reinterpret_cast<const float*>(smem + 2 * PP_BUF + 8192 + wave * 1024);
+    const bool has_bias = e.bias != nullptr;
+    auto load_bias = [&](const PPTile& tb) {
+        const unsigned int voff = (unsigned int)min(tb.n0 + lane * 4, g.N - 4) * 4u;
+        glds(has_bias ? (const void*)e.bias : g.B, has_bias ? voff : 0u, __builtin_amdgcn_readfirstlane(bias_lds));
+    };
+    u32x4_t xq[2][4];                                             // operand vectors of two quadrants in flight: slot = quadrant & 1
+    auto load_x = [&](int q, const PPTile& tl, bool valid) {      // q compile-time
+        const int s = q >> 1, t = (q == 1 || q == 2) ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xq[q & 1][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, q_off(tl, valid, s, i, t, false), 0, 0);
+    };
+
+    f32x4_t acc[8][4];                                            // (s*4+i, t*2+j'); written by the first MFMAs of every tile
+    bf16x8_t af[4][2], bf0[2][2], bf1[2][2];
+
+    // convert + store the two quadrants (s, 0), (s, 1) of the finished tile `tl`: 8 full-line stores (16 with the pre-activation)
+    auto pair_epilogue = [&](int s, const PPTile& tl) {           // s compile-time
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x4_t f, sec;
+            if (PREK) {                                           // pre-activation first, in its own pass (register budget)
+                u32x4_t pr[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const f32x4_t a0 = acc[s * 4 + i][t * 2 + 0], a1 = acc[s * 4 + i][t * 2 + 1];
+                    pr[t] = u32x4_t{pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[0], a1[1]), pack_bf16x2(a1[2], a1[3])};
+                }
+                pair_swap(pr[0], pr[1], f, sec);
+                __builtin_amdgcn_raw_buffer_store_b128(f, rs_pre, p_off(tl, s, i, 0, false), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(sec, rs_pre, p_off(tl, s, i, 1, false), 0, 0);
+            }
+            u32x4_t o[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v[k] = acc[s * 4 + i][t * 2 + 0][k];
+                    v[4 + k] = acc[s * 4 + i][t * 2 + 1][k];
+                }
+                if (ACTK) {
+                    if (e.act == 1) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = gelu_fast_f(v[k]);
+                    } else if (e.act) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = apply_act(v[k], e.act);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] *= gate;
+                o[t] = u32x4_t{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+            }
+            pair_swap(o[0], o[1], f, sec);
+            __builtin_amdgcn_raw_buffer_store_b128(f, rs_c, p_off(tl, s, i, 0, true), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(sec, rs_c, p_off(tl, s, i, 1, true), 0, 0);
+        }
+    };
+
+    // accumulators of quadrant q of a new tile = bias (+ residual): done in the load segment of the phase that first
+    // multiplies into them, right after the previous tile's values were stored
+    auto acc_init = [&](int q) {                                  // q compile-time
+        const int s = q >> 1, t = (q == 1 || q == 2) ? 1 : 0;
+        const float* bp = bias_slab + wc * 64 + t * 32 + (opaque_lane() >> 4) * 8;
+        f32x4_t b[2];
+        b[0] = *reinterpret_cast<const f32x4_t*>(bp);
+        b[1] = *reinterpret_cast<const f32x4_t*>(bp + 4);
+        if (!has_bias) b[0] = b[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                f32x4_t c = b[jp];
+                if (X1K == 1) {
+                    const u32x4_t r = xq[q & 1][i];
+                    c[0] += __uint_as_float(r[jp * 2] << 16);
+                    c[1] += __uint_as_float(r[jp * 2] & 0xffff0000u);
+                    c[2] += __uint_as_float(r[jp * 2 + 1] << 16);
+                    c[3] += __uint_as_float(r[jp * 2 + 1] & 0xffff0000u);
+                }
+                acc[s * 4 + i][t * 2 + jp] = c;
+            }
+    };
+
+    // ---- prologue: the first tile's bias (and residual quadrants 0, 1) first, then U0..U3 of K-tile 0 and U0 U1 of K-tile 1
+    // (the units the steady-state schedule would have issued before phase 0)
+    PPTile cur = pp_tile(first, g.tiles_n);
+    load_bias(cur);
+    if (X1K == 1) { load_x(0, cur, true); load_x(1, cur, true); }
+    stage_unit(0); stage_unit(1); stage_unit(2); stage_unit(3);
+    advance_cursor();
+    stage_unit(0); stage_unit(1);
+    pp_wait_vmcnt<8>();                                           // U0(0), U1(0) landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();
+
+    // one K-tile = 4 phases.  KIND selects the vmcnt counts and the extra work of the phases:
+    //   FIRST_CHAIN: quadrant epilogues of the previous tile `prev` + accumulator init (bias / residual) + operand loads of
+    //                quadrants 2, 3;  FIRST_COLD: the same without a previous tile;  LAST: next tile's bias and the operand
+    //                loads of quadrants 0, 1 (of `nxt` for a residual, of `cur` for a GELU' operand).
+#define PP_MFMA(S, BF, T)                                                                                                  \
+    do {                                                                                                                   \
+        __builtin_amdgcn_s_setprio(1);                                                                                     \
+        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                      \
+        _Pragma("unroll") for (int jp = 0; jp < 2; ++jp)                                                                   \
+            acc[(S) * 4 + i][(T) * 2 + jp] =                                                                               \
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[jp][kh], af[i][kh], acc[(S) * 4 + i][(T) * 2 + jp], 0, 0, 0);   \
+        __builtin_amdgcn_s_setprio(0);                                                                                     \
+    } while (0)
+#define PP_KTILE(KIND, BUFIDX)                                                                                             \
+    do {                                                                                                                   \
+        constexpr bool FIRSTK = (KIND) == PP_FIRST_CHAIN || (KIND) == PP_FIRST_COLD;                                       \
+        constexpr bool CHAIN = (KIND) == PP_FIRST_CHAIN;                                                                   \
+        constexpr bool LASTK = (KIND) == PP_LAST;                                                                          \
+        const unsigned char* buf = smem + ((BUFIDX) & 1) * PP_BUF;                                                         \
+        /* ---------------- phase 0: read A sub 0 (U0) + B sub 0 (U1); stage U2 of kt+1; quadrant 0 = (0,0) */             \
+        {                                                                                                                  \
+            if (CHAIN) pair_epilogue(0, prev);                                                                             \
+            if (CHAIN) pp_wait_vmcnt<6 + 2 * NX + 2 * NSQ>();   /* the bias DMA of LAST phase 1 (this wave's own slab) */       \
+            if (FIRSTK) acc_init(0);                                                                                     \
+            if (X1K == 1 && FIRSTK) load_x(2, cur, true);                                                                  \
+            if (X1K == 2 && CHAIN) load_x(2, prev, true);                                                                  \
+            const unsigned char* pa = buf + 0 * PP_UNIT + a_base;                                                          \
+            const unsigned char* pb = buf + 1 * PP_UNIT + b_base;                                                          \
+            _Pragma("unroll") for (int jp = 0; jp < 2; ++jp) {                                                             \
+                bf0[jp][0] = *reinterpret_cast<const bf16x8_t*>(pb + jp * 2048 + swz0);                                    \
+                bf0[jp][1] = *reinterpret_cast<const bf16x8_t*>(pb + jp * 2048 + swz1);                                    \
+            }                                                                                                              \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
+                af[i][0] = *reinterpret_cast<const bf16x8_t*>(pa + i * 2048 + swz0);                                       \
+                af[i][1] = *reinterpret_cast<const bf16x8_t*>(pa + i * 2048 + swz1);                                       \
+            }                                                                                                              \
+            stage_unit(2);                                                                                                 \
+            pp_wait_vmcnt<pp_nwait(KIND, 0, NSQ, NX, X1K)>();                                                              \
+            __builtin_amdgcn_s_barrier();                                                                                  \
+            PP_MFMA(0, bf0, 0);                                                                                 \
+            __builtin_amdgcn_s_barrier();                                                                                  \
+        }                                                                                                                  \
+        /* ---------------- phase 1: read B sub 1 (U2); stage U3 of kt+1; quadrant 1 = (0,1) */                            \
+        {                                                                                                                  \
+            if (FIRSTK) acc_init(1);                                                                                     \
+            if (LASTK) load_bias(nxt);                                                                                    \
+            if (X1K == 1 && FIRSTK) load_x(3, cur, true);                                                                  \
+            if (X1K == 2 && CHAIN) load_x(3, prev, true);                                                                  \
+            const unsigned char* pb = buf + 2 * PP_UNIT + b_base;                                                          \
+            _Pragma("unroll") for (int jp = 0; jp < 2; ++jp) {                                                             \
+                bf1[jp][0] = *reinterpret_cast<const bf16x8_t*>(pb + jp * 2048 + swz0);                                    \
+                bf1[jp][1] = *reinterpret_cast<const bf16x8_t*>(pb + jp * 2048 + swz1);                                    \
+            }                                                                                                              \
+            stage_unit(3);                                                                                                 \
+            advance_cursor();                                                                                              \
+            pp_wait_vmcnt<pp_nwait(KIND, 1, NSQ, NX, X1K)>();                                                              \
+            __builtin_amdgcn_s_barrier();                                                                                  \
+            PP_MFMA(0, bf1, 1);                                                                                 \
+            __builtin_amdgcn_s_barrier();                                                                                  \
+        }                                                                                                                  \
+        /* ---------------- phase 2: read A sub 1 (U3); stage U0 of kt+2; quadrant 2 = (1,1) */                            \
+        {                                                                                                                  \
+            if (CHAIN) pair_epilogue(1, prev);                                                                             \
+            if (FIRSTK) acc_init(2);                                                                                     \
+            if (X1K == 1 && LASTK) load_x(0, nxt, have_next);                                                              \
+            if (X1K == 2 && LASTK) load_x(0, cur, true);                                                                   \
+            const unsigned char* pa = buf + 3 * PP_UNIT + a_base;                                                          \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
+                af[i][0] = *reinterpret_cast<const bf16x8_t*>(pa + i * 2048 + swz0);                                       \
+                af[i][1] = *reinterpret_cast<const bf16x8_t*>(pa + i * 2048 + swz1);                                       \
+            }                                                                                                              \
+            stage_unit(0);                                                                                                 \
+            pp_wait_vmcnt<pp_nwait(KIND, 2, NSQ, NX, X1K)>();                                                              \
+            __builtin_amdgcn_s_barrier();                                                                                  \
+            PP_MFMA(1, bf1, 1);                                                                                 \
+            __builtin_amdgcn_s_barrier();                                                                                  \
+        }                                                                                                                  \
+        /* ---------------- phase 3: no reads; stage U1 of kt+2; quadrant 3 = (1,0) */                                     \
+        {                                                                                                                  \
+            if (FIRSTK) acc_init(3);                                                                                     \
+            if (X1K == 1 && LASTK) load_x(1, nxt, have_next);                                                              \
+            if (X1K == 2 && LASTK) load_x(1, cur, true);                                                                   \
+            stage_unit(1);                                                                                                 \
+            pp_wait_vmcnt<pp_nwait(KIND, 3, NSQ, NX, X1K)>();                                                              \
+            __builtin_amdgcn_s_barrier();                                                                                  \
+            PP_MFMA(1, bf0, 0);                                                                                 \
+            __builtin_amdgcn_s_barrier();                                                                                  \
+        }                                                                                                                  \
+    } while (0)
+
+    PPTile prev = cur, nxt = cur;
+    bool have_next = false;
+    for (int ts = 0; ts < my_tiles; ++ts) {
+        have_next = ts + 1 < my_tiles;
+        nxt = pp_tile(first + (have_next ? ts + 1 : ts) * G, g.tiles_n);
+        // the second wave row runs one barrier behind the first inside a tile (ping-pong); the skew is applied per tile (and
+        // undone by the first row at the tile's end) so that both rows cross the tile boundary together
+        if (wr == 1) __builtin_amdgcn_s_barrier();
+#define PP_STAMP(KT_) do { if (STAMPS && g.colsum && lane == 0 && (wave & 3) == 0 && ts < 4 && (KT_) < 16)                      \
+            reinterpret_cast<long long*>(g.colsum)[((blockIdx.x * 2 + wr) * 4 + ts) * 16 + (KT_)] = __builtin_readcyclecounter(); } while (0)
+        PP_STAMP(0);
+        const int kb = ts * KT;
+        if (ts == 0) {
+            PP_KTILE(PP_FIRST_COLD, kb);
+            PP_STAMP(1);
+            PP_KTILE(PP_SECOND_COLD, kb + 1);
+        } else {
+            PP_KTILE(PP_FIRST_CHAIN, kb);
+            PP_STAMP(1);
+            PP_KTILE(PP_SECOND_CHAIN, kb + 1);
+        }
+        for (int kt = 2; kt < KT - 1; ++kt) { PP_STAMP(kt); PP_KTILE(PP_PLAIN, kb + kt); }
+        PP_STAMP(KT - 1);
+        PP_KTILE(PP_LAST, kb + KT - 1);
+        PP_STAMP(KT);
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+        prev = cur;
+        cur = nxt;
+    }
+#undef PP_KTILE
+#undef PP_MFMA
+#undef PP_STAMP
+    // ---- the last tile's epilogue
+    pair_epilogue(0, prev);
+    pair_epilogue(1, prev);
+    pp_wait_vmcnt<0>();
+}
+
+}  // namespace egv
+using namespace egv;
+
+// returns 1 if the persistent ping-pong kernel took the call
+namespace egv { extern float* g_timing_buf; }   // tools/gemm_pp_stamps.py (egv_debug_timing)
+int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
+    GemmArgs g = gin;
+    g.colsum = egv::g_timing_buf;
+    const GemmEpi& e = g.e;
+    if ((g.K % 64) || g.K < 192 || (g.N % 64) || !g.a_vec_ok || !g.b_vec_ok) return 0;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if ((g.ldc % 8) || (e.ldr % 8) || !al16(g.C) || !al16(e.res1) || !al16(e.pre) || !al16(e.aux) || (e.bias && !al16(e.bias))) return 0;
+    if ((long long)g.M * g.lda >= (1LL << 30) || (long long)g.N * g.ldb >= (1LL << 30)) return 0;   // 32-bit byte offsets
+    if ((long long)g.M * g.ldc >= (1LL << 30) || (long long)g.M * e.ldr >= (1LL << 30)) return 0;
+    if (e.scale != 1.0f) return 0;                                // the bias rides in as the accumulators' initial value
+    if (e.res2) return 0;                                         // gated two-residual form (i2t projection): ring kernel
+    if (e.res1 && (e.gate || e.dact || e.act || e.pre)) return 0;
+    if (e.dact && (e.act || e.pre)) return 0;
+    if (e.pre && !e.act) return 0;
+    g.tiles_m = (g.M + 255) / 256;
+    g.tiles_n = (g.N + 255) / 256;
+    const int ntiles = g.tiles_m * g.tiles_n;
+    static int ncu = 0;
+    if (!ncu) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipGetDeviceProperties(&prop, dev);
+        ncu = prop.multiProcessorCount > 0 ? (prop.multiProcessorCount / 8) * 8 : 256;
+    }
+    int grid = ncu;
+    if (ntiles < grid) grid = ((ntiles + 7) / 8) * 8;
+#define PP_LAUNCH(X, P, AC)                                                                                              \
+    do {                                                                                                                 \
+        static bool attr = false;                                                                                        \
+        if (!attr) {                                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<X, P, AC>),                           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);                               \
+            attr = true;                                                                                                 \
+        }                                                                                                                \
+        hipLaunchKernelGGL((gemm_pp_kernel<X, P, AC>), dim3(grid), dim3(512), PP_LDS, st, g, ntiles);                    \
+        return 1;                                                                                                        \
+    } while (0)
+    if (e.res1 || e.dact) return 0;                               // residual / GELU' operand epilogues: ring kernel (the operand prefetch does not fit the register budget yet)
+    if (e.pre) PP_LAUNCH(0, true, true);
+    if (e.act) PP_LAUNCH(0, false, true);
+    static const bool stamps = getenv("EGV_PP_STAMPS") != nullptr;                       // instrumentation build of the plain kind
+    if (stamps) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<0, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+            attr = true;
+        }
+        hipLaunchKernelGGL((gemm_pp_kernel<0, false, false, true>), dim3(grid), dim3(512), PP_LDS, st, g, ntiles);
+        return 1;
+    }
+    PP_LAUNCH(0, false, false);
+#undef PP_LAUNCH
+}
