@@ -243,6 +243,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
 
     // convert + store the two quadrants (s, 0), (s, 1) of the finished tile `tl`: 8 full-line stores (16 with the pre-activation)
     auto pair_epilogue = [&](int s, const PPTile& tl) {           // s compile-time
+        float bias8[2][8];                                        // the finished tile's bias from this wave's LDS slab
+        {
+            const float* bp = bias_slab + wc * 64 + (opaque_lane() >> 4) * 8;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(bp + t * 32), b1 = *reinterpret_cast<const f32x4_t*>(bp + t * 32 + 4);
+                if (!has_bias) b0 = b1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { bias8[t][k] = b0[k]; bias8[t][4 + k] = b1[k]; }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             u32x4_t f, sec;
@@ -251,7 +262,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const f32x4_t a0 = acc[s * 4 + i][t * 2 + 0], a1 = acc[s * 4 + i][t * 2 + 1];
-                    pr[t] = u32x4_t{pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[0], a1[1]), pack_bf16x2(a1[2], a1[3])};
+                    pr[t] = u32x4_t{pack_bf16x2(a0[0] + bias8[t][0], a0[1] + bias8[t][1]), pack_bf16x2(a0[2] + bias8[t][2], a0[3] + bias8[t][3]),
+                                    pack_bf16x2(a1[0] + bias8[t][4], a1[1] + bias8[t][5]), pack_bf16x2(a1[2] + bias8[t][6], a1[3] + bias8[t][7])};
                 }
                 pair_swap(pr[0], pr[1], f, sec);
                 __builtin_amdgcn_raw_buffer_store_b128(f, rs_pre, p_off(tl, s, i, 0, false), 0, 0);
@@ -263,8 +275,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                 float v[8];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    v[k] = acc[s * 4 + i][t * 2 + 0][k];
-                    v[4 + k] = acc[s * 4 + i][t * 2 + 1][k];
+                    v[k] = acc[s * 4 + i][t * 2 + 0][k] + bias8[t][k];            // (sum over K) + bias: the ring kernels' order, bit for bit
+                    v[4 + k] = acc[s * 4 + i][t * 2 + 1][k] + bias8[t][4 + k];
                 }
                 if (ACTK) {
                     if (e.act == 1) {
@@ -285,35 +297,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
         }
     };
 
-    // accumulators of quadrant q of a new tile = bias (+ residual): done in the load segment of the phase that first
-    // multiplies into them, right after the previous tile's values were stored
-    auto acc_init = [&](int q) {                                  // q compile-time
-        const int s = q >> 1, t = (q == 1 || q == 2) ? 1 : 0;
-        const float* bp = bias_slab + wc * 64 + t * 32 + (opaque_lane() >> 4) * 8;
-        f32x4_t b[2];
-        b[0] = *reinterpret_cast<const f32x4_t*>(bp);
-        b[1] = *reinterpret_cast<const f32x4_t*>(bp + 4);
-        if (!has_bias) b[0] = b[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int jp = 0; jp < 2; ++jp) {
-                f32x4_t c = b[jp];
-                if (X1K == 1) {
-                    const u32x4_t r = xq[q & 1][i];
-                    c[0] += __uint_as_float(r[jp * 2] << 16);
-                    c[1] += __uint_as_float(r[jp * 2] & 0xffff0000u);
-                    c[2] += __uint_as_float(r[jp * 2 + 1] << 16);
-                    c[3] += __uint_as_float(r[jp * 2 + 1] & 0xffff0000u);
-                }
-                acc[s * 4 + i][t * 2 + jp] = c;
-            }
-    };
-
     // ---- prologue: the first tile's bias (and residual quadrants 0, 1) first, then U0..U3 of K-tile 0 and U0 U1 of K-tile 1
     // (the units the steady-state schedule would have issued before phase 0)
     PPTile cur = pp_tile(first, g.tiles_n);
-    load_bias(cur);
     if (X1K == 1) { load_x(0, cur, true); load_x(1, cur, true); }
     stage_unit(0); stage_unit(1); stage_unit(2); stage_unit(3);
     advance_cursor();
@@ -325,14 +311,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
     //   FIRST_CHAIN: quadrant epilogues of the previous tile `prev` + accumulator init (bias / residual) + operand loads of
     //                quadrants 2, 3;  FIRST_COLD: the same without a previous tile;  LAST: next tile's bias and the operand
     //                loads of quadrants 0, 1 (of `nxt` for a residual, of `cur` for a GELU' operand).
-#define PP_MFMA(S, BF, T)                                                                                                  \
+#define PP_MFMA(S, BF, T, ZERO)                                                                                            \
     do {                                                                                                                   \
         __builtin_amdgcn_s_setprio(1);                                                                                     \
         _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                                   \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                      \
         _Pragma("unroll") for (int jp = 0; jp < 2; ++jp)                                                                   \
-            acc[(S) * 4 + i][(T) * 2 + jp] =                                                                               \
-                __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[jp][kh], af[i][kh], acc[(S) * 4 + i][(T) * 2 + jp], 0, 0, 0);   \
+            acc[(S) * 4 + i][(T) * 2 + jp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                      \
+                BF[jp][kh], af[i][kh], ((ZERO) && kh == 0) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[(S) * 4 + i][(T) * 2 + jp], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                                     \
     } while (0)
 #define PP_KTILE(KIND, BUFIDX)                                                                                             \
@@ -343,9 +329,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
         const unsigned char* buf = smem + ((BUFIDX) & 1) * PP_BUF;                                                         \
         /* ---------------- phase 0: read A sub 0 (U0) + B sub 0 (U1); stage U2 of kt+1; quadrant 0 = (0,0) */             \
         {                                                                                                                  \
+            if (CHAIN) pp_wait_vmcnt<6 + 2 * NX>();         /* the bias DMA of LAST phase 1 (this wave's own slab) landed */ \
             if (CHAIN) pair_epilogue(0, prev);                                                                             \
-            if (CHAIN) pp_wait_vmcnt<6 + 2 * NX + 2 * NSQ>();   /* the bias DMA of LAST phase 1 (this wave's own slab) */       \
-            if (FIRSTK) acc_init(0);                                                                                     \
             if (X1K == 1 && FIRSTK) load_x(2, cur, true);                                                                  \
             if (X1K == 2 && CHAIN) load_x(2, prev, true);                                                                  \
             const unsigned char* pa = buf + 0 * PP_UNIT + a_base;                                                          \
@@ -361,13 +346,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
             stage_unit(2);                                                                                                 \
             pp_wait_vmcnt<pp_nwait(KIND, 0, NSQ, NX, X1K)>();                                                              \
             __builtin_amdgcn_s_barrier();                                                                                  \
-            PP_MFMA(0, bf0, 0);                                                                                 \
+            PP_MFMA(0, bf0, 0, FIRSTK);                                                                                 \
             __builtin_amdgcn_s_barrier();                                                                                  \
         }                                                                                                                  \
         /* ---------------- phase 1: read B sub 1 (U2); stage U3 of kt+1; quadrant 1 = (0,1) */                            \
         {                                                                                                                  \
-            if (FIRSTK) acc_init(1);                                                                                     \
-            if (LASTK) load_bias(nxt);                                                                                    \
+            if (LASTK) load_bias(cur);                                                                                    \
             if (X1K == 1 && FIRSTK) load_x(3, cur, true);                                                                  \
             if (X1K == 2 && CHAIN) load_x(3, prev, true);                                                                  \
             const unsigned char* pb = buf + 2 * PP_UNIT + b_base;                                                          \
@@ -379,13 +363,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
             advance_cursor();                                                                                              \
             pp_wait_vmcnt<pp_nwait(KIND, 1, NSQ, NX, X1K)>();                                                              \
             __builtin_amdgcn_s_barrier();                                                                                  \
-            PP_MFMA(0, bf1, 1);                                                                                 \
+            PP_MFMA(0, bf1, 1, FIRSTK);                                                                                 \
             __builtin_amdgcn_s_barrier();                                                                                  \
         }                                                                                                                  \
         /* ---------------- phase 2: read A sub 1 (U3); stage U0 of kt+2; quadrant 2 = (1,1) */                            \
         {                                                                                                                  \
             if (CHAIN) pair_epilogue(1, prev);                                                                             \
-            if (FIRSTK) acc_init(2);                                                                                     \
             if (X1K == 1 && LASTK) load_x(0, nxt, have_next);                                                              \
             if (X1K == 2 && LASTK) load_x(0, cur, true);                                                                   \
             const unsigned char* pa = buf + 3 * PP_UNIT + a_base;                                                          \
@@ -396,18 +379,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
             stage_unit(0);                                                                                                 \
             pp_wait_vmcnt<pp_nwait(KIND, 2, NSQ, NX, X1K)>();                                                              \
             __builtin_amdgcn_s_barrier();                                                                                  \
-            PP_MFMA(1, bf1, 1);                                                                                 \
+            PP_MFMA(1, bf1, 1, FIRSTK);                                                                                 \
             __builtin_amdgcn_s_barrier();                                                                                  \
         }                                                                                                                  \
         /* ---------------- phase 3: no reads; stage U1 of kt+2; quadrant 3 = (1,0) */                                     \
         {                                                                                                                  \
-            if (FIRSTK) acc_init(3);                                                                                     \
             if (X1K == 1 && LASTK) load_x(1, nxt, have_next);                                                              \
             if (X1K == 2 && LASTK) load_x(1, cur, true);                                                                   \
             stage_unit(1);                                                                                                 \
             pp_wait_vmcnt<pp_nwait(KIND, 3, NSQ, NX, X1K)>();                                                              \
             __builtin_amdgcn_s_barrier();                                                                                  \
-            PP_MFMA(1, bf0, 0);                                                                                 \
+            PP_MFMA(1, bf0, 0, FIRSTK);                                                                                 \
             __builtin_amdgcn_s_barrier();                                                                                  \
         }                                                                                                                  \
     } while (0)
@@ -445,6 +427,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
 #undef PP_MFMA
 #undef PP_STAMP
     // ---- the last tile's epilogue
+    pp_wait_vmcnt<0>();                                           // its bias slab (and the dummy DMAs)
     pair_epilogue(0, prev);
     pair_epilogue(1, prev);
     pp_wait_vmcnt<0>();
