@@ -38,6 +38,39 @@ class AttnDesc(C.Structure):
     ]
 
 
+class VBlockDesc(C.Structure):
+    """struct egv_vblock_desc (include/egovlp_hip.h) -- field order is the ABI."""
+    _fields_ = [
+        ('dtype', i32), ('B', i32), ('F', i32), ('N', i32), ('H', i32), ('D', i32), ('Hd', i32), ('L', i32),
+        ('eps', f32),
+        ('x', vp), ('out', vp), ('y', vp), ('y_mask', vp),
+        ('save', vp), ('save_bytes', i64), ('ws', vp), ('ws_bytes', i64),
+        ('w', vp * 9), ('wt', vp * 9), ('b', vp * 9),
+        ('ln_g', vp * 4), ('ln_b', vp * 4),
+        ('alpha', vp),
+        ('dout', vp), ('dx', vp), ('dy', vp),
+        ('dw', vp * 9), ('db', vp * 9), ('dln_g', vp * 4), ('dln_b', vp * 4), ('dalpha', vp),
+        ('stream', vp), ('stream2', vp),
+    ]
+
+
+class TLayerDesc(C.Structure):
+    """struct egv_tlayer_desc (include/egovlp_hip.h) -- field order is the ABI."""
+    _fields_ = [
+        ('dtype', i32), ('B', i32), ('L', i32), ('H', i32), ('D', i32), ('Hd', i32), ('S', i32),
+        ('eps', f32), ('drop_p', f32),
+        ('seeds', C.c_uint * 6),
+        ('hid', vp), ('out', vp), ('mask', vp), ('enc', vp),
+        ('save', vp), ('save_bytes', i64), ('ws', vp), ('ws_bytes', i64),
+        ('w', vp * 10), ('wt', vp * 10), ('b', vp * 10),
+        ('ln_g', vp * 2), ('ln_b', vp * 2),
+        ('alpha', vp),
+        ('dout', vp), ('dhid', vp), ('denc', vp),
+        ('dw', vp * 10), ('db', vp * 10), ('dln_g', vp * 2), ('dln_b', vp * 2), ('dalpha', vp),
+        ('stream', vp), ('stream2', vp),
+    ]
+
+
 # name -> (restype, argtypes); every symbol declared in include/egovlp_hip.h
 PROTOTYPES = {
     'egv_abi_version': (i32, []),
@@ -76,6 +109,14 @@ PROTOTYPES = {
     'egv_egonce_fwd': (i32, [vp, vp, vp, i32, f32, i32, i32, vp, vp, vp, vp]),
     'egv_egonce_bwd': (i32, [vp, vp, vp, vp, vp, vp, i32, f32, i32, i32, vp]),
     'egv_adamw_step': (i32, [vp, vp, i32, i32, f32, f32, f32, f32, f32, f32, f32, vp]),
+    'egv_vblock_save_bytes': (i64, [C.POINTER(VBlockDesc)]),
+    'egv_vblock_ws_bytes': (i64, [C.POINTER(VBlockDesc), i32]),
+    'egv_vblock_fwd': (i32, [C.POINTER(VBlockDesc)]),
+    'egv_vblock_bwd': (i32, [C.POINTER(VBlockDesc)]),
+    'egv_tlayer_save_bytes': (i64, [C.POINTER(TLayerDesc)]),
+    'egv_tlayer_ws_bytes': (i64, [C.POINTER(TLayerDesc), i32]),
+    'egv_tlayer_fwd': (i32, [C.POINTER(TLayerDesc)]),
+    'egv_tlayer_bwd': (i32, [C.POINTER(TLayerDesc)]),
     'egv_prof_enable': (i32, [i32]),
     'egv_prof_reset': (i32, []),
     'egv_prof_collect': (i32, [C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int), i32]),

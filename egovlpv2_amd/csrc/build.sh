@@ -17,10 +17,13 @@ for f in egv_gemm.hip egv_gemm2.hip egv_gemm3.hip egv_norm.hip egv_attn.hip egv_
     pids+=($!)
   fi
 done
-if [ ! -f build/egv_api.o ] || [ egv_api.cpp -nt build/egv_api.o ]; then
-  hipcc $FLAGS -x hip -c egv_api.cpp -o build/egv_api.o &
-  pids+=($!)
-fi
+for f in egv_api.cpp egv_block.cpp; do
+  o=build/${f%.cpp}.o
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ ../../include/egovlp_hip.h -nt "$o" ]; then
+    hipcc $FLAGS -x hip -c "$f" -o "$o" &
+    pids+=($!)
+  fi
+done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT build/egv_gemm.o build/egv_gemm2.o build/egv_gemm3.o build/egv_norm.o build/egv_attn.o build/egv_attn_mfma.o build/egv_misc.o build/egv_optim.o build/egv_api.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT build/egv_gemm.o build/egv_gemm2.o build/egv_gemm3.o build/egv_norm.o build/egv_attn.o build/egv_attn_mfma.o build/egv_misc.o build/egv_optim.o build/egv_api.o build/egv_block.o
 echo "built $OUT"

@@ -1,0 +1,659 @@
+// Block-level entry points: one C-ABI call runs a whole SpaceTimeBlock (video_transformer.py:214-228, VarAttention :117-187)
+// or a whole RobertaLayer (roberta.py:444-505) forward or backward -- the sequence of kernel launches the Python layer used to
+// issue one ctypes call / one autograd node at a time.  Nothing is computed here: every step is one of the kernels behind
+// include/egovlp_hip.h; this file owns the ORDER, the saved-activation layout, the scratch plan and the two-stream
+// choreography of the backward pass (weight gradients run beside the data-gradient chain).
+//
+// Memory: `save` (forward writes, backward reads) and `ws` (scratch) are caller-allocated; sizes from the *_bytes queries.
+// Streams: all work is enqueued on `stream`; with `stream2` != NULL the weight-gradient GEMMs of a backward call are enqueued
+// on stream2 between an event recorded on `stream` (their operands are ready) and a final join (stream waits for stream2), so
+// when the call returns every output is ordered on `stream` like single-stream work.  The events come from a small
+// library-owned pool (created once, never destroyed); no other state is kept.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include "../../include/egovlp_hip.h"
+
+void egv_set_error(const char* fmt, ...);
+extern "C" int egv_layernorm_bwd2(int dtype, const void* dy, const void* x, const float* stats, const float* gamma,
+                                  const void* add, const void* add2, void* dx, float* dgamma, float* dbeta, int M, int D,
+                                  void* workspace, void* stream);
+
+namespace {
+
+#define BCHK(call)                    \
+    do {                              \
+        int rc__ = (call);            \
+        if (rc__ != 0) return rc__;   \
+    } while (0)
+
+inline size_t al(size_t x) { return (x + 255) & ~size_t(255); }
+
+struct Bump {
+    char* base;
+    size_t off = 0, cap;
+    Bump(void* p, long long c) : base((char*)p), cap((size_t)c) {}
+    void* take(size_t n) { return base + take_off(n); }
+    size_t take_off(size_t n) {               // offset form (layout computation: base == nullptr)
+        off = al(off);
+        const size_t r = off;
+        off += n;
+        return r;
+    }
+    bool ok() const { return off <= cap; }
+};
+
+// ---- event ring (stream fork / join inside one call) ----
+hipEvent_t next_event() {
+    static thread_local std::vector<hipEvent_t> ring;
+    static thread_local size_t pos = 0;
+    if (ring.empty()) {
+        ring.resize(64);
+        for (auto& e : ring) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    }
+    hipEvent_t e = ring[pos];
+    pos = (pos + 1) % ring.size();
+    return e;
+}
+
+struct Fork {                 // weight-gradient stream of one backward call
+    hipStream_t main, side;
+    bool used = false;
+    Fork(void* m, void* s, int M) : main((hipStream_t)m), side((s && M >= 4096) ? (hipStream_t)s : (hipStream_t)m) {}
+    bool forked() const { return side != main; }
+    // order the side stream after everything enqueued on main so far; returns the stream to launch the weight gradient on
+    void* begin() {
+        if (forked()) {
+            hipEvent_t e = next_event();
+            (void)hipEventRecord(e, main);
+            (void)hipStreamWaitEvent(side, e, 0);
+            used = true;
+        }
+        return (void*)side;
+    }
+    void join() {
+        if (forked() && used) {
+            hipEvent_t e = next_event();
+            (void)hipEventRecord(e, side);
+            (void)hipStreamWaitEvent(main, e, 0);
+        }
+    }
+};
+
+inline int esz(int dtype) { return dtype == EGV_BF16 ? 2 : 4; }
+inline char* at(const void* p, size_t bytes) { return (char*)p + bytes; }
+
+// y = act(x W^T + b) (+ gate, residuals, saved pre-activation): forward of one Linear
+int lin_fwd(int dt, int M, int N, int K, const void* x, const void* w, const float* b, void* y, int act, const float* gate,
+            const void* r1, const void* r2, void* pre, void* st) {
+    return egv_gemm(dt, 0, 0, M, N, K, x, K, w, K, y, N, 0, b, act, gate, r1, r2, pre, nullptr, 0, N, 1.0f, st);
+}
+// dx[M,K] = gate * (dz[M,N] W[N,K]) * act'(aux): NT form on the transposed copy when there is one
+int lin_dgrad(int dt, int M, int N, int K, const void* dz, const void* w, const void* wt, void* dx, const float* gate, const void* aux,
+              int dact, void* st) {
+    if (wt) return egv_gemm(dt, 0, 0, M, K, N, dz, N, wt, N, dx, K, 0, nullptr, 0, gate, nullptr, nullptr, nullptr, aux, dact, K, 1.0f, st);
+    return egv_gemm(dt, 0, 1, M, K, N, dz, N, w, K, dx, K, 0, nullptr, 0, gate, nullptr, nullptr, nullptr, aux, dact, K, 1.0f, st);
+}
+int lin_wgrad(int dt, int M, int N, int K, const void* dz, int ldz, const void* x, float* dw, float* db, const float* gate, void* ws,
+              long long wsb, void* st) {
+    return egv_gemm_wgrad(dt, M, N, K, dz, ldz, x, K, dw, db, 1.0f, gate, ws, wsb, st);
+}
+
+void rowset(long long& bs, long long& base, long long& gs, long long& is, int& n, long long a, long long b, long long c, long long d, int e) {
+    bs = a; base = b; gs = c; is = d; n = e;
+}
+
+int nsplit_for(int n_other) {
+    if (n_other <= 224) return 1;
+    int s = n_other / 384;
+    if (s > 32) s = 32;
+    if (s < 2) s = 2;
+    return s;
+}
+
+// ---- divided space / time attention on the fused qkv buffer [M, 3D] (VarAttention core, video_transformer.py:121-150) ----
+struct Divided {
+    int dt, B, Fr, N, H, D, S, M;
+    bool space;
+    void fill(egv_attn_desc& d, const void* qkv, void* O, float* lse) const {
+        std::memset(&d, 0, sizeof(d));
+        const int es = esz(dt);
+        d.Q = qkv; d.K = at(qkv, (size_t)D * es); d.V = at(qkv, (size_t)2 * D * es); d.O = O;
+        d.ldq = d.ldk = d.ldv = 3 * D; d.ldo = D;
+        d.lse = lse;
+        d.B = B; d.H = H;
+        d.scale = 0.125f;                       // 64^-0.5 (head_dim 64)
+        d.nsplit = 1;
+    }
+    void groups(egv_attn_desc& d) const {
+        d.G = space ? Fr : N;
+        if (space) { rowset(d.q_bs, d.q_base, d.q_gs, d.q_is, d.q_n, S, 1, N, 1, N); rowset(d.k_bs, d.k_base, d.k_gs, d.k_is, d.k_n, S, 1, N, 1, N); }
+        else { rowset(d.q_bs, d.q_base, d.q_gs, d.q_is, d.q_n, S, 1, 1, N, Fr); rowset(d.k_bs, d.k_base, d.k_gs, d.k_is, d.k_n, S, 1, 1, N, Fr); }
+        d.extra = 1; d.extra_bs = S; d.extra_row = 0;
+    }
+    long long ws_bytes() const {
+        const int ns = nsplit_for(S);
+        long long a = egv_attn_split_workspace_bytes(0, B, 1, H, 1, ns), b = egv_attn_split_workspace_bytes(1, B, 1, H, 1, ns),
+                  c = egv_attn_bwd_dkv_workspace_bytes(B, 1, H, 1, ns);
+        long long m = a > b ? a : b;
+        return m > c ? m : c;
+    }
+    int fwd(const void* qkv, void* O, float* lse, void* ws, long long wsb, void* st) const {
+        egv_attn_desc d;
+        fill(d, qkv, O, lse);
+        groups(d);
+        BCHK(egv_attn_fwd(dt, &d, st));
+        fill(d, qkv, O, lse);                    // CLS query over all S keys
+        d.G = 1;
+        rowset(d.q_bs, d.q_base, d.q_gs, d.q_is, d.q_n, S, 0, 0, 1, 1);
+        rowset(d.k_bs, d.k_base, d.k_gs, d.k_is, d.k_n, S, 0, 0, 1, S);
+        d.nsplit = nsplit_for(S);
+        d.ws = (float*)ws; d.ws_bytes = wsb;
+        return egv_attn_fwd(dt, &d, st);
+    }
+    int bwd(const void* qkv, const void* O, float* lse, const void* dO, void* dqkv, float* delta, void* ws, long long wsb, void* st) const {
+        const int es = esz(dt);
+        auto grads = [&](egv_attn_desc& d) {
+            d.dO = dO; d.dQ = dqkv; d.dK = at(dqkv, (size_t)D * es); d.dV = at(dqkv, (size_t)2 * D * es);
+            d.lddq = d.lddk = d.lddv = 3 * D;
+            d.delta = delta;
+        };
+        egv_attn_desc d;
+        fill(d, qkv, const_cast<void*>(O), lse); grads(d); groups(d);
+        BCHK(egv_attn_bwd_dq(dt, &d, st));
+        const int ns = nsplit_for(S);
+        fill(d, qkv, const_cast<void*>(O), lse); grads(d);
+        d.G = 1;
+        rowset(d.q_bs, d.q_base, d.q_gs, d.q_is, d.q_n, S, 0, 0, 1, 1);
+        rowset(d.k_bs, d.k_base, d.k_gs, d.k_is, d.k_n, S, 0, 0, 1, S);
+        d.nsplit = ns; d.ws = (float*)ws; d.ws_bytes = wsb;
+        BCHK(egv_attn_bwd_dq(dt, &d, st));
+        fill(d, qkv, const_cast<void*>(O), lse); grads(d); groups(d);
+        BCHK(egv_attn_bwd_dkv(dt, &d, st));
+        fill(d, qkv, const_cast<void*>(O), lse); grads(d);  // CLS key <- all S queries
+        d.G = 1;
+        rowset(d.q_bs, d.q_base, d.q_gs, d.q_is, d.q_n, S, 0, 0, 1, S);
+        rowset(d.k_bs, d.k_base, d.k_gs, d.k_is, d.k_n, S, 0, 0, 1, 1);
+        d.nsplit = ns; d.ws = (float*)ws; d.ws_bytes = wsb;
+        return egv_attn_bwd_dkv(dt, &d, st);
+    }
+};
+
+// ---- plain softmax(scale q k^T + mask) v per (batch, head) with optional probability dropout ----
+struct Plain {
+    int dt, B, H, D, nq, nk;
+    float scale, drop_p;
+    unsigned int drop_seed;
+    const float* mask;                              // [B, nk] additive fp32 or NULL
+    int fwd_ns() const { return nk <= 224 ? 1 : (nk + 223) / 224; }
+    int dkv_ns() const { return nq <= 224 ? 1 : (nq + 223) / 224; }
+    long long ws_bytes() const {
+        long long a = egv_attn_split_workspace_bytes(0, B, 1, H, nq, fwd_ns()), b = egv_attn_split_workspace_bytes(1, B, 1, H, nq, fwd_ns()),
+                  c = egv_attn_bwd_dkv_workspace_bytes(B, 1, H, nk, dkv_ns());
+        long long m = a > b ? a : b;
+        return m > c ? m : c;
+    }
+    void fill(egv_attn_desc& d, const void* q, int ldq, const void* k, const void* v, int ldkv, void* O, float* lse) const {
+        std::memset(&d, 0, sizeof(d));
+        d.Q = q; d.K = k; d.V = v; d.O = O;
+        d.ldq = ldq; d.ldk = d.ldv = ldkv; d.ldo = D;
+        d.lse = lse;
+        d.B = B; d.G = 1; d.H = H;
+        rowset(d.q_bs, d.q_base, d.q_gs, d.q_is, d.q_n, nq, 0, 0, 1, nq);
+        rowset(d.k_bs, d.k_base, d.k_gs, d.k_is, d.k_n, nk, 0, 0, 1, nk);
+        d.scale = scale;
+        d.mask = mask; d.mask_ld = mask ? nk : 0;
+        d.nsplit = 1;
+        d.drop_p = drop_p; d.drop_seed = drop_seed;
+    }
+    int fwd(const void* q, int ldq, const void* k, const void* v, int ldkv, void* O, float* lse, void* ws, long long wsb, void* st) const {
+        egv_attn_desc d;
+        fill(d, q, ldq, k, v, ldkv, O, lse);
+        d.nsplit = fwd_ns(); d.ws = (float*)ws; d.ws_bytes = wsb;
+        return egv_attn_fwd(dt, &d, st);
+    }
+    int bwd(const void* q, int ldq, const void* k, const void* v, int ldkv, const void* O, float* lse, const void* dO, void* dq, int lddq,
+            void* dk, void* dv, int lddkv, float* delta, void* ws, long long wsb, void* st) const {
+        egv_attn_desc d;
+        fill(d, q, ldq, k, v, ldkv, const_cast<void*>(O), lse);
+        d.dO = dO; d.dQ = dq; d.dK = dk; d.dV = dv; d.lddq = lddq; d.lddk = d.lddv = lddkv; d.delta = delta;
+        d.nsplit = fwd_ns(); d.ws = (float*)ws; d.ws_bytes = wsb;
+        BCHK(egv_attn_bwd_dq(dt, &d, st));
+        d.nsplit = dkv_ns();
+        return egv_attn_bwd_dkv(dt, &d, st);
+    }
+};
+
+// =====================================================================================================================
+// SpaceTimeBlock
+// =====================================================================================================================
+enum { VW_TQKV = 0, VW_TPROJ, VW_SQKV, VW_SPROJ, VW_FC1, VW_FC2, VW_KV_I2T, VW_Q_I2T, VW_PROJ_I2T };
+enum { VL_NORM3 = 0, VL_NORM1, VL_NORM2, VL_NORM_I2T };
+
+struct VLayout {           // saved activations of one block (byte offsets into `save`)
+    size_t stats3, h3, qkv_t, tctx, lse_t, tr, stats1, h1, qkv_s, sctx, lse_s, sr, stats2, h2, pre, act;
+    size_t s, kv, stats_i, hs, q, o, lse_x, pg;     // fused only
+    size_t total;
+};
+
+VLayout vlayout(const egv_vblock_desc* d) {
+    VLayout L{};
+    Bump b(nullptr, 0);
+    const size_t es = esz(d->dtype);
+    const size_t S = 1 + (size_t)d->F * d->N, M = (size_t)d->B * S, D = d->D, Hd = d->Hd, H = d->H;
+    auto T = [&](size_t n) { return b.take_off(n); };
+    L.stats3 = T(M * 8); L.h3 = T(M * D * es); L.qkv_t = T(M * 3 * D * es); L.tctx = T(M * D * es); L.lse_t = T(M * H * 4);
+    L.tr = T(M * D * es); L.stats1 = T(M * 8); L.h1 = T(M * D * es); L.qkv_s = T(M * 3 * D * es); L.sctx = T(M * D * es);
+    L.lse_s = T(M * H * 4); L.sr = T(M * D * es); L.stats2 = T(M * 8); L.h2 = T(M * D * es); L.pre = T(M * Hd * es); L.act = T(M * Hd * es);
+    if (d->L > 0) {
+        const size_t BL = (size_t)d->B * d->L;
+        L.s = T(M * D * es); L.kv = T(BL * 2 * D * es); L.stats_i = T(M * 8); L.hs = T(M * D * es); L.q = T(M * D * es);
+        L.o = T(M * D * es); L.lse_x = T(M * H * 4); L.pg = T(M * D * es);
+    }
+    L.total = al(b.off);
+    return L;
+}
+
+}  // namespace
+
+extern "C" long long egv_vblock_save_bytes(const egv_vblock_desc* d) { return (long long)vlayout(d).total; }
+
+extern "C" long long egv_vblock_ws_bytes(const egv_vblock_desc* d, int backward) {
+    const size_t es = esz(d->dtype);
+    const size_t S = 1 + (size_t)d->F * d->N, M = (size_t)d->B * S, D = d->D, Hd = d->Hd, H = d->H;
+    Divided dv{d->dtype, d->B, d->F, d->N, d->H, d->D, (int)S, (int)M, true};
+    long long attn = dv.ws_bytes();
+    if (d->L > 0) {
+        Plain p{d->dtype, d->B, d->H, d->D, (int)S, d->L, 0.125f, 0.f, 0u, nullptr};
+        if (p.ws_bytes() > attn) attn = p.ws_bytes();
+    }
+    size_t tot = al((size_t)attn) + 4096;
+    if (backward) {
+        long long wg = 0;
+        auto mx = [&](long long v) { if (v > wg) wg = v; };
+        mx(egv_gemm_wgrad_workspace_bytes(3 * (int)D, (int)D, (int)M)); mx(egv_gemm_wgrad_workspace_bytes((int)D, (int)D, (int)M));
+        mx(egv_gemm_wgrad_workspace_bytes((int)Hd, (int)D, (int)M)); mx(egv_gemm_wgrad_workspace_bytes((int)D, (int)Hd, (int)M));
+        if (d->L > 0) mx(egv_gemm_wgrad_workspace_bytes(2 * (int)D, (int)D, d->B * d->L));
+        tot += al((size_t)wg) + al((size_t)egv_layernorm_bwd_workspace_bytes((int)M, (int)D));
+        tot += al(M * Hd * es) + 8 * al(M * D * es) + 2 * al(M * 3 * D * es) + 3 * al(M * H * 4) + 4096;
+        if (d->L > 0) tot += 4 * al(M * D * es) + al((size_t)d->B * d->L * 2 * D * es) + 4096;
+    }
+    return (long long)tot + 65536;
+}
+
+extern "C" int egv_vblock_fwd(const egv_vblock_desc* d) {
+    const int dt = d->dtype;
+    const int S = 1 + d->F * d->N, M = d->B * S, D = d->D, Hd = d->Hd;
+    const bool fused = d->L > 0;
+    if (!(d->x && d->out && d->save && d->ws)) { egv_set_error("egv_vblock_fwd: null buffer"); return -1; }
+    const VLayout L = vlayout(d);
+    if ((long long)L.total > d->save_bytes) { egv_set_error("egv_vblock_fwd: save buffer too small"); return -1; }
+    char* sv = (char*)d->save;
+    void* st = d->stream;
+    Bump ws(d->ws, d->ws_bytes);
+    Divided dvt{dt, d->B, d->F, d->N, d->H, D, S, M, false}, dvs{dt, d->B, d->F, d->N, d->H, D, S, M, true};
+    long long awb = dvs.ws_bytes();
+    Plain px{dt, d->B, d->H, D, S, d->L, 0.125f, 0.f, 0u, d->y_mask};
+    if (fused && px.ws_bytes() > awb) awb = px.ws_bytes();
+    void* aws = ws.take((size_t)awb);
+    if (!ws.ok()) { egv_set_error("egv_vblock_fwd: workspace too small"); return -1; }
+
+    // temporal attention (video_transformer.py:217-218): x + proj(attn(qkv(norm3 x)))
+    BCHK(egv_layernorm_fwd(dt, d->x, sv + L.h3, d->ln_g[VL_NORM3], d->ln_b[VL_NORM3], (float*)(sv + L.stats3), M, D, d->eps, st));
+    BCHK(lin_fwd(dt, M, 3 * D, D, sv + L.h3, d->w[VW_TQKV], d->b[VW_TQKV], sv + L.qkv_t, 0, nullptr, nullptr, nullptr, nullptr, st));
+    BCHK(dvt.fwd(sv + L.qkv_t, sv + L.tctx, (float*)(sv + L.lse_t), aws, awb, st));
+    BCHK(lin_fwd(dt, M, D, D, sv + L.tctx, d->w[VW_TPROJ], d->b[VW_TPROJ], sv + L.tr, 0, nullptr, d->x, nullptr, nullptr, st));
+    // spatial attention (:219-222): residual from x, not from the time residual
+    BCHK(egv_layernorm_fwd(dt, sv + L.tr, sv + L.h1, d->ln_g[VL_NORM1], d->ln_b[VL_NORM1], (float*)(sv + L.stats1), M, D, d->eps, st));
+    BCHK(lin_fwd(dt, M, 3 * D, D, sv + L.h1, d->w[VW_SQKV], d->b[VW_SQKV], sv + L.qkv_s, 0, nullptr, nullptr, nullptr, nullptr, st));
+    BCHK(dvs.fwd(sv + L.qkv_s, sv + L.sctx, (float*)(sv + L.lse_s), aws, awb, st));
+    if (!fused) {
+        BCHK(lin_fwd(dt, M, D, D, sv + L.sctx, d->w[VW_SPROJ], d->b[VW_SPROJ], sv + L.sr, 0, nullptr, d->x, nullptr, nullptr, st));
+    } else {
+        // image-to-text cross attention (:155-185): s = proj(ctx); q from norm_i2t_i(s), k|v from the text states; x + s + alpha*proj_i2t(o)
+        const int BL = d->B * d->L;
+        BCHK(lin_fwd(dt, M, D, D, sv + L.sctx, d->w[VW_SPROJ], d->b[VW_SPROJ], sv + L.s, 0, nullptr, nullptr, nullptr, nullptr, st));
+        BCHK(lin_fwd(dt, BL, 2 * D, D, d->y, d->w[VW_KV_I2T], d->b[VW_KV_I2T], sv + L.kv, 0, nullptr, nullptr, nullptr, nullptr, st));
+        BCHK(egv_layernorm_fwd(dt, sv + L.s, sv + L.hs, d->ln_g[VL_NORM_I2T], d->ln_b[VL_NORM_I2T], (float*)(sv + L.stats_i), M, D, d->eps, st));
+        BCHK(lin_fwd(dt, M, D, D, sv + L.hs, d->w[VW_Q_I2T], d->b[VW_Q_I2T], sv + L.q, 0, nullptr, nullptr, nullptr, nullptr, st));
+        BCHK(px.fwd(sv + L.q, D, sv + L.kv, at(sv + L.kv, (size_t)D * esz(dt)), 2 * D, sv + L.o, (float*)(sv + L.lse_x), aws, awb, st));
+        BCHK(lin_fwd(dt, M, D, D, sv + L.o, d->w[VW_PROJ_I2T], d->b[VW_PROJ_I2T], sv + L.sr, 0, d->alpha, sv + L.s, d->x, sv + L.pg, st));
+    }
+    // MLP (:226): sr + fc2(gelu(fc1(norm2 sr)))
+    BCHK(egv_layernorm_fwd(dt, sv + L.sr, sv + L.h2, d->ln_g[VL_NORM2], d->ln_b[VL_NORM2], (float*)(sv + L.stats2), M, D, d->eps, st));
+    BCHK(lin_fwd(dt, M, Hd, D, sv + L.h2, d->w[VW_FC1], d->b[VW_FC1], sv + L.act, EGV_ACT_GELU, nullptr, nullptr, nullptr, sv + L.pre, st));
+    BCHK(lin_fwd(dt, M, D, Hd, sv + L.act, d->w[VW_FC2], d->b[VW_FC2], d->out, 0, nullptr, sv + L.sr, nullptr, nullptr, st));
+    return 0;
+}
+
+extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
+    const int dt = d->dtype;
+    const size_t es = esz(dt);
+    const int S = 1 + d->F * d->N, M = d->B * S, D = d->D, Hd = d->Hd, H = d->H;
+    const bool fused = d->L > 0;
+    if (!(d->x && d->dout && d->dx && d->save && d->ws)) { egv_set_error("egv_vblock_bwd: null buffer"); return -1; }
+    const VLayout L = vlayout(d);
+    const char* sv = (const char*)d->save;
+    void* st = d->stream;
+    Fork fk(d->stream, d->stream2, M);
+    Bump ws(d->ws, d->ws_bytes);
+    Divided dvt{dt, d->B, d->F, d->N, d->H, D, S, M, false}, dvs{dt, d->B, d->F, d->N, d->H, D, S, M, true};
+    long long awb = dvs.ws_bytes();
+    Plain px{dt, d->B, d->H, D, S, d->L, 0.125f, 0.f, 0u, d->y_mask};
+    if (fused && px.ws_bytes() > awb) awb = px.ws_bytes();
+    void* aws = ws.take((size_t)awb);
+    long long wgb = 0;
+    {
+        auto mx = [&](long long v) { if (v > wgb) wgb = v; };
+        mx(egv_gemm_wgrad_workspace_bytes(3 * D, D, M)); mx(egv_gemm_wgrad_workspace_bytes(D, D, M));
+        mx(egv_gemm_wgrad_workspace_bytes(Hd, D, M)); mx(egv_gemm_wgrad_workspace_bytes(D, Hd, M));
+        if (fused) mx(egv_gemm_wgrad_workspace_bytes(2 * D, D, d->B * d->L));
+    }
+    void* wgw = ws.take((size_t)wgb);                       // weight-gradient slabs: the side stream runs them one after another
+    void* lnw = ws.take((size_t)egv_layernorm_bwd_workspace_bytes(M, D));
+    void* dpre = ws.take((size_t)M * Hd * es);
+    void* dh2 = ws.take((size_t)M * D * es);
+    void* d_sr = ws.take((size_t)M * D * es);
+    void* d_sctx = ws.take((size_t)M * D * es);
+    void* dqkv_s = ws.take((size_t)M * 3 * D * es);
+    void* dh1 = ws.take((size_t)M * D * es);
+    void* d_tr = ws.take((size_t)M * D * es);
+    void* d_tctx = ws.take((size_t)M * D * es);
+    void* dqkv_t = ws.take((size_t)M * 3 * D * es);
+    void* dh3 = ws.take((size_t)M * D * es);
+    float* delta_s = (float*)ws.take((size_t)M * H * 4);
+    float* delta_t = (float*)ws.take((size_t)M * H * 4);
+    void *d_s = nullptr, *dhs = nullptr, *dq = nullptr, *d_o = nullptr, *dkv = nullptr;
+    float* delta_x = nullptr;
+    if (fused) {
+        d_s = ws.take((size_t)M * D * es); dhs = ws.take((size_t)M * D * es); dq = ws.take((size_t)M * D * es); d_o = ws.take((size_t)M * D * es);
+        dkv = ws.take((size_t)d->B * d->L * 2 * D * es);
+        delta_x = (float*)ws.take((size_t)M * H * 4);
+    }
+    void* dotw = ws.take(4096);
+    if (!ws.ok()) { egv_set_error("egv_vblock_bwd: workspace too small (%zu > %zu)", ws.off, ws.cap); return -1; }
+    auto wgrad = [&](int N, int K, const void* dz, const void* x, int w, const float* gate, int rows) -> int {
+        return lin_wgrad(dt, rows, N, K, dz, N, x, d->dw[w], d->db[w], gate, wgw, wgb, fk.begin());
+    };
+
+    // ---- MLP: out = sr + fc2(gelu(pre)), pre = fc1(h2)
+    BCHK(wgrad(D, Hd, d->dout, sv + L.act, VW_FC2, nullptr, M));
+    BCHK(lin_dgrad(dt, M, D, Hd, d->dout, d->w[VW_FC2], d->wt[VW_FC2], dpre, nullptr, sv + L.pre, EGV_ACT_GELU, st));
+    BCHK(wgrad(Hd, D, dpre, sv + L.h2, VW_FC1, nullptr, M));
+    BCHK(lin_dgrad(dt, M, Hd, D, dpre, d->w[VW_FC1], d->wt[VW_FC1], dh2, nullptr, nullptr, 0, st));
+    // d_sr = LN2'(dh2) + dout (skip path of the MLP residual)
+    BCHK(egv_layernorm_bwd2(dt, dh2, sv + L.sr, (const float*)(sv + L.stats2), d->ln_g[VL_NORM2], d->dout, nullptr, d_sr, d->dln_g[VL_NORM2],
+                            d->dln_b[VL_NORM2], M, D, lnw, st));
+    const void* d_sproj_out = d_sr;                          // gradient at the output of attn.proj
+    if (fused) {
+        // sr = alpha * P + s + x, P = proj_i2t(o) (saved as pg)
+        const int BL = d->B * d->L;
+        BCHK(egv_dot(dt, d_sr, sv + L.pg, (long long)M * D, d->dalpha, 1.0f, dotw, st));
+        BCHK(wgrad(D, D, d_sr, sv + L.o, VW_PROJ_I2T, d->alpha, M));
+        BCHK(lin_dgrad(dt, M, D, D, d_sr, d->w[VW_PROJ_I2T], d->wt[VW_PROJ_I2T], d_o, d->alpha, nullptr, 0, st));
+        BCHK(px.bwd(sv + L.q, D, sv + L.kv, at(sv + L.kv, (size_t)D * es), 2 * D, sv + L.o, (float*)const_cast<char*>(sv + L.lse_x), d_o, dq, D, dkv,
+                    at(dkv, (size_t)D * es), 2 * D, delta_x, aws, awb, st));
+        BCHK(wgrad(D, D, dq, sv + L.hs, VW_Q_I2T, nullptr, M));
+        BCHK(lin_dgrad(dt, M, D, D, dq, d->w[VW_Q_I2T], d->wt[VW_Q_I2T], dhs, nullptr, nullptr, 0, st));
+        BCHK(egv_layernorm_bwd2(dt, dhs, sv + L.s, (const float*)(sv + L.stats_i), d->ln_g[VL_NORM_I2T], d_sr, nullptr, d_s, d->dln_g[VL_NORM_I2T],
+                                d->dln_b[VL_NORM_I2T], M, D, lnw, st));
+        BCHK(lin_wgrad(dt, BL, 2 * D, D, dkv, 2 * D, d->y, d->dw[VW_KV_I2T], d->db[VW_KV_I2T], nullptr, wgw, wgb, fk.begin()));
+        if (d->dy) BCHK(lin_dgrad(dt, BL, 2 * D, D, dkv, d->w[VW_KV_I2T], d->wt[VW_KV_I2T], d->dy, nullptr, nullptr, 0, st));
+        d_sproj_out = d_s;
+    }
+    // ---- spatial attention
+    BCHK(wgrad(D, D, d_sproj_out, sv + L.sctx, VW_SPROJ, nullptr, M));
+    BCHK(lin_dgrad(dt, M, D, D, d_sproj_out, d->w[VW_SPROJ], d->wt[VW_SPROJ], d_sctx, nullptr, nullptr, 0, st));
+    BCHK(dvs.bwd(sv + L.qkv_s, sv + L.sctx, (float*)const_cast<char*>(sv + L.lse_s), d_sctx, dqkv_s, delta_s, aws, awb, st));
+    BCHK(wgrad(3 * D, D, dqkv_s, sv + L.h1, VW_SQKV, nullptr, M));
+    BCHK(lin_dgrad(dt, M, 3 * D, D, dqkv_s, d->w[VW_SQKV], d->wt[VW_SQKV], dh1, nullptr, nullptr, 0, st));
+    BCHK(egv_layernorm_bwd2(dt, dh1, sv + L.tr, (const float*)(sv + L.stats1), d->ln_g[VL_NORM1], nullptr, nullptr, d_tr, d->dln_g[VL_NORM1],
+                            d->dln_b[VL_NORM1], M, D, lnw, st));
+    // ---- temporal attention
+    BCHK(wgrad(D, D, d_tr, sv + L.tctx, VW_TPROJ, nullptr, M));
+    BCHK(lin_dgrad(dt, M, D, D, d_tr, d->w[VW_TPROJ], d->wt[VW_TPROJ], d_tctx, nullptr, nullptr, 0, st));
+    BCHK(dvt.bwd(sv + L.qkv_t, sv + L.tctx, (float*)const_cast<char*>(sv + L.lse_t), d_tctx, dqkv_t, delta_t, aws, awb, st));
+    BCHK(wgrad(3 * D, D, dqkv_t, sv + L.h3, VW_TQKV, nullptr, M));
+    BCHK(lin_dgrad(dt, M, 3 * D, D, dqkv_t, d->w[VW_TQKV], d->wt[VW_TQKV], dh3, nullptr, nullptr, 0, st));
+    // dx = LN3'(dh3) + d_sr + d_tr: x feeds norm3, the time residual and the space residual
+    BCHK(egv_layernorm_bwd2(dt, dh3, d->x, (const float*)(sv + L.stats3), d->ln_g[VL_NORM3], d_sr, d_tr, d->dx, d->dln_g[VL_NORM3],
+                            d->dln_b[VL_NORM3], M, D, lnw, st));
+    fk.join();
+    return 0;
+}
+
+// =====================================================================================================================
+// RobertaLayer
+// =====================================================================================================================
+namespace {
+enum { TW_Q = 0, TW_K, TW_V, TW_AO, TW_FC1, TW_FC2, TW_CQ, TW_CK, TW_CV, TW_CO };
+enum { TL_ATT = 0, TL_OUT };
+
+struct TLayout {
+    size_t q, k, v, ctx, lse, a0, a0d, cq, ck, cv, cctx, lse_c, pg, a_pre, stats0, a, pre, act, f0, f_pre, stats1;
+    size_t total;
+};
+
+TLayout tlayout(const egv_tlayer_desc* d) {
+    TLayout L{};
+    Bump b(nullptr, 0);
+    const size_t es = esz(d->dtype);
+    const size_t BL = (size_t)d->B * d->L, BS = (size_t)d->B * d->S, D = d->D, Hd = d->Hd, H = d->H;
+    const bool fused = d->S > 0, drop = d->drop_p > 0.f;
+    auto T = [&](size_t n) { return b.take_off(n); };
+    L.q = T(BL * D * es); L.k = T(BL * D * es); L.v = T(BL * D * es); L.ctx = T(BL * D * es); L.lse = T(BL * H * 4);
+    if (fused || drop) L.a0 = T(BL * D * es);
+    if (fused && drop) L.a0d = T(BL * D * es);
+    if (fused) {
+        L.cq = T(BL * D * es); L.ck = T(BS * D * es); L.cv = T(BS * D * es); L.cctx = T(BL * D * es); L.lse_c = T(BL * H * 4);
+        L.pg = T(BL * D * es);
+    }
+    L.a_pre = T(BL * D * es); L.stats0 = T(BL * 8); L.a = T(BL * D * es); L.pre = T(BL * Hd * es); L.act = T(BL * Hd * es);
+    if (drop) L.f0 = T(BL * D * es);
+    L.f_pre = T(BL * D * es); L.stats1 = T(BL * 8);
+    L.total = al(b.off);
+    return L;
+}
+
+struct TPlan {               // attention problems of one layer
+    Plain self, cross;
+    long long awb;
+};
+TPlan tplan(const egv_tlayer_desc* d) {
+    TPlan p{};
+    const bool drop = d->drop_p > 0.f;
+    p.self = Plain{d->dtype, d->B, d->H, d->D, d->L, d->L, 0.125f, drop ? d->drop_p : 0.f, d->seeds[0], d->mask};
+    p.cross = Plain{d->dtype, d->B, d->H, d->D, d->L, d->S, 0.125f, drop ? d->drop_p : 0.f, d->seeds[2], nullptr};
+    p.awb = p.self.ws_bytes();
+    if (d->S > 0 && p.cross.ws_bytes() > p.awb) p.awb = p.cross.ws_bytes();
+    return p;
+}
+}  // namespace
+
+extern "C" long long egv_tlayer_save_bytes(const egv_tlayer_desc* d) { return (long long)tlayout(d).total; }
+
+extern "C" long long egv_tlayer_ws_bytes(const egv_tlayer_desc* d, int backward) {
+    const size_t es = esz(d->dtype);
+    const size_t BL = (size_t)d->B * d->L, BS = (size_t)d->B * d->S, D = d->D, Hd = d->Hd, H = d->H;
+    size_t tot = al((size_t)tplan(d).awb) + al(BL * D * es) + 4096;
+    if (backward) {
+        long long wg = 0;
+        auto mx = [&](long long v) { if (v > wg) wg = v; };
+        mx(egv_gemm_wgrad_workspace_bytes((int)D, (int)D, (int)BL)); mx(egv_gemm_wgrad_workspace_bytes((int)Hd, (int)D, (int)BL));
+        mx(egv_gemm_wgrad_workspace_bytes((int)D, (int)Hd, (int)BL));
+        if (d->S > 0) mx(egv_gemm_wgrad_workspace_bytes((int)D, (int)D, (int)BS));
+        tot += al((size_t)wg) + al((size_t)egv_layernorm_bwd_workspace_bytes((int)BL, (int)D));
+        tot += 17 * al(BL * D * es) + al(BL * Hd * es) + 2 * al(BL * H * 4) + 4096;
+        if (d->S > 0) tot += 3 * al(BS * D * es) + 4096;
+    }
+    return (long long)tot + 65536;
+}
+
+extern "C" int egv_tlayer_fwd(const egv_tlayer_desc* d) {
+    const int dt = d->dtype;
+    const int BL = d->B * d->L, BS = d->B * d->S, D = d->D, Hd = d->Hd;
+    const bool fused = d->S > 0, drop = d->drop_p > 0.f;
+    const float p = d->drop_p;
+    if (!(d->hid && d->out && d->save && d->ws)) { egv_set_error("egv_tlayer_fwd: null buffer"); return -1; }
+    const TLayout L = tlayout(d);
+    if ((long long)L.total > d->save_bytes) { egv_set_error("egv_tlayer_fwd: save buffer too small"); return -1; }
+    char* sv = (char*)d->save;
+    void* st = d->stream;
+    const TPlan tp = tplan(d);
+    Bump ws(d->ws, d->ws_bytes);
+    void* aws = ws.take((size_t)tp.awb);
+    if (!ws.ok()) { egv_set_error("egv_tlayer_fwd: workspace too small"); return -1; }
+    const long long n = (long long)BL * D;
+
+    BCHK(lin_fwd(dt, BL, D, D, d->hid, d->w[TW_Q], d->b[TW_Q], sv + L.q, 0, nullptr, nullptr, nullptr, nullptr, st));
+    BCHK(lin_fwd(dt, BL, D, D, d->hid, d->w[TW_K], d->b[TW_K], sv + L.k, 0, nullptr, nullptr, nullptr, nullptr, st));
+    BCHK(lin_fwd(dt, BL, D, D, d->hid, d->w[TW_V], d->b[TW_V], sv + L.v, 0, nullptr, nullptr, nullptr, nullptr, st));
+    BCHK(tp.self.fwd(sv + L.q, D, sv + L.k, sv + L.v, D, sv + L.ctx, (float*)(sv + L.lse), aws, tp.awb, st));
+    if (!fused) {
+        if (!drop) {
+            BCHK(lin_fwd(dt, BL, D, D, sv + L.ctx, d->w[TW_AO], d->b[TW_AO], sv + L.a_pre, 0, nullptr, d->hid, nullptr, nullptr, st));   // dense(ctx) + hidden
+        } else {
+            BCHK(lin_fwd(dt, BL, D, D, sv + L.ctx, d->w[TW_AO], d->b[TW_AO], sv + L.a0, 0, nullptr, nullptr, nullptr, nullptr, st));
+            BCHK(egv_dropout_add(dt, sv + L.a0, d->hid, nullptr, sv + L.a_pre, n, p, d->seeds[1], st));
+        }
+    } else {
+        BCHK(lin_fwd(dt, BL, D, D, sv + L.ctx, d->w[TW_AO], d->b[TW_AO], sv + L.a0, 0, nullptr, nullptr, nullptr, nullptr, st));
+        const char* a0x = sv + L.a0;
+        if (drop) {
+            BCHK(egv_dropout_add(dt, sv + L.a0, nullptr, nullptr, sv + L.a0d, n, p, d->seeds[1], st));
+            a0x = sv + L.a0d;
+        }
+        BCHK(lin_fwd(dt, BL, D, D, a0x, d->w[TW_CQ], d->b[TW_CQ], sv + L.cq, 0, nullptr, nullptr, nullptr, nullptr, st));
+        BCHK(lin_fwd(dt, BS, D, D, d->enc, d->w[TW_CK], d->b[TW_CK], sv + L.ck, 0, nullptr, nullptr, nullptr, nullptr, st));
+        BCHK(lin_fwd(dt, BS, D, D, d->enc, d->w[TW_CV], d->b[TW_CV], sv + L.cv, 0, nullptr, nullptr, nullptr, nullptr, st));
+        BCHK(tp.cross.fwd(sv + L.cq, D, sv + L.ck, sv + L.cv, D, sv + L.cctx, (float*)(sv + L.lse_c), aws, tp.awb, st));
+        if (!drop) {
+            // alpha_t2i * dense(cctx) + a0 + hidden (roberta.py:486-488)
+            BCHK(lin_fwd(dt, BL, D, D, sv + L.cctx, d->w[TW_CO], d->b[TW_CO], sv + L.a_pre, 0, d->alpha, a0x, d->hid, sv + L.pg, st));
+        } else {
+            // the gate commutes with the keep mask: y = alpha * dense(cctx) in the GEMM epilogue (pre-gate value saved), then dropout + adds
+            void* y = ws.take((size_t)n * esz(dt));
+            if (!ws.ok()) { egv_set_error("egv_tlayer_fwd: workspace too small"); return -1; }
+            BCHK(lin_fwd(dt, BL, D, D, sv + L.cctx, d->w[TW_CO], d->b[TW_CO], y, 0, d->alpha, nullptr, nullptr, sv + L.pg, st));
+            BCHK(egv_dropout_add(dt, y, a0x, d->hid, sv + L.a_pre, n, p, d->seeds[3], st));
+        }
+    }
+    BCHK(egv_layernorm_fwd(dt, sv + L.a_pre, sv + L.a, d->ln_g[TL_ATT], d->ln_b[TL_ATT], (float*)(sv + L.stats0), BL, D, d->eps, st));
+    BCHK(lin_fwd(dt, BL, Hd, D, sv + L.a, d->w[TW_FC1], d->b[TW_FC1], sv + L.act, EGV_ACT_GELU, nullptr, nullptr, nullptr, sv + L.pre, st));
+    if (!drop) {
+        BCHK(lin_fwd(dt, BL, D, Hd, sv + L.act, d->w[TW_FC2], d->b[TW_FC2], sv + L.f_pre, 0, nullptr, sv + L.a, nullptr, nullptr, st));
+    } else {
+        BCHK(lin_fwd(dt, BL, D, Hd, sv + L.act, d->w[TW_FC2], d->b[TW_FC2], sv + L.f0, 0, nullptr, nullptr, nullptr, nullptr, st));
+        BCHK(egv_dropout_add(dt, sv + L.f0, sv + L.a, nullptr, sv + L.f_pre, n, p, d->seeds[4], st));
+    }
+    BCHK(egv_layernorm_fwd(dt, sv + L.f_pre, d->out, d->ln_g[TL_OUT], d->ln_b[TL_OUT], (float*)(sv + L.stats1), BL, D, d->eps, st));
+    return 0;
+}
+
+extern "C" int egv_tlayer_bwd(const egv_tlayer_desc* d) {
+    const int dt = d->dtype;
+    const size_t es = esz(dt);
+    const int BL = d->B * d->L, BS = d->B * d->S, D = d->D, Hd = d->Hd, H = d->H;
+    const bool fused = d->S > 0, drop = d->drop_p > 0.f;
+    const float p = d->drop_p;
+    if (!(d->hid && d->dout && d->dhid && d->save && d->ws)) { egv_set_error("egv_tlayer_bwd: null buffer"); return -1; }
+    const TLayout L = tlayout(d);
+    const char* sv = (const char*)d->save;
+    void* st = d->stream;
+    Fork fk(d->stream, d->stream2, fused ? BS : BL);
+    const TPlan tp = tplan(d);
+    Bump ws(d->ws, d->ws_bytes);
+    void* aws = ws.take((size_t)tp.awb);
+    long long wgb = 0;
+    {
+        auto mx = [&](long long v) { if (v > wgb) wgb = v; };
+        mx(egv_gemm_wgrad_workspace_bytes(D, D, BL)); mx(egv_gemm_wgrad_workspace_bytes(Hd, D, BL)); mx(egv_gemm_wgrad_workspace_bytes(D, Hd, BL));
+        if (fused) mx(egv_gemm_wgrad_workspace_bytes(D, D, BS));
+    }
+    void* wgw = ws.take((size_t)wgb);
+    void* lnw = ws.take((size_t)egv_layernorm_bwd_workspace_bytes(BL, D));
+    const size_t nb = (size_t)BL * D * es;
+    void* df_pre = ws.take(nb); void* df0 = ws.take(nb); void* dpre = ws.take((size_t)BL * Hd * es); void* da = ws.take(nb);
+    void* da_pre = ws.take(nb); void* da0 = ws.take(nb); void* dctx = ws.take(nb);
+    void* dq = ws.take(nb); void* dk = ws.take(nb); void* dv = ws.take(nb); void* t1 = ws.take(nb); void* t2 = ws.take(nb);
+    float* delta = (float*)ws.take((size_t)BL * H * 4);
+    void *dyg = nullptr, *dcctx = nullptr, *dcq = nullptr, *dck = nullptr, *dcv = nullptr, *da0d = nullptr, *te = nullptr;
+    float* delta_c = nullptr;
+    if (fused) {
+        dyg = ws.take(nb); dcctx = ws.take(nb); dcq = ws.take(nb); da0d = ws.take(nb);
+        dck = ws.take((size_t)BS * D * es); dcv = ws.take((size_t)BS * D * es); te = ws.take((size_t)BS * D * es);
+        delta_c = (float*)ws.take((size_t)BL * H * 4);
+    }
+    void* dotw = ws.take(4096);
+    if (!ws.ok()) { egv_set_error("egv_tlayer_bwd: workspace too small (%zu > %zu)", ws.off, ws.cap); return -1; }
+    const long long n = (long long)BL * D;
+    auto wgrad = [&](int rows, int N, int K, const void* dz, const void* x, int w, const float* gate) -> int {
+        return lin_wgrad(dt, rows, N, K, dz, N, x, d->dw[w], d->db[w], gate, wgw, wgb, fk.begin());
+    };
+    // dx = dz W + res (dgrad whose output also receives a skip gradient)
+    auto dgrad_res = [&](int rows, int N, int K, const void* dz, int w, void* dx, const void* res, const float* gate) -> int {
+        if (d->wt[w]) return egv_gemm(dt, 0, 0, rows, K, N, dz, N, d->wt[w], N, dx, K, 0, nullptr, 0, gate, res, nullptr, nullptr, nullptr, 0, K, 1.0f, st);
+        return egv_gemm(dt, 0, 1, rows, K, N, dz, N, d->w[w], K, dx, K, 0, nullptr, 0, gate, res, nullptr, nullptr, nullptr, 0, K, 1.0f, st);
+    };
+
+    // out = LN(f_pre)
+    BCHK(egv_layernorm_bwd2(dt, d->dout, sv + L.f_pre, (const float*)(sv + L.stats1), d->ln_g[TL_OUT], nullptr, nullptr, df_pre, d->dln_g[TL_OUT],
+                            d->dln_b[TL_OUT], BL, D, lnw, st));
+    // f_pre = [dropout](fc2(act)) + a
+    const void* dfc2 = df_pre;
+    if (drop) {
+        BCHK(egv_dropout_add(dt, df_pre, nullptr, nullptr, df0, n, p, d->seeds[4], st));
+        dfc2 = df0;
+    }
+    BCHK(wgrad(BL, D, Hd, dfc2, sv + L.act, TW_FC2, nullptr));
+    BCHK(lin_dgrad(dt, BL, D, Hd, dfc2, d->w[TW_FC2], d->wt[TW_FC2], dpre, nullptr, sv + L.pre, EGV_ACT_GELU, st));
+    BCHK(wgrad(BL, Hd, D, dpre, sv + L.a, TW_FC1, nullptr));
+    BCHK(dgrad_res(BL, Hd, D, dpre, TW_FC1, da, df_pre, nullptr));                         // + skip gradient of the residual a
+    BCHK(egv_layernorm_bwd2(dt, da, sv + L.a_pre, (const float*)(sv + L.stats0), d->ln_g[TL_ATT], nullptr, nullptr, da_pre, d->dln_g[TL_ATT],
+                            d->dln_b[TL_ATT], BL, D, lnw, st));
+    // a_pre = [dropout](...) + hid  (+ a0 in the fused form): da_pre flows to hid unchanged
+    const void* d_ao = da_pre;                                                             // gradient at the output of attention.output.dense
+    if (!fused) {
+        if (drop) {
+            BCHK(egv_dropout_add(dt, da_pre, nullptr, nullptr, da0, n, p, d->seeds[1], st));
+            d_ao = da0;
+        }
+    } else {
+        const void* dy_ = da_pre;
+        if (drop) {
+            BCHK(egv_dropout_add(dt, da_pre, nullptr, nullptr, dyg, n, p, d->seeds[3], st));
+            dy_ = dyg;
+        }
+        const char* a0x = drop ? sv + L.a0d : sv + L.a0;
+        BCHK(egv_dot(dt, dy_, sv + L.pg, n, d->dalpha, 1.0f, dotw, st));
+        BCHK(wgrad(BL, D, D, dy_, sv + L.cctx, TW_CO, d->alpha));
+        BCHK(lin_dgrad(dt, BL, D, D, dy_, d->w[TW_CO], d->wt[TW_CO], dcctx, d->alpha, nullptr, 0, st));
+        BCHK(tp.cross.bwd(sv + L.cq, D, sv + L.ck, sv + L.cv, D, sv + L.cctx, (float*)const_cast<char*>(sv + L.lse_c), dcctx, dcq, D, dck, dcv, D, delta_c,
+                          aws, tp.awb, st));
+        BCHK(wgrad(BL, D, D, dcq, a0x, TW_CQ, nullptr));
+        BCHK(dgrad_res(BL, D, D, dcq, TW_CQ, da0d, da_pre, nullptr));                       // a0 also feeds the residual
+        BCHK(wgrad(BS, D, D, dck, d->enc, TW_CK, nullptr));
+        BCHK(wgrad(BS, D, D, dcv, d->enc, TW_CV, nullptr));
+        if (d->denc) {
+            BCHK(lin_dgrad(dt, BS, D, D, dck, d->w[TW_CK], d->wt[TW_CK], te, nullptr, nullptr, 0, st));
+            BCHK(dgrad_res(BS, D, D, dcv, TW_CV, d->denc, te, nullptr));
+        }
+        d_ao = da0d;
+        if (drop) {
+            BCHK(egv_dropout_add(dt, da0d, nullptr, nullptr, da0, n, p, d->seeds[1], st));
+            d_ao = da0;
+        }
+    }
+    BCHK(wgrad(BL, D, D, d_ao, sv + L.ctx, TW_AO, nullptr));
+    BCHK(lin_dgrad(dt, BL, D, D, d_ao, d->w[TW_AO], d->wt[TW_AO], dctx, nullptr, nullptr, 0, st));
+    BCHK(tp.self.bwd(sv + L.q, D, sv + L.k, sv + L.v, D, sv + L.ctx, (float*)const_cast<char*>(sv + L.lse), dctx, dq, D, dk, dv, D, delta, aws, tp.awb, st));
+    BCHK(wgrad(BL, D, D, dq, d->hid, TW_Q, nullptr));
+    BCHK(wgrad(BL, D, D, dk, d->hid, TW_K, nullptr));
+    BCHK(wgrad(BL, D, D, dv, d->hid, TW_V, nullptr));
+    BCHK(dgrad_res(BL, D, D, dq, TW_Q, t1, da_pre, nullptr));
+    BCHK(dgrad_res(BL, D, D, dk, TW_K, t2, t1, nullptr));
+    BCHK(dgrad_res(BL, D, D, dv, TW_V, d->dhid, t2, nullptr));
+    fk.join();
+    return 0;
+}

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                            const T* __restrict__ add, T* __restrict__ dx,
+                                                            const T* __restrict__ add, const T* __restrict__ add2, T* __restrict__ dx,
                                                             float* __restrict__ partial, int M, int D, int rows_per_block) {
     __shared__ float red[4][2][LN_MAXV * 256];
     const int lane = threadIdx.x & 63;
@@ -118,6 +118,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                 if (add) {
                     float a[4];
                     ld4(add + (size_t)row * D + c, a);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += a[e];
+                }
+                if (add2) {
+                    float a[4];
+                    ld4(add2 + (size_t)row * D + c, a);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] += a[e];
                 }
@@ -319,9 +325,19 @@ static inline int ln_bwd_blocks(int M) {
 
 extern "C" long long egv_layernorm_bwd_workspace_bytes(int M, int D) { return (long long)ln_bwd_blocks(M) * 2 * D * 4; }
 
+extern "C" int egv_layernorm_bwd2(int dtype, const void* dy, const void* x, const float* stats, const float* gamma,
+                                  const void* add, const void* add2, void* dx, float* dgamma, float* dbeta, int M, int D,
+                                  void* workspace, void* stream);
 extern "C" int egv_layernorm_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma,
                                  const void* add, void* dx, float* dgamma, float* dbeta, int M, int D, void* workspace,
                                  void* stream) {
+    return egv_layernorm_bwd2(dtype, dy, x, stats, gamma, add, nullptr, dx, dgamma, dbeta, M, D, workspace, stream);
+}
+// dx = LN'(dy) + add + add2: the second addend is the other skip path of a divided space-time block (x feeds the time
+// residual AND the space residual, video_transformer.py:218,222)
+extern "C" int egv_layernorm_bwd2(int dtype, const void* dy, const void* x, const float* stats, const float* gamma,
+                                  const void* add, const void* add2, void* dx, float* dgamma, float* dbeta, int M, int D,
+                                  void* workspace, void* stream) {
     EGV_CHECK(D % 4 == 0 && D <= LN_MAXV * 256, "egv_layernorm_bwd: D=%d unsupported", D);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nb = ln_bwd_blocks(M);
@@ -330,10 +346,10 @@ extern "C" int egv_layernorm_bwd(int dtype, const void* dy, const void* x, const
     float* partial = (float*)workspace;
     if (dtype == EGV_BF16)
         hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(nb2), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, stats, gamma,
-                           (const bf16_t*)add, (bf16_t*)dx, partial, M, D, rpb);
+                           (const bf16_t*)add, (const bf16_t*)add2, (bf16_t*)dx, partial, M, D, rpb);
     else
         hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(nb2), dim3(256), 0, st, (const float*)dy, (const float*)x, stats, gamma,
-                           (const float*)add, (float*)dx, partial, M, D, rpb);
+                           (const float*)add, (const float*)add2, (float*)dx, partial, M, D, rpb);
     EGV_LAUNCH_CHECK();
     // partial layout [nb2][2][D]: columns 0..D-1 = dgamma, D..2D-1 = dbeta
     if (dbeta == dgamma + D) {                  // caller keeps [dgamma ; dbeta] in one buffer: one reduction over 2D columns

@@ -17,6 +17,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib as L
+from . import _lib as L_
 from ._lib import lib, check, AttnDesc
 
 ACT = {'none': L.ACT_NONE, 'gelu': L.ACT_GELU, 'relu': L.ACT_RELU, 'tanh': L.ACT_TANH}
@@ -702,6 +703,190 @@ class DropoutAddFn(Function):
 
 def dropout_add(x, p, seed, r1=None, r2=None):
     return DropoutAddFn.apply(x, r1, r2, p, seed)
+
+
+# ---- block-level calls (csrc/egv_block.cpp): one C-ABI call per SpaceTimeBlock / RobertaLayer and direction -----------------
+def _side_stream_ptr():
+    """raw handle of the weight-gradient companion stream of the current stream (None: single-stream mode)"""
+    if os.environ.get('EGV_NO_OVERLAP'):
+        return None
+    cur = torch.cuda.current_stream()
+    key = (cur.device.index, cur.cuda_stream)
+    st = _wg_streams.get(key)
+    if st is None:
+        st = _wg_streams[key] = torch.cuda.Stream(device=cur.device)
+    return st.cuda_stream
+
+
+def _fill_weights(d, weights, dtype):
+    for i, w in enumerate(weights):
+        d.w[i] = _p(compute_weight(w, dtype))
+        wt = compute_weight_t(w, dtype)
+        d.wt[i] = _p(wt) if wt is not None else None
+
+
+class _GradPack:
+    """one flat fp32 buffer holding the gradients of every parameter of a block call; views are handed to autograd"""
+
+    def __init__(self, params, device):
+        sizes = [p.numel() for p in params]
+        self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+        self.views = []
+        off = 0
+        for p, n in zip(params, sizes):
+            self.views.append(self.flat[off:off + n].view(p.shape))
+            off += n
+
+
+class VideoBlockFn(Function):
+    """SpaceTimeBlock.forward (video_transformer.py:214-228).  params = [W, b] x 6 (timeattn.qkv, timeattn.proj, attn.qkv,
+    attn.proj, mlp.fc1, mlp.fc2), [gamma, beta] x 3 (norm3, norm1, norm2) and, for a fused block, [W, b] x 3 (qkv_text_i2t,
+    qkv_i2t, proj_i2t), norm_i2t_i gamma / beta, alpha_i2t."""
+
+    @staticmethod
+    def _desc(cfg, x, y, y_mask, params):
+        B, Fr, N, H, Hd, eps, L = cfg
+        fused = L > 0
+        d = L_.VBlockDesc()
+        d.dtype, d.B, d.F, d.N, d.H, d.D, d.Hd, d.L, d.eps = _dt(x), B, Fr, N, H, x.shape[1], Hd, L, eps
+        d.x = _p(x)
+        nw = 9 if fused else 6
+        ws = [params[2 * i] for i in range(6)] + ([params[18 + 2 * i] for i in range(3)] if fused else [])
+        bs = [params[2 * i + 1] for i in range(6)] + ([params[19 + 2 * i] for i in range(3)] if fused else [])
+        _fill_weights(d, ws, x.dtype)
+        for i in range(nw):
+            d.b[i] = _p(bs[i])
+        for i in range(3):
+            d.ln_g[i], d.ln_b[i] = _p(params[12 + 2 * i]), _p(params[13 + 2 * i])
+        if fused:
+            d.ln_g[3], d.ln_b[3] = _p(params[24]), _p(params[25])
+            d.alpha = _p(params[26])
+            d.y, d.y_mask = _p(y), _p(y_mask)
+        d.stream = _st()
+        return d
+
+    @staticmethod
+    def forward(ctx, cfg, x, y, y_mask, *params):
+        _need_gpu(x)
+        assert x.dim() == 2 and x.is_contiguous()
+        d = VideoBlockFn._desc(cfg, x, y, y_mask, params)
+        out = torch.empty_like(x)
+        nsave = lib.egv_vblock_save_bytes(C.byref(d))
+        save = torch.empty(nsave, dtype=torch.uint8, device=x.device)
+        ws = workspace(lib.egv_vblock_ws_bytes(C.byref(d), 0), x.device, slot=2)
+        d.out, d.save, d.save_bytes, d.ws, d.ws_bytes = _p(out), _p(save), nsave, _p(ws), ws.numel()
+        check(lib.egv_vblock_fwd(C.byref(d)), 'egv_vblock_fwd')
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, y, y_mask, save, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y, y_mask, save, *params = ctx.saved_tensors
+        cfg = ctx.cfg
+        fused = cfg[6] > 0
+        dout = dout.contiguous()
+        d = VideoBlockFn._desc(cfg, x, y, y_mask, params)
+        dx = torch.empty_like(x)
+        dy = torch.empty_like(y) if (fused and ctx.needs_input_grad[2]) else None
+        # LayerNorm gradients live as [gamma ; beta] pairs (one reduction launch per LayerNorm): params are ordered that way
+        gp = _GradPack(params, x.device)
+        nwsb = lib.egv_vblock_ws_bytes(C.byref(d), 1)
+        ws = torch.empty(nwsb, dtype=torch.uint8, device=x.device)
+        d.save, d.save_bytes, d.ws, d.ws_bytes = _p(save), save.numel(), _p(ws), nwsb
+        d.dout, d.dx, d.dy = _p(dout), _p(dx), _p(dy)
+        g = gp.views
+        for i in range(6):
+            d.dw[i], d.db[i] = _p(g[2 * i]), _p(g[2 * i + 1])
+        for i in range(3):
+            d.dln_g[i], d.dln_b[i] = _p(g[12 + 2 * i]), _p(g[13 + 2 * i])
+        if fused:
+            for i in range(3):
+                d.dw[6 + i], d.db[6 + i] = _p(g[18 + 2 * i]), _p(g[19 + 2 * i])
+            d.dln_g[3], d.dln_b[3] = _p(g[24]), _p(g[25])
+            d.dalpha = _p(g[26])
+        d.stream2 = _side_stream_ptr()
+        check(lib.egv_vblock_bwd(C.byref(d)), 'egv_vblock_bwd')
+        return (None, dx, dy, None, *g)
+
+
+def video_block(x, params, B, Fr, N, H, Hd, eps, y=None, y_mask=None, L=0):
+    return VideoBlockFn.apply((B, Fr, N, H, Hd, float(eps), L if y is not None else 0), x, y, y_mask, *params)
+
+
+class TextLayerFn(Function):
+    """RobertaLayer.forward (roberta.py:444-505).  params = [W, b] x 6 (query, key, value, attention.output.dense,
+    intermediate.dense, output.dense), [gamma, beta] x 2 (attention.output.LayerNorm, output.LayerNorm) and, for a fused layer,
+    [W, b] x 4 (crossattention_t2i.self.{query,key,value}, crossattention_t2i.output.dense), alpha_t2i."""
+
+    @staticmethod
+    def _desc(cfg, hid, mask, enc, params):
+        B, Lt, H, Hd, eps, S, p, seeds = cfg
+        fused = S > 0
+        d = L_.TLayerDesc()
+        d.dtype, d.B, d.L, d.H, d.D, d.Hd, d.S, d.eps, d.drop_p = _dt(hid), B, Lt, H, hid.shape[1], Hd, S, eps, p
+        for i, sd in enumerate(seeds):
+            d.seeds[i] = sd & 0xFFFFFFFF
+        d.hid, d.mask = _p(hid), _p(mask)
+        nw = 10 if fused else 6
+        ws = [params[2 * i] for i in range(6)] + ([params[16 + 2 * i] for i in range(4)] if fused else [])
+        bs = [params[2 * i + 1] for i in range(6)] + ([params[17 + 2 * i] for i in range(4)] if fused else [])
+        _fill_weights(d, ws, hid.dtype)
+        for i in range(nw):
+            d.b[i] = _p(bs[i])
+        for i in range(2):
+            d.ln_g[i], d.ln_b[i] = _p(params[12 + 2 * i]), _p(params[13 + 2 * i])
+        if fused:
+            d.alpha = _p(params[24])
+            d.enc = _p(enc)
+        d.stream = _st()
+        return d
+
+    @staticmethod
+    def forward(ctx, cfg, hid, mask, enc, *params):
+        _need_gpu(hid)
+        assert hid.dim() == 2 and hid.is_contiguous()
+        d = TextLayerFn._desc(cfg, hid, mask, enc, params)
+        out = torch.empty_like(hid)
+        nsave = lib.egv_tlayer_save_bytes(C.byref(d))
+        save = torch.empty(nsave, dtype=torch.uint8, device=hid.device)
+        ws = workspace(lib.egv_tlayer_ws_bytes(C.byref(d), 0), hid.device, slot=2)
+        d.out, d.save, d.save_bytes, d.ws, d.ws_bytes = _p(out), _p(save), nsave, _p(ws), ws.numel()
+        check(lib.egv_tlayer_fwd(C.byref(d)), 'egv_tlayer_fwd')
+        ctx.cfg = cfg
+        ctx.save_for_backward(hid, mask, enc, save, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        hid, mask, enc, save, *params = ctx.saved_tensors
+        cfg = ctx.cfg
+        fused = cfg[5] > 0
+        dout = dout.contiguous()
+        d = TextLayerFn._desc(cfg, hid, mask, enc, params)
+        dhid = torch.empty_like(hid)
+        denc = torch.empty_like(enc) if (fused and ctx.needs_input_grad[3]) else None
+        gp = _GradPack(params, hid.device)
+        nwsb = lib.egv_tlayer_ws_bytes(C.byref(d), 1)
+        ws = torch.empty(nwsb, dtype=torch.uint8, device=hid.device)
+        d.save, d.save_bytes, d.ws, d.ws_bytes = _p(save), save.numel(), _p(ws), nwsb
+        d.dout, d.dhid, d.denc = _p(dout), _p(dhid), _p(denc)
+        g = gp.views
+        for i in range(6):
+            d.dw[i], d.db[i] = _p(g[2 * i]), _p(g[2 * i + 1])
+        for i in range(2):
+            d.dln_g[i], d.dln_b[i] = _p(g[12 + 2 * i]), _p(g[13 + 2 * i])
+        if fused:
+            for i in range(4):
+                d.dw[6 + i], d.db[6 + i] = _p(g[16 + 2 * i]), _p(g[17 + 2 * i])
+            d.dalpha = _p(g[24])
+        d.stream2 = _side_stream_ptr()
+        check(lib.egv_tlayer_bwd(C.byref(d)), 'egv_tlayer_bwd')
+        return (None, dhid, None, denc, *g)
+
+
+def text_layer(hid, mask, params, B, Lt, H, Hd, eps, enc=None, S=0, drop_p=0.0, seeds=(0, 0, 0, 0, 0, 0)):
+    return TextLayerFn.apply((B, Lt, H, Hd, float(eps), S if enc is not None else 0, float(drop_p), tuple(seeds)), hid, mask, enc, *params)
 
 
 # ---- patch embedding + CLS + positional / temporal embedding ------------------------------------------------

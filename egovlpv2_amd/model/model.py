@@ -249,32 +249,39 @@ class FrozenInTime(nn.Module):
                              self.compute_dtype)
         return x.reshape(B * self.cfg.seq, self.cfg.dim)
 
+    def _block_params(self, kind, i, fused):
+        """parameter tensors of block i in the order the block-level C entry points expect (include/egovlp_hip.h)"""
+        cache = self.__dict__.setdefault('_bp_cache', {})
+        key = (kind, i, fused)
+        lst = cache.get(key)
+        if lst is None:
+            if kind == 'video':
+                pfx = f'video_model.blocks.{i}'
+                names = [f'{pfx}.{m}.{t}' for m in ('timeattn.qkv', 'timeattn.proj', 'attn.qkv', 'attn.proj', 'mlp.fc1', 'mlp.fc2')
+                         for t in ('weight', 'bias')]
+                names += [f'{pfx}.{m}.{t}' for m in ('norm3', 'norm1', 'norm2') for t in ('weight', 'bias')]
+                if fused:
+                    a = pfx + '.attn'
+                    names += [f'{a}.{m}.{t}' for m in ('qkv_text_i2t', 'qkv_i2t', 'proj_i2t') for t in ('weight', 'bias')]
+                    names += [a + '.norm_i2t_i.weight', a + '.norm_i2t_i.bias', a + '.alpha_i2t']
+            else:
+                pfx = f'text_model.encoder.layer.{i}'
+                names = [f'{pfx}.{m}.{t}' for m in ('attention.self.query', 'attention.self.key', 'attention.self.value',
+                                                   'attention.output.dense', 'intermediate.dense', 'output.dense') for t in ('weight', 'bias')]
+                names += [f'{pfx}.{m}.{t}' for m in ('attention.output.LayerNorm', 'output.LayerNorm') for t in ('weight', 'bias')]
+                if fused:
+                    ca = pfx + '.crossattention_t2i'
+                    names += [f'{ca}.{m}.{t}' for m in ('self.query', 'self.key', 'self.value', 'output.dense') for t in ('weight', 'bias')]
+                    names += [pfx + '.alpha_t2i']
+            lst = cache[key] = [self.p(n) for n in names]
+        return lst
+
     def _video_block(self, x, i, B, y=None, y_mask=None, L=0):
-        """SpaceTimeBlock.forward (video_transformer.py:214-228) on the flat (B*S, d) token matrix."""
+        """SpaceTimeBlock.forward (video_transformer.py:214-228) on the flat (B*S, d) token matrix: one C-ABI call forward, one
+        backward (csrc/egv_block.cpp)."""
         c = self.cfg
-        pfx = f'video_model.blocks.{i}'
-        Fr, N, H = c.frames, c.n_patches, c.heads
-        # pre-norm residuals: _ln_skip returns (LayerNorm(x), x) so that the skip gradient is added inside the LN backward kernel
-        h, xs = self._ln_skip(x, pfx + '.norm3', c.eps_video)
-        qkv = self._lin(h, pfx + '.timeattn.qkv')
-        t_ctx = ops.divided_attention(qkv, B, Fr, N, H, 'time')
-        tr = self._lin(t_ctx, pfx + '.timeattn.proj', res1=xs)                       # time_residual = x + t   (:218)
-        qkv = self._lin(self._ln(tr, pfx + '.norm1', c.eps_video), pfx + '.attn.qkv')
-        s_ctx = ops.divided_attention(qkv, B, Fr, N, H, 'space')
-        if y is None:
-            sr = self._lin(s_ctx, pfx + '.attn.proj', res1=xs)                       # space_residual = x + s  (:222)
-        else:
-            a = pfx + '.attn'
-            s = self._lin(s_ctx, a + '.proj')
-            kv = self._lin(y, a + '.qkv_text_i2t')                                    # (B*L, 2D) = [k | v]   (:159-164)
-            hs, ss = self._ln_skip(s, a + '.norm_i2t_i', c.eps_video)
-            q = self._lin(hs, a + '.qkv_i2t')
-            o = ops.plain_attention(q, kv[:, :c.dim], kv[:, c.dim:], B, H, c.seq, L, c.head_dim ** -0.5, mask=y_mask)
-            # x + (s + alpha * proj_i2t(o))   (:185, :222)
-            sr = self._lin(o, a + '.proj_i2t', gate=self.p(a + '.alpha_i2t'), res1=ss, res2=xs)
-        h2, srs = self._ln_skip(sr, pfx + '.norm2', c.eps_video)
-        return ops.mlp(h2, self.p(pfx + '.mlp.fc1.weight'), self.p(pfx + '.mlp.fc1.bias'),
-                       self.p(pfx + '.mlp.fc2.weight'), self.p(pfx + '.mlp.fc2.bias'), res=srs)
+        return ops.video_block(x, self._block_params('video', i, y is not None), B, c.frames, c.n_patches, c.heads, c.dim * c.mlp_ratio,
+                               c.eps_video, y=y, y_mask=y_mask, L=L)
 
     def _cls_rows(self, x, B, rows_per_sample):
         return x.reshape(B, rows_per_sample, -1)[:, 0].contiguous()
@@ -319,54 +326,20 @@ class FrozenInTime(nn.Module):
         return ((1.0 - attention_mask.to(torch.float32)) * F32_MIN).contiguous()
 
     def _text_layer(self, hid, mask, i, B, L, enc=None):
-        """RobertaLayer.forward (roberta.py:444-505); enc = video tokens (B*S, d) for the fused layers."""
+        """RobertaLayer.forward (roberta.py:444-505); enc = video tokens (B*S, d) for the fused layers.  One C-ABI call forward,
+        one backward.  Train mode: dropout on the attention probabilities (roberta.py:313) inside the attention kernels and on
+        every dense output before its residual add (:342, :422); one seed per site, drawn here in the sites' order."""
         c = self.cfg
-        pfx = f'text_model.encoder.layer.{i}'
-        sa = pfx + '.attention.self'
-        q, k, v = self._lin(hid, sa + '.query'), self._lin(hid, sa + '.key'), self._lin(hid, sa + '.value')
         p = self._drop_p()
+        fused = enc is not None
+        seeds = [0] * 6
         if p > 0:
-            return self._text_layer_dropout(hid, mask, i, B, L, enc, q, k, v, p)
-        ctx = ops.plain_attention(q, k, v, B, c.heads, L, L, 1.0 / math.sqrt(c.head_dim), mask=mask)
-        if enc is None:
-            a = self._lin(ctx, pfx + '.attention.output.dense', res1=hid)           # dense(ctx) + hidden  (:488)
-        else:
-            a0 = self._lin(ctx, pfx + '.attention.output.dense')
-            ca = pfx + '.crossattention_t2i'
-            cq = self._lin(a0, ca + '.self.query')
-            ck, cv = self._lin(enc, ca + '.self.key'), self._lin(enc, ca + '.self.value')
-            cctx = ops.plain_attention(cq, ck, cv, B, c.heads, L, c.seq, 1.0 / math.sqrt(c.head_dim), mask=None)
-            # alpha_t2i * dense(cctx) + a0 + hidden   (:486-488)
-            a = self._lin(cctx, ca + '.output.dense', gate=self.p(pfx + '.alpha_t2i'), res1=a0, res2=hid)
-        a = self._ln(a, pfx + '.attention.output.LayerNorm', c.eps_text)
-        f = ops.mlp(a, self.p(pfx + '.intermediate.dense.weight'), self.p(pfx + '.intermediate.dense.bias'),
-                    self.p(pfx + '.output.dense.weight'), self.p(pfx + '.output.dense.bias'), res=a)
-        return self._ln(f, pfx + '.output.LayerNorm', c.eps_text)
-
-    def _text_layer_dropout(self, hid, mask, i, B, L, enc, q, k, v, p):
-        """train-mode RobertaLayer: dropout on the attention probabilities (roberta.py:313) inside the attention kernels and
-        on every dense output before its residual add (:342, :422) as one dropout+add pass; the alpha_t2i gate commutes
-        with the keep mask, so it stays in the GEMM epilogue."""
-        c = self.cfg
-        pfx = f'text_model.encoder.layer.{i}'
-        sc = 1.0 / math.sqrt(c.head_dim)
-        ctx = ops.plain_attention(q, k, v, B, c.heads, L, L, sc, mask=mask, drop_p=p, drop_seed=self._drop_seed())
-        a0 = self._lin(ctx, pfx + '.attention.output.dense')
-        if enc is None:
-            a = ops.dropout_add(a0, p, self._drop_seed(), r1=hid)
-        else:
-            a0 = ops.dropout_add(a0, p, self._drop_seed())
-            ca = pfx + '.crossattention_t2i'
-            cq = self._lin(a0, ca + '.self.query')
-            ck, cv = self._lin(enc, ca + '.self.key'), self._lin(enc, ca + '.self.value')
-            cctx = ops.plain_attention(cq, ck, cv, B, c.heads, L, c.seq, sc, mask=None, drop_p=p, drop_seed=self._drop_seed())
-            y = self._lin(cctx, ca + '.output.dense', gate=self.p(pfx + '.alpha_t2i'))
-            a = ops.dropout_add(y, p, self._drop_seed(), r1=a0, r2=hid)
-        a = self._ln(a, pfx + '.attention.output.LayerNorm', c.eps_text)
-        f = ops.mlp(a, self.p(pfx + '.intermediate.dense.weight'), self.p(pfx + '.intermediate.dense.bias'),
-                    self.p(pfx + '.output.dense.weight'), self.p(pfx + '.output.dense.bias'), res=None)
-        f = ops.dropout_add(f, p, self._drop_seed(), r1=a)
-        return self._ln(f, pfx + '.output.LayerNorm', c.eps_text)
+            seeds[0], seeds[1] = self._drop_seed(), self._drop_seed()
+            if fused:
+                seeds[2], seeds[3] = self._drop_seed(), self._drop_seed()
+            seeds[4] = self._drop_seed()
+        return ops.text_layer(hid, mask, self._block_params('text', i, fused), B, L, c.heads, c.dim * c.mlp_ratio, c.eps_text,
+                              enc=enc, S=c.seq if fused else 0, drop_p=p, seeds=seeds)
 
     # ------------------------------------------------------------------ reference API
     def compute_text(self, text_data):

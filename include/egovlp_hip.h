@@ -169,6 +169,71 @@ int egv_cast_weights(const void* table, const int* prefix, int ntensors, int nti
 int egv_adamw_step(const void* table, const int* prefix, int ntensors, int nchunks, float lr, float step_size, float beta1,
                    float beta2, float eps, float weight_decay, float grad_scale, void* stream);
 
+
+/* ---- block-level entry points (csrc/egv_block.cpp): ONE call = one SpaceTimeBlock / one RobertaLayer, forward or backward.
+ * They issue the same kernels as the entry points above, in the reference's order; what they add is the saved-activation
+ * layout, the scratch plan and the stream choreography, so that the host issues ~130 calls per training step instead of
+ * ~4 600.  save/ws: caller-allocated, sizes from the *_bytes queries (ws: forward and backward sizes differ).  All work is
+ * enqueued on `stream`; with stream2 != NULL the weight-gradient GEMMs of a backward call run on stream2, forked from and
+ * joined back into `stream` inside the call (events from a library-owned pool), so every output is ordered on `stream`
+ * when the call returns.  Weights: w[i] = compute-dtype copy W[N,K]; wt[i] = its transpose W^T[K,N] (bf16 mode, may be
+ * NULL: dgrad then reads W as a [reduction, out] operand); biases, LayerNorm affine terms, gates and ALL gradients fp32.
+ * dln_b[i] must be dln_g[i] + D (one [2][D] buffer per LayerNorm).
+ *
+ * SpaceTimeBlock.forward (video_transformer.py:214-228) with VarAttention (:117-187) and Mlp (:42-58) on the flat token
+ * matrix x[B*S, D], S = 1 + F*N.  L > 0 selects the fused form: y[B*L, D] = text states, y_mask[B, L] additive fp32 key mask,
+ * weights 6..8 = qkv_text_i2t (2D x D), qkv_i2t, proj_i2t, LayerNorm 3 = norm_i2t_i, alpha = alpha_i2t (:155-185).
+ * Weight order: timeattn.qkv, timeattn.proj, attn.qkv, attn.proj, mlp.fc1, mlp.fc2; LayerNorm order: norm3, norm1, norm2. */
+typedef struct egv_vblock_desc {
+    int dtype, B, F, N, H, D, Hd, L;
+    float eps;
+    const void* x; void* out;                       /* [B*S, D] */
+    const void* y; const float* y_mask;             /* fused only */
+    void* save; long long save_bytes;
+    void* ws; long long ws_bytes;
+    const void* w[9]; const void* wt[9]; const float* b[9];
+    const float* ln_g[4]; const float* ln_b[4];
+    const float* alpha;
+    /* backward */
+    const void* dout; void* dx; void* dy;           /* dy [B*L, D]: gradient of the text states (fused), may be NULL */
+    float* dw[9]; float* db[9]; float* dln_g[4]; float* dln_b[4]; float* dalpha;
+    void* stream; void* stream2;
+} egv_vblock_desc;
+long long egv_vblock_save_bytes(const egv_vblock_desc* d);
+long long egv_vblock_ws_bytes(const egv_vblock_desc* d, int backward);
+int egv_vblock_fwd(const egv_vblock_desc* d);
+int egv_vblock_bwd(const egv_vblock_desc* d);
+
+/* RobertaLayer.forward (roberta.py:444-505) on hid[B*L, D]: self attention (:257-327, separate q/k/v Linears, additive key
+ * mask, probability dropout), RobertaSelfOutput (:335-345), optional text-to-image cross attention over enc[B*S, D] (video
+ * tokens, no mask, :486-488: alpha_t2i * dense(cctx) + a0 + hidden, no LayerNorm inside), intermediate + output (:397-426).
+ * drop_p > 0 (train mode): hidden dropout before every residual add and attention-probability dropout; seeds[0..5] = one
+ * 32-bit seed per site: 0 self-attention probabilities, 1 attention.output, 2 crossattention probabilities,
+ * 3 crossattention.output, 4 output (5 unused).  Weight order: query, key, value, attention.output.dense, intermediate.dense,
+ * output.dense, crossattention_t2i.self.{query,key,value}, crossattention_t2i.output.dense; LayerNorm order:
+ * attention.output.LayerNorm, output.LayerNorm. */
+typedef struct egv_tlayer_desc {
+    int dtype, B, L, H, D, Hd, S;                   /* S > 0: fused layer, enc has B*S rows */
+    float eps, drop_p;
+    unsigned int seeds[6];
+    const void* hid; void* out;                     /* [B*L, D] */
+    const float* mask;                              /* [B, L] additive fp32 */
+    const void* enc;
+    void* save; long long save_bytes;
+    void* ws; long long ws_bytes;
+    const void* w[10]; const void* wt[10]; const float* b[10];
+    const float* ln_g[2]; const float* ln_b[2];
+    const float* alpha;
+    /* backward */
+    const void* dout; void* dhid; void* denc;       /* denc [B*S, D]: gradient of the video tokens (fused), may be NULL */
+    float* dw[10]; float* db[10]; float* dln_g[2]; float* dln_b[2]; float* dalpha;
+    void* stream; void* stream2;
+} egv_tlayer_desc;
+long long egv_tlayer_save_bytes(const egv_tlayer_desc* d);
+long long egv_tlayer_ws_bytes(const egv_tlayer_desc* d, int backward);
+int egv_tlayer_fwd(const egv_tlayer_desc* d);
+int egv_tlayer_bwd(const egv_tlayer_desc* d);
+
 /* ---- instrumentation: HIP-event timing of the GEMM launches on their own stream (bench.py roofline) ---- */
 int egv_prof_enable(int on);
 int egv_prof_reset(void);
