@@ -1,17 +1,15 @@
-// 256-row MFMA GEMM for gfx950 (bf16 storage, fp32 accumulate): the throughput path for the large Linear layers of the
-// EgoVLPv2 hot path (M = B*S = 25 096 tokens).
+// 256-row MFMA ring GEMMs for gfx950 (bf16 storage, fp32 accumulate): the Linear layers of the EgoVLPv2 hot path whose shape or
+// epilogue the persistent ping-pong kernel (egv_gemm3.hip) does not take -- residual / GELU' / gated epilogues, the text-side
+// grids -- and every weight gradient (M = B*S = 25 096 tokens).
 //
-// Differences from the generic 128x128 kernel (egv_gemm.hip):
-//   * 512-thread workgroups (8 waves), 256x256 or 256x128 output tiles, K step 64;
-//   * operands that are K-contiguous in memory are staged by the DMA path: global_load_lds_dwordx4 (16 B per lane, 1 KiB per
-//     wave instruction) straight into LDS, no VGPR round trip;  the LDS image is linear (the DMA writes lane-linear) and the
-//     bank-conflict-free XOR swizzle (16-byte chunk c of row r lives at chunk c ^ (r & 7)) is applied on the per-lane SOURCE
-//     address and again on the fragment read (cdna_hip_programming.md rule 21);
-//   * operands whose reduction index is the slow (row) index (both operands of wgrad) go global -> VGPR -> 8x8 bf16 block
-//     transpose -> ds_write_b128 into the SAME swizzled image, so the MFMA loop is shared;
-//   * two LDS stages: the loads of K-tile t+1 are in flight while tile t feeds the matrix cores, one barrier per K step.
-// Ragged edges: rows beyond M/N are clamped on load (their products are never stored); the reduction tail of wgrad is
-// zero-filled; direct operands require K % 64 == 0 (true for every Linear of the model), otherwise the caller falls back.
+//   * gemm_ring_kernel (NT, forward + dgrad): 512-thread workgroups, 256x128 (or 128x128) tiles, K step 32, NS-stage LDS ring filled
+//     by global_load_lds_dwordx4 with NS-1 K-tiles in flight, counted s_waitcnt vmcnt + one raw s_barrier per K step, XOR swizzle
+//     applied on the DMA's per-lane source address and on the fragment read, epilogue through a per-wave LDS transpose;
+//   * gemm_wgrad_ring_kernel (TN, dW = dY^T X): both operands are reduction-major in memory; K-tiles are DMA-staged as stored
+//     (buffer_load ... lds, reduction tail zero through the descriptor) and the fragments gathered with ds_read_b64_tr_b16;
+//     split over the reduction into fp32 slabs, bias gradient from the fragments in registers.
+// Ragged edges: rows beyond M/N are clamped on load (their products are never stored); NT operands require K % 64 == 0 (true
+// for every Linear of the model), otherwise the caller falls back to the generic 128x128 kernel (egv_gemm.hip).
 #include "egv_gemm.h"
 #include <cstdlib>
 
@@ -26,200 +24,8 @@ struct Cfg {
     static constexpr int BM = WGM * MI * 16, BN = WGN * NI * 16;
     static constexpr int STAGE = (BM + BN) * 128;      // bytes per LDS stage (rows of 64 bf16)
 };
-using CfgA = Cfg<2, 4, 8, 4>;   // 256 x 256
 using CfgB = Cfg<4, 2, 4, 4>;   // 256 x 128
 using CfgC = Cfg<4, 2, 2, 4>;   // 128 x 128 (3 workgroups per CU with a 3-stage ring: fills the wave-quantisation tail of N=768 GEMMs)
-
-// ---- DMA staging of a K-contiguous operand tile: ROWS rows x 128 B into s (swizzled) ----
-template <int ROWS>
-__device__ __forceinline__ void stage_dma(const bf16_t* base, int rows_total, int ld, int row0, int k0, unsigned char* s,
-                                          int wave, int lane) {
-    const int rl = lane >> 3;
-    const int c = (lane & 7) ^ rl;
-#pragma unroll
-    for (int p = wave; p < ROWS / 8; p += 8) {
-        const int gr = min(row0 + p * 8 + rl, rows_total - 1);
-        const bf16_t* src = base + (size_t)gr * ld + k0 + c * 8;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s + p * 1024), 16, 0, 0);
-    }
-}
-
-// ---- register staging of a transposed operand (stored [reduction, rows]): one 8x8 unit per thread ----
-struct TUnit {
-    u32x4_t r[8];
-};
-
-template <int ROWS>
-__device__ __forceinline__ void tload(TUnit& u, const bf16_t* base, int rows_total, int ld, int row0, int k0, int kend, int unit) {
-    constexpr int RB = ROWS / 8;
-    const int kb = unit / RB, rb = unit % RB;
-    const int grow0 = row0 + rb * 8;
-    const bool row_ok = grow0 < rows_total;          // rows_total % 8 == 0 is a launch precondition
-    const bf16_t* p = base + (size_t)(k0 + kb * 8) * ld + grow0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        u32x4_t x = {0u, 0u, 0u, 0u};
-        if (row_ok && k0 + kb * 8 + j < kend) x = *reinterpret_cast<const u32x4_t*>(p + (size_t)j * ld);
-        u.r[j] = x;
-    }
-}
-
-template <int ROWS>
-__device__ __forceinline__ void tstore(const TUnit& u, unsigned char* s, int unit) {
-    constexpr int RB = ROWS / 8;
-    const int kb = unit / RB, rb = unit % RB;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        u32x4_t o;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const unsigned int a = u.r[2 * d][e >> 1], b = u.r[2 * d + 1][e >> 1];
-            o[d] = (e & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
-        }
-        // row rb*8+e, logical chunk kb -> physical chunk kb ^ (row & 7) = kb ^ e
-        *reinterpret_cast<u32x4_t*>(s + (rb * 8 + e) * 128 + ((kb ^ e) * 16)) = o;
-    }
-}
-
-template <typename CFG, int AT, int BT, typename OutT>
-__global__ __launch_bounds__(512) void gemm2_kernel(const GemmArgs g) {
-    constexpr int BM = CFG::BM, BN = CFG::BN, MI = CFG::MI, NI = CFG::NI;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 stages
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = wave_id();
-    const int wm = wave / CFG::WGN, wn = wave % CFG::WGN;
-    const int fr = lane & 15, fg = lane >> 4;
-
-    const int ntile = g.tiles_m * g.tiles_n;
-    const int t = xcd_remap(blockIdx.x, ntile);
-    const int tm = t / g.tiles_n, tn = t % g.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int kbeg = blockIdx.z * g.k_per_split;
-    const int kend = min(g.K, kbeg + g.k_per_split);
-
-    const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A);
-    const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B);
-
-    f32x4_t acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    // transposed-operand unit assignment: A units on threads [0, BM), B units on threads [BM, BM+BN)
-    static_assert(AT && BT, "gemm2_kernel is the wgrad (both operands reduction-major) kernel");
-    const int unitA = tid;
-    const int unitB = tid - BM;
-    const bool hasA = unitA < BM;
-    const bool hasB = unitB >= 0 && unitB < BN;
-    TUnit ur[1];                       // next K-tile in flight in registers
-    float bsum[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
-    const bool want_colsum = (g.colsum != nullptr) && (tn == 0);
-
-    auto issue = [&](TUnit& u, int k0) {
-        if (hasA) tload<BM>(u, A, g.M, g.lda, m0, k0, kend, unitA);
-        else if (hasB) tload<BN>(u, B, g.N, g.ldb, n0, k0, kend, unitB);
-    };
-    auto commit = [&](const TUnit& u, int stage) {
-        unsigned char* sA = smem + stage * CFG::STAGE;
-        unsigned char* sB = sA + BM * 128;
-        if (hasA) {
-            tstore<BM>(u, sA, unitA);
-            if (want_colsum) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        bsum[2 * d] += __uint_as_float(u.r[j][d] << 16);
-                        bsum[2 * d + 1] += __uint_as_float(u.r[j][d] & 0xffff0000u);
-                    }
-            }
-        } else if (hasB) {
-            tstore<BN>(u, sB, unitB);
-        }
-    };
-    auto compute = [&](int stage) {
-        const unsigned char* sA = smem + stage * CFG::STAGE;
-        const unsigned char* sB = sA + BM * 128;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8_t b[NI];
-            const int co = (((ks * 4 + fg) ^ (fr & 7)) * 16);
-#pragma unroll
-            for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(sB + (wn * NI * 16 + j * 16 + fr) * 128 + co);
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(sA + (wm * MI * 16 + i * 16 + fr) * 128 + co);
-#pragma unroll
-                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a, acc[i][j], 0, 0, 0);
-            }
-        }
-    };
-
-    // software pipeline: the loads of tile t+1 are in flight (registers) while tile t feeds the MFMAs from LDS stage t&1
-    issue(ur[0], kbeg);
-    commit(ur[0], 0);
-    __syncthreads();
-    int stage = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += 64) {
-        const bool more = k0 + 64 < kend;
-        if (more) issue(ur[0], k0 + 64);
-        compute(stage);
-        if (more) commit(ur[0], stage ^ 1);
-        __syncthreads();
-        stage ^= 1;
-    }
-
-    if (want_colsum) {
-        // threads with the same row block rb (unit % RB) hold partial sums of 8 different k blocks: combine through LDS
-        float* red = reinterpret_cast<float*>(smem);                 // [8 kb][BM]
-        __syncthreads();
-        if (hasA) {
-            constexpr int RB = BM / 8;
-            const int kb = unitA / RB, rb = unitA % RB;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) red[kb * BM + rb * 8 + e] = bsum[e];
-        }
-        __syncthreads();
-        if (tid < BM && m0 + tid < g.M) {
-            float t = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < 8; ++kb) t += red[kb * BM + tid];
-            g.colsum[(size_t)blockIdx.z * g.M + m0 + tid] = t;
-        }
-    }
-
-    OutT* C = reinterpret_cast<OutT*>(g.C) + (size_t)blockIdx.z * g.slab_stride;
-    const float gate = g.e.gate ? *g.e.gate : 1.0f;
-#pragma clang loop unroll(full)
-    for (int mi = 0; mi < MI; ++mi) {
-        const int m = m0 + wm * MI * 16 + mi * 16 + fr;
-        if (m >= g.M) continue;
-#pragma clang loop unroll(full)
-        for (int ni = 0; ni < NI; ++ni) {
-            const int n = n0 + wn * NI * 16 + ni * 16 + fg * 4;
-            if (n >= g.N) continue;
-            float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
-            gemm_epilogue4<bf16_t, OutT>(g, C, m, n, v, gate);
-        }
-    }
-}
-
-template <typename CFG, int AT, int BT, typename OutT>
-static void launch2(GemmArgs g, int nz, hipStream_t st) {
-    g.tiles_m = (g.M + CFG::BM - 1) / CFG::BM;
-    g.tiles_n = (g.N + CFG::BN - 1) / CFG::BN;
-    const size_t lds = 2 * CFG::STAGE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_kernel<CFG, AT, BT, OutT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm2_kernel<CFG, AT, BT, OutT>), dim3(g.tiles_m * g.tiles_n, 1, nz), dim3(512), lds, st, g);
-}
 
 // ------------------------------------------------------------------------------------------------
 // NT ring kernel: K step 32 (64-byte LDS rows), NS-stage LDS ring filled by global_load_lds with NS-1 K-tiles in flight,
@@ -269,9 +75,6 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    long long* stamps = reinterpret_cast<long long*>(g.colsum);          // debug only (egv_debug_timing)
-    const bool stamp = stamps != nullptr && tid == 0;
-    if (stamp) stamps[blockIdx.x * 8 + 0] = clock64();
     const int nt = g.K / 32;
     auto issue = [&](int kt, int slot) {
         unsigned char* sA = smem + slot * STG;
@@ -284,14 +87,12 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmArgs g) {
 
     const int frag_off = fr * 64 + ((fg ^ (((fr >> 2) & 1) * 3)) * 16);
     int slot = 0, islot = NS - 1;
-    if (stamp) stamps[blockIdx.x * 8 + 1] = clock64();
     for (int kt = 0; kt < nt; ++kt) {
         const int rem = nt - 1 - kt;
         if (rem >= NS - 2) wait_vmcnt<P*(NS - 2)>();
         else if (NS > 3 && rem == 1) wait_vmcnt<P>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        if (stamp && kt == 0) stamps[blockIdx.x * 8 + 2] = clock64();
         if (kt + NS - 1 < nt) issue(kt + NS - 1, islot);
         const unsigned char* sA = smem + slot * STG + frag_off;
         const unsigned char* sB = sA + BM * 64;
@@ -317,9 +118,7 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmArgs g) {
     // C accesses are 16-byte vectors forming 128-byte row segments (8 lanes per row) instead of 8-byte scattered ones.
     static_assert(NI == 4, "wave tile must be 64 columns wide");
     constexpr int EP = 68;                                     // floats per LDS slab row (64 + 4 pad)
-    if (stamp) stamps[blockIdx.x * 8 + 3] = clock64();
     __syncthreads();                                           // every wave is done with the operand stages
-    if (stamp) stamps[blockIdx.x * 8 + 4] = clock64();
     float* slab = reinterpret_cast<float*>(smem) + wave * 16 * EP;
     bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
     const GemmEpi& e = g.e;
@@ -401,15 +200,14 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmArgs g) {
             }
         }
     }
-    if (stamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamps[blockIdx.x * 8 + 5] = clock64(); }
 }
 
+// tools/gemm_pp_stamps.py: buffer for the per-K-tile timestamps of the EGV_PP_STAMPS instrumentation build of gemm_pp_kernel
 float* g_timing_buf = nullptr;
 extern "C" int egv_debug_timing(void* buf) { g_timing_buf = (float*)buf; return 0; }
 
 template <typename CFG, int NS>
 static void launch_ring(GemmArgs g, hipStream_t st) {
-    g.colsum = g_timing_buf;
     g.tiles_m = (g.M + CFG::BM - 1) / CFG::BM;
     g.tiles_n = (g.N + CFG::BN - 1) / CFG::BN;
     const size_t lds = (size_t)NS * (CFG::BM + CFG::BN) * 64;
@@ -584,13 +382,6 @@ static void launch_wgrad_ring(GemmArgs g, int nz, hipStream_t st) {
 }  // namespace egv
 using namespace egv;
 
-static inline double wave_eff(int M, int N, int bm, int bn, int nz) {
-    const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * nz;
-    const long long rounds = (tiles + 255) / 256;
-    const double useful = (double)M * N / ((double)((M + bm - 1) / bm) * bm * ((N + bn - 1) / bn) * bn);
-    return useful * (double)tiles / (double)(rounds * 256);
-}
-
 int egv_gemm3_launch(const egv::GemmArgs& g, hipStream_t st);
 
 int egv_gemm2_launch(const GemmArgs& g, int a_trans, int b_trans, int out_f32, int nz, hipStream_t st) {
@@ -611,19 +402,12 @@ int egv_gemm2_launch(const GemmArgs& g, int a_trans, int b_trans, int out_f32, i
         launch_wgrad_ring<CfgB, 3>(g, nz, st);
         return 1;
     }
-    const bool useA = wave_eff(g.M, g.N, 256, 256, nz) >= wave_eff(g.M, g.N, 256, 128, nz) * 0.98;
-    if (!a_trans) {
-        (void)useA;
+    {
         static const int pp = getenv("EGV_GEMM_PP") ? atoi(getenv("EGV_GEMM_PP")) : 1;     // persistent ping-pong kernel (egv_gemm3.hip) for large grids; 0 = ring kernels only
         if (pp && (long long)((g.M + 255) / 256) * ((g.N + 255) / 256) >= 64 && egv_gemm3_launch(g, st)) return 1;
-        static const int force = getenv("EGV_GEMM_CFG") ? atoi(getenv("EGV_GEMM_CFG")) : 0;     // experiments only
         const long long tb = (long long)((g.M + 255) / 256) * ((g.N + 127) / 128);
-        if (force == 1 && tb <= 128) return 0;                  // experiment: generic 128x128 kernel for small grids
-        if (force == 3) launch_ring<CfgC, 3>(g, st);
-        else if (tb <= 128) launch_ring<CfgC, 6>(g, st);     // latency-bound small grids (text tokens): 128x128 tiles, 5 K-tiles in flight
+        if (tb <= 128) launch_ring<CfgC, 6>(g, st);     // latency-bound small grids (text tokens): 128x128 tiles, 5 K-tiles in flight
         else launch_ring<CfgB, 3>(g, st);      // 256x128 tile x 3 stages = 72 KB: 2 workgroups per CU (epilogue of one overlaps the K loop of the other)
-    } else {
-        if (useA) launch2<CfgA, 1, 1, float>(g, nz, st); else launch2<CfgB, 1, 1, float>(g, nz, st);
     }
     return 1;
 }

@@ -75,11 +75,22 @@ def _cast_event():
     return ev
 
 
+_stream_seen = {}        # stream handle -> (id of the cast event this stream already waits for, ids of copies recorded on it)
+
+
 def _cross_stream(ent):
-    """a cached copy made on another stream: order this stream after the cast kernel, keep the allocator informed"""
-    if ent[3] != _st():
-        torch.cuda.current_stream().wait_event(ent[4])
-        ent[1].record_stream(torch.cuda.current_stream())
+    """a cached copy made on another stream: order this stream after the cast kernel, keep the allocator informed -- once per
+    stream and cast (all copies of one prepare_weights launch share one event), not once per use"""
+    st = _st()
+    if ent[3] != st:
+        seen = _stream_seen.get(st)
+        if seen is None or seen[0] != id(ent[4]):
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ent[4])
+            seen = _stream_seen[st] = (id(ent[4]), set(), cur, ent[4])
+        if id(ent[1]) not in seen[1]:
+            ent[1].record_stream(seen[2])
+            seen[1].add(id(ent[1]))
     return ent[1]
 
 

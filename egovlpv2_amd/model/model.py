@@ -156,7 +156,8 @@ class FrozenInTime(nn.Module):
         self._P = None
 
         if load_checkpoint not in ["", None]:
-            checkpoint = torch.load(load_checkpoint, map_location='cpu')
+            # reference checkpoints pickle a ConfigParser under 'config' (base_trainer.py:412-436): weights_only must be off
+            checkpoint = torch.load(load_checkpoint, map_location='cpu', weights_only=False)
             state_dict = checkpoint['state_dict']
             new_state_dict = state_dict_data_parallel_fix(state_dict, self.state_dict())
             new_state_dict = self._inflate_positional_embeds(new_state_dict)

@@ -1,17 +1,22 @@
-"""Summarise a rocprofv3 --kernel-trace results.db (rocpd sqlite) into a markdown table under profiles/."""
-import re, sqlite3, sys
-db, out, title, nsteps = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
-c = sqlite3.connect(db)
-rows = list(c.execute("select name, count(*), sum(end-start)/1e6, avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3 from kernels group by name order by 3 desc"))
-tot = sum(r[2] for r in rows)
-with open(out, 'w') as f:
-    f.write(f"# {title}\n\n")
-    f.write("Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-gemm-events`\n")
-    f.write("(BASELINE.json configs[2]: full fusion EgoNCE+MLM+ITM, B=8, 16x224^2 frames, 32 tokens, bf16 storage, 1 x MI355X;\n")
-    f.write(f"the trace holds {nsteps} steps including the warm-up step).\n\n")
-    f.write(f"Total kernel time {tot:.1f} ms over {nsteps} steps = **{tot/nsteps:.1f} ms/step**.\n\n")
-    f.write("| kernel | calls/step | ms/step | % | avg us | min us | max us |\n|---|---|---|---|---|---|---|\n")
-    for n, cnt, ms, avg, mn, mx in rows[:40]:
-        n = re.sub(r'\(.*', '', n).replace('void ', '')
-        f.write(f"| `{n[:95]}` | {cnt/nsteps:.1f} | {ms/nsteps:.2f} | {100*ms/tot:.1f} | {avg:.1f} | {mn:.1f} | {mx:.1f} |\n")
-print(open(out).read()[:1500])
+"""Summarise a rocprofv3 --kernel-trace result (rocpd sqlite): per kernel calls/step, ms/step, avg/min/max us.
+usage: prof_summary.py results.db steps [top]"""
+import sqlite3, sys, collections, re
+db = sqlite3.connect(sys.argv[1])
+steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+top = int(sys.argv[3]) if len(sys.argv) > 3 else 45
+tabs = [r[0] for r in db.execute("select name from sqlite_master where type in ('table','view')")]
+view = 'kernels' if 'kernels' in tabs else None
+if view is None:
+    raise SystemExit(f"no kernels view; tables: {tabs[:40]}")
+cols = [c[1] for c in db.execute(f"pragma table_info('{view}')")]
+namecol = 'name' if 'name' in cols else 'kernel_name'
+rows = db.execute(f"select {namecol}, start, end from {view}").fetchall()
+agg = collections.defaultdict(list)
+for n, s, e in rows:
+    n = re.sub(r'\(.*$', '', n)
+    agg[n].append((e - s) / 1e3)
+tot = sum(sum(v) for v in agg.values())
+print(f"Total kernel time {tot / 1e3:.1f} ms over {steps:g} steps = **{tot / 1e3 / steps:.1f} ms/step**; {sum(len(v) for v in agg.values()) / steps:.0f} launches/step\n")
+print("| kernel | calls/step | ms/step | % | avg us | min us | max us |\n|---|---|---|---|---|---|---|")
+for n, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:top]:
+    print(f"| `{n[:100]}` | {len(v) / steps:.1f} | {sum(v) / 1e3 / steps:.2f} | {100 * sum(v) / tot:.1f} | {sum(v) / len(v):.1f} | {min(v):.1f} | {max(v):.1f} |")
