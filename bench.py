@@ -79,15 +79,15 @@ def _cpu_sample(frames, L, workload, threads):
     return one(PathConfig(frames=frames), 1, L)
 
 
-def cpu_baseline(cfg, L, workload, timeout_s=240):
+def cpu_baseline(cfg, L, workload, timeout_s=300):
     """The CPU oracle (oracle/ref_model.py, kind 'port': a restatement of the reference's fp32 CPU path, pinned to the
     reference by tests/golden) timed on this box's host cores on a BOUNDED sample of the same workload: the same model and
-    token count per frame at B=1 with 4 frames (the reference's own pre-training clip length), one fwd+bwd step, in a
-    subprocess with a timeout.  pairs/s is reported for that sample; the 16-frame workload costs ~3.98x the FLOPs per pair."""
+    shapes (16 x 224^2 frames, 32 tokens, all three losses) at B=1, one fwd+bwd step on all physical cores, in a subprocess
+    with a timeout."""
     import subprocess
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
-    frames = 4
+    threads = max(1, cores // 2) if cores > 16 else cores       # physical cores (SMT siblings add nothing to fp32 GEMMs)
+    frames = cfg.frames                                       # the workload's own shapes at B = 1 (SURVEY.md 8d)
     code = (f"import sys, json; sys.path.insert(0, {REPO!r}); import bench; "
             f"print(json.dumps(bench._cpu_sample({frames}, {L}, {workload!r}, {threads})))")
     try:
@@ -97,9 +97,13 @@ def cpu_baseline(cfg, L, workload, timeout_s=240):
         return {"value": None, "unit": "pairs/s", "cores": threads, "kind": "port", "sample": f"failed: {type(e).__name__}"}
     f4 = flops_per_pair(type(cfg)(frames=frames), L, workload)
     f16 = flops_per_pair(cfg, L, workload)
+    try:
+        model_name = [ln.split(':', 1)[1].strip() for ln in open('/proc/cpuinfo') if ln.startswith('model name')][0]
+    except Exception:
+        model_name = 'unknown CPU'
     return {"value": round(1.0 / dt, 5), "unit": "pairs/s", "cores": threads, "kind": "port",
             "sample": f"oracle fp32 fwd+bwd, B=1, {frames}x{cfg.img}^2 frames, {L} tokens, {'EgoNCE' if workload == 'dual' else 'EgoNCE+MLM+ITM'}, "
-                      f"{threads} torch threads of {cores} logical CPUs; 1 step = {dt:.1f} s",
+                      f"{threads} torch threads of {cores} logical CPUs ({model_name}); 1 step = {dt:.1f} s",
             "seconds": round(dt, 2), "flops_ratio_workload_over_sample": round(f16 / f4, 3),
             "value_scaled_to_workload": round(1.0 / dt * f4 / f16, 5)}
 
@@ -232,16 +236,19 @@ def main():
         recs = ops.prof_collect()
         kinds = {0: 'gemm_kernel<bf16,NT> (generic 128x128)', 1: 'gemm_kernel<bf16,NN> (generic)', 2: 'gemm_kernel<bf16,TN> (generic)',
                  4: 'gemm_kernel<f32,NT>', 5: 'gemm_kernel<f32,NN>', 6: 'gemm_kernel<f32,TN>',
-                 8: 'gemm_ring_kernel (NT fwd+dgrad, 256x128 DMA ring)', 10: 'gemm_wgrad_ring_kernel (TN wgrad, 256x128 DMA ring)'}
+                 8: 'gemm_ring_kernel<256x128> (NT fwd+dgrad, DMA ring)', 10: 'gemm_wgrad_ring_kernel (TN wgrad, 256x128 DMA ring)',
+                 12: 'gemm_pp_kernel (NT fwd+dgrad, persistent ping-pong 256x256)', 13: 'gemm_ring_kernel<128x128> (NT, text-side grids)'}
+        pmc_names = {8: 'gemm_ring_kernel<256x128>', 10: 'gemm_wgrad_ring_kernel', 12: 'gemm_pp_kernel', 13: 'gemm_ring_kernel<128x128>'}
         agg = {}
-        for fl, ms, kd in recs:
-            e = agg.setdefault(kd, [0.0, 0.0, 0])
+        for fl, ms, kd, by in recs:
+            e = agg.setdefault(kd, [0.0, 0.0, 0, 0.0])
             e[0] += fl
             e[1] += ms
             e[2] += 1
+            e[3] += by
         if os.environ.get('EGV_BENCH_SHAPES'):           # per (kernel kind, FLOPs) breakdown on stderr: which shapes run slow in-step
             by = {}
-            for fl, ms, kd in recs:
+            for fl, ms, kd, _b in recs:
                 e = by.setdefault((kd, fl), [0.0, 0])
                 e[0] += ms
                 e[1] += 1
@@ -250,21 +257,28 @@ def main():
                       f"avg_us={ms / n * 1e3:8.1f} TF={fl * n / (ms * 1e-3) / 1e12 if ms else 0:7.1f}", file=sys.stderr)
         tot_ms = sum(e[1] for e in agg.values())
         dom = max(agg, key=lambda k: agg[k][1])
-        fl, ms, n = agg[dom]
+        fl, ms, n, alg_bytes = agg[dom]
         ach = fl / (ms * 1e-3) / 1e12
-        traffic = None
-        try:                                    # PMC numbers are collected in separate rocprofv3 passes (profiles/round1_pmc_gemm.md)
-            pm = json.load(open(os.path.join(REPO, 'profiles', 'pmc_traffic.json')))
-            if dom == 8:
-                traffic = pm['gemm_ring_kernel']
+        # HBM traffic and MFMA-busy counters of the dominant kernel: rocprofv3 --pmc passes over THIS script (in-step, separate
+        # passes per counter group, gfx950 FETCH_SIZE correction), summarised by tools/pmc_instep.py into profiles/
+        traffic = mfma_busy = launches_per_step = None
+        try:
+            pm = json.load(open(os.path.join(REPO, 'profiles', 'round2_pmc_instep.json')))
+            ent = pm['kernels'].get(pmc_names.get(dom, ''))
+            if ent:
+                traffic = {k: ent[k] for k in ('fetch_bytes_per_launch', 'write_bytes_per_launch', 'traffic_bytes_per_launch', 'method') if k in ent}
+                traffic['algorithmic_bytes_per_launch'] = round(alg_bytes / n)
+                mfma_busy = ent.get('mfma_busy_frac')
+            launches_per_step = pm.get('launches_per_step')
         except Exception:
-            traffic = None
+            pass
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                "mfma_busy_frac_rocprof": mfma_busy,
                 "kernel": kinds.get(dom, str(dom)), "launches": n, "avg_launch_ms": round(ms / n, 4),
                 "all_gemm": {kinds.get(k, str(k)): {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1), "ms_per_step": round(v[1] / a.steps, 2),
                                                     "launches_per_step": v[2] // a.steps} for k, v in agg.items()},
-                "gemm_ms_per_step": round(tot_ms / a.steps, 2)}
+                "gemm_ms_per_step": round(tot_ms / a.steps, 2), "launches_per_step_rocprof": launches_per_step}
 
     if rank == 0:
         pairs = world * a.batch * a.steps
@@ -283,6 +297,7 @@ def main():
                "model_tflops": round(value * fpp / 1e12, 1), "executed_tflops": round(value * fpx / 1e12, 1),
                "mfma_frac_of_peak": round(value * fpx / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
                "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
+               "kernel_launches_per_step": (roof or {}).pop('launches_per_step_rocprof', None),
                "losses": losses, "roofline": roof}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, a.text_len, a.workload)

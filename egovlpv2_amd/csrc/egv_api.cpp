@@ -21,7 +21,7 @@ extern "C" int egv_abi_version(void) { return 1; }
 
 // ---- per-launch HIP-event timing of the GEMM kernels, on the stream they are launched on ----
 namespace {
-struct Rec { hipEvent_t a, b; double flops; int kind; };
+struct Rec { hipEvent_t a, b; double flops, bytes; int kind; };
 std::mutex g_mu;
 bool g_on = false;
 std::vector<Rec> g_recs;
@@ -37,17 +37,17 @@ bool egv_prof_on() { return g_on; }
 void* egv_prof_begin(void* stream) {
     if (!g_on) return nullptr;
     std::lock_guard<std::mutex> lk(g_mu);
-    Rec r; r.a = get_event(); r.b = get_event(); r.flops = 0; r.kind = 0;
+    Rec r; r.a = get_event(); r.b = get_event(); r.flops = 0; r.bytes = 0; r.kind = 0;
     hipEventRecord(r.a, reinterpret_cast<hipStream_t>(stream));
     g_recs.push_back(r);
     return reinterpret_cast<void*>(g_recs.size());      // 1-based handle
 }
 
-void egv_prof_end(void* handle, void* stream, double flops, int kind) {
+void egv_prof_end(void* handle, void* stream, double flops, int kind, double bytes) {
     if (!handle) return;
     std::lock_guard<std::mutex> lk(g_mu);
     Rec& r = g_recs[reinterpret_cast<size_t>(handle) - 1];
-    r.flops = flops; r.kind = kind;
+    r.flops = flops; r.kind = kind; r.bytes = bytes;
     hipEventRecord(r.b, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -60,7 +60,11 @@ extern "C" int egv_prof_reset(void) {
     return 0;
 }
 
+extern "C" int egv_prof_collect2(double* flops, double* bytes, float* ms, int* kind, int max_records);
 extern "C" int egv_prof_collect(double* flops, float* ms, int* kind, int max_records) {
+    return egv_prof_collect2(flops, nullptr, ms, kind, max_records);
+}
+extern "C" int egv_prof_collect2(double* flops, double* bytes, float* ms, int* kind, int max_records) {
     std::lock_guard<std::mutex> lk(g_mu);
     int n = 0;
     for (auto& r : g_recs) {
@@ -69,6 +73,7 @@ extern "C" int egv_prof_collect(double* flops, float* ms, int* kind, int max_rec
         float t = 0.f;
         hipEventElapsedTime(&t, r.a, r.b);
         flops[n] = r.flops; ms[n] = t; kind[n] = r.kind;
+        if (bytes) bytes[n] = r.bytes;
         ++n;
     }
     return n;

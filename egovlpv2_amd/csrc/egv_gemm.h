@@ -113,5 +113,5 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, OutT* C, int m
 
 }  // namespace egv
 
-// egv_gemm2.hip: returns 1 if the 256-row glds kernel covers the call (and enqueued it)
+// egv_gemm2.hip: non-zero if a DMA-staged kernel covered the call (and enqueued it): 1 ring 256x128 / wgrad, 2 persistent ping-pong, 3 ring 128x128
 int egv_gemm2_launch(const egv::GemmArgs& g, int a_trans, int b_trans, int out_f32, int nz, hipStream_t st);

@@ -272,7 +272,7 @@ static int launch_gemm(const GemmArgs& g, int nz, hipStream_t st) {
 using namespace egv;
 
 void* egv_prof_begin(void* stream);
-void egv_prof_end(void* handle, void* stream, double flops, int kind);
+void egv_prof_end(void* handle, void* stream, double flops, int kind, double bytes);
 
 static inline int vec_ok(const void* p, int ld, int dtype) {
     const int vec = dtype == EGV_BF16 ? 8 : 4;
@@ -302,9 +302,13 @@ extern "C" int egv_gemm(int dtype, int a_trans, int b_trans, int M, int N, int K
     g.e.bias = bias; g.e.gate = gate; g.e.res1 = res1; g.e.res2 = res2; g.e.pre = pre; g.e.aux = aux;
     g.e.act = act; g.e.dact = dact; g.e.ldr = ldr ? ldr : ldc; g.e.scale = scale;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const double es_ = dtype == EGV_BF16 ? 2.0 : 4.0;
+    // algorithmic bytes: operands + output once, plus every epilogue operand that is read or written
+    const double abytes = es_ * ((double)M * K + (double)N * K + (double)M * N * (1 + (res1 != nullptr) + (res2 != nullptr) + (pre != nullptr) + (aux != nullptr)));
     void* ph = egv_prof_begin(stream);
-    if (dtype == EGV_BF16 && egv_gemm2_launch(g, a_trans, b_trans, out_f32, 1, st)) {
-        egv_prof_end(ph, stream, 2.0 * M * N * K, 8 + (b_trans ? 1 : 0));
+    const int took = dtype == EGV_BF16 ? egv_gemm2_launch(g, a_trans, b_trans, out_f32, 1, st) : 0;
+    if (took) {
+        egv_prof_end(ph, stream, 2.0 * M * N * K, took == 2 ? 12 : (took == 3 ? 13 : 8), abytes);   // 8 ring 256x128, 12 persistent ping-pong, 13 ring 128x128
         EGV_LAUNCH_CHECK();
         return 0;
     }
@@ -318,7 +322,7 @@ extern "C" int egv_gemm(int dtype, int a_trans, int b_trans, int M, int N, int K
     }
     if (dtype == EGV_BF16) { EGV_DISPATCH(bf16_t) } else { EGV_DISPATCH(float) }
 #undef EGV_DISPATCH
-    egv_prof_end(ph, stream, 2.0 * M * N * K, (dtype == EGV_BF16 ? 0 : 4) + (b_trans ? 1 : 0));
+    egv_prof_end(ph, stream, 2.0 * M * N * K, (dtype == EGV_BF16 ? 0 : 4) + (b_trans ? 1 : 0), abytes);
     EGV_LAUNCH_CHECK();
     return 0;
 }
@@ -407,7 +411,7 @@ extern "C" int egv_gemm_wgrad(int dtype, int M, int N, int K, const void* dY, in
     if (v2) {
         if (dbias) g.colsum = bias_part;
         if (egv_gemm2_launch(g, 1, 1, 1, nz, st)) {
-            egv_prof_end(ph, stream, 2.0 * M * N * K, 10);
+            egv_prof_end(ph, stream, 2.0 * M * N * K, 10, 2.0 * ((double)M * N + (double)M * K) + 4.0 * N * K);
             bias_fused = dbias != nullptr;
         } else {
             v2 = false;
@@ -417,7 +421,7 @@ extern "C" int egv_gemm_wgrad(int dtype, int M, int N, int K, const void* dY, in
     if (!v2) {
         if (dtype == EGV_BF16) launch_gemm<bf16_t, 1, 1, float>(g, nz, st);
         else launch_gemm<float, 1, 1, float>(g, nz, st);
-        egv_prof_end(ph, stream, 2.0 * M * N * K, (dtype == EGV_BF16 ? 0 : 4) + 2);
+        egv_prof_end(ph, stream, 2.0 * M * N * K, (dtype == EGV_BF16 ? 0 : 4) + 2, (dtype == EGV_BF16 ? 2.0 : 4.0) * ((double)M * N + (double)M * K) + 4.0 * N * K);
     }
     EGV_LAUNCH_CHECK();
     const bool fuse_bias_reduce = dbias && bias_fused && nz > 1;

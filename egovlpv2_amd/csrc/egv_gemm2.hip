@@ -404,9 +404,9 @@ int egv_gemm2_launch(const GemmArgs& g, int a_trans, int b_trans, int out_f32, i
     }
     {
         static const int pp = getenv("EGV_GEMM_PP") ? atoi(getenv("EGV_GEMM_PP")) : 1;     // persistent ping-pong kernel (egv_gemm3.hip) for large grids; 0 = ring kernels only
-        if (pp && (long long)((g.M + 255) / 256) * ((g.N + 255) / 256) >= 64 && egv_gemm3_launch(g, st)) return 1;
+        if (pp && (long long)((g.M + 255) / 256) * ((g.N + 255) / 256) >= 64 && egv_gemm3_launch(g, st)) return 2;   // 2: persistent kernel
         const long long tb = (long long)((g.M + 255) / 256) * ((g.N + 127) / 128);
-        if (tb <= 128) launch_ring<CfgC, 6>(g, st);     // latency-bound small grids (text tokens): 128x128 tiles, 5 K-tiles in flight
+        if (tb <= 128) { launch_ring<CfgC, 6>(g, st); return 3; }   // 3: small-grid ring     // latency-bound small grids (text tokens): 128x128 tiles, 5 K-tiles in flight
         else launch_ring<CfgB, 3>(g, st);      // 256x128 tile x 3 stages = 72 KB: 2 workgroups per CU (epilogue of one overlaps the K loop of the other)
     }
     return 1;

@@ -1117,10 +1117,11 @@ def prof_reset():
 
 def prof_collect(max_records: int = 1 << 16):
     fl = (C.c_double * max_records)()
+    by = (C.c_double * max_records)()
     ms = (C.c_float * max_records)()
     kd = (C.c_int * max_records)()
-    n = lib.egv_prof_collect(fl, ms, kd, max_records)
-    return [(fl[i], ms[i], kd[i]) for i in range(n)]
+    n = lib.egv_prof_collect2(fl, by, ms, kd, max_records)
+    return [(fl[i], ms[i], kd[i], by[i]) for i in range(n)]
 
 
 def invalidate_weight_cache():

@@ -239,6 +239,8 @@ int egv_prof_enable(int on);
 int egv_prof_reset(void);
 /* synchronises the recorded events; returns the number of (flops, ms) records copied to the HOST arrays */
 int egv_prof_collect(double* flops, float* ms, int* kind, int max_records);
+/* the same plus the algorithmic bytes of each launch (operands, output and epilogue operands once) */
+int egv_prof_collect2(double* flops, double* bytes, float* ms, int* kind, int max_records);
 
 #ifdef __cplusplus
 }
