@@ -749,6 +749,70 @@ class _GradPack:
             off += n
 
 
+# Parameter gradients of a block that is used several times per step (EgoNCE / MLM / ITM passes share the backbones): every
+# backward call writes its own flat pack; calls after the first add theirs to the first one with ONE flat add, and only the call
+# that completes the step's uses hands gradients to autograd -- instead of autograd accumulating ~27 tensors per block call
+# with one small ATen add each (809 launches per step).  AccumulateGrad (and with it DDP's reducer hook) then fires once per
+# parameter and step.  If a backward pass ends with uses outstanding (partial graphs), the pending sums are flushed into .grad.
+_acc = {}
+_acc_cb = [False]
+
+
+def _acc_forward(key, needs_grad, fused):
+    """key identifies the block; its parameters split into the SHARED set (used by the fused and the unfused form of the block)
+    and the EXTRA set (cross-attention parameters, fused form only): each has its own use count"""
+    if needs_grad:
+        for k in ((key, 0), (key, 1)) if fused else ((key, 0),):
+            e = _acc.setdefault(k, {'uses': 0, 'done': 0, 'flat': None, 'views': None, 'params': None})
+            e['uses'] += 1
+
+
+def _acc_flush():
+    _acc_cb[0] = False
+    for key in list(_acc.keys()):
+        e = _acc[key]
+        if e['done'] and e['flat'] is not None:              # a backward pass ended before every use of the block came back
+            with torch.no_grad():
+                for p, g in zip(e['params'], e['views']):
+                    if p.requires_grad:
+                        p.grad = g.clone() if p.grad is None else p.grad.add_(g)
+            e['uses'] -= e['done']
+            e['done'], e['flat'] = 0, None
+        if e['uses'] <= 0:
+            del _acc[key]
+
+
+def _acc_part(k, flat, views, params):
+    e = _acc.get(k)
+    if e is None:                                             # forward ran without bookkeeping (should not happen): plain path
+        return views
+    if e['flat'] is None:
+        e['flat'], e['views'], e['params'] = flat, views, params
+    else:
+        e['flat'].add_(flat)
+    e['done'] += 1
+    if e['done'] >= e['uses']:
+        del _acc[k]
+        return e['views']
+    if not _acc_cb[0]:
+        _acc_cb[0] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_acc_flush)
+    return [None] * len(params)
+
+
+def _acc_backward(key, pack, params, nshared):
+    ns = sum(p.numel() for p in params[:nshared])
+    out = list(_acc_part((key, 0), pack.flat[:ns], pack.views[:nshared], params[:nshared]))
+    if len(params) > nshared:
+        out += list(_acc_part((key, 1), pack.flat[ns:], pack.views[nshared:], params[nshared:]))
+    return out
+
+
+def begin_step():
+    """forget gradient bookkeeping of an aborted step (called at the top of FrozenInTime.forward)"""
+    _acc.clear()
+
+
 class VideoBlockFn(Function):
     """SpaceTimeBlock.forward (video_transformer.py:214-228).  params = [W, b] x 6 (timeattn.qkv, timeattn.proj, attn.qkv,
     attn.proj, mlp.fc1, mlp.fc2), [gamma, beta] x 3 (norm3, norm1, norm2) and, for a fused block, [W, b] x 3 (qkv_text_i2t,
@@ -788,6 +852,8 @@ class VideoBlockFn(Function):
         d.out, d.save, d.save_bytes, d.ws, d.ws_bytes = _p(out), _p(save), nsave, _p(ws), ws.numel()
         check(lib.egv_vblock_fwd(C.byref(d)), 'egv_vblock_fwd')
         ctx.cfg = cfg
+        ctx.key = ('v', id(params[0]))
+        _acc_forward(ctx.key, any(ctx.needs_input_grad[4:]), cfg[6] > 0)
         ctx.save_for_backward(x, y, y_mask, save, *params)
         return out
 
@@ -818,7 +884,7 @@ class VideoBlockFn(Function):
             d.dalpha = _p(g[26])
         d.stream2 = _side_stream_ptr()
         check(lib.egv_vblock_bwd(C.byref(d)), 'egv_vblock_bwd')
-        return (None, dx, dy, None, *g)
+        return (None, dx, dy, None, *_acc_backward(ctx.key, gp, params, 18))
 
 
 def video_block(x, params, B, Fr, N, H, Hd, eps, y=None, y_mask=None, L=0):
@@ -865,6 +931,8 @@ class TextLayerFn(Function):
         d.out, d.save, d.save_bytes, d.ws, d.ws_bytes = _p(out), _p(save), nsave, _p(ws), ws.numel()
         check(lib.egv_tlayer_fwd(C.byref(d)), 'egv_tlayer_fwd')
         ctx.cfg = cfg
+        ctx.key = ('t', id(params[0]))
+        _acc_forward(ctx.key, any(ctx.needs_input_grad[4:]), cfg[5] > 0)
         ctx.save_for_backward(hid, mask, enc, save, *params)
         return out
 
@@ -893,7 +961,7 @@ class TextLayerFn(Function):
             d.dalpha = _p(g[24])
         d.stream2 = _side_stream_ptr()
         check(lib.egv_tlayer_bwd(C.byref(d)), 'egv_tlayer_bwd')
-        return (None, dhid, None, denc, *g)
+        return (None, dhid, None, denc, *_acc_backward(ctx.key, gp, params, 16))
 
 
 def text_layer(hid, mask, params, B, Lt, H, Hd, eps, enc=None, S=0, drop_p=0.0, seeds=(0, 0, 0, 0, 0, 0)):

@@ -469,6 +469,7 @@ class FrozenInTime(nn.Module):
                 task_names='EgoNCE_ITM_MLM'):
         """model.py:370-487.  Returns (loss, loss_dict, ret)."""
         ret, loss_dict = {}, {}
+        ops.begin_step()
         if 'Feature_Extraction' in task_names:                                                   # :375-377
             return self.compute_video(data['video'])
         world = getattr(args, 'world_size', 1)
