@@ -18,6 +18,7 @@
 // Operands are swapped in the MFMA (D = W_frag * X_frag^T) so that every lane owns 4 consecutive
 // output columns of one row: bias / residual / aux loads and the store are 8-16 B vectors.
 #include "egv_gemm.h"
+#include <cstdlib>
 
 namespace egv {
 
@@ -343,6 +344,18 @@ static inline int wgrad_splits(int tiles, int M, long long out_elems, double flo
     return best;
 }
 
+int egv_gemm4_launch(const egv::GemmArgs& g, int nz, hipStream_t st);
+// ping-pong weight-gradient kernel (egv_gemm4.hip): 256x256 tiles, one (tile, split) item per CU
+static inline bool wgrad_use_pp(int dtype, int M, int N, int K) {
+    static const int on = getenv("EGV_WGRAD_PP") ? atoi(getenv("EGV_WGRAD_PP")) : 1;
+    return on && dtype == EGV_BF16 && (N % 256) == 0 && (K % 256) == 0 && M >= 4096 && (N / 256) * (K / 256) <= 128;
+}
+static inline int wgrad_pp_splits(int M, int N, int K) {
+    const int tiles = (N / 256) * (K / 256);
+    int nz = 256 / tiles;
+    while (nz > 1 && M / nz < 512) --nz;
+    return nz < 1 ? 1 : nz;
+}
 static inline bool wgrad_use_gemm2(int dtype, int M, int N, int K) { return dtype == EGV_BF16 && N >= 128 && K >= 64 && M >= 256; }
 
 static inline int wgrad_plan(int dtype, int M, int N, int K, bool& v2) {
@@ -360,7 +373,8 @@ extern "C" long long egv_gemm_wgrad_workspace_bytes(int N, int K, int M) {
     const int nz = wgrad_plan(EGV_BF16, M, N, K, v2);
     bool v2f;
     const int nzf = wgrad_plan(EGV_F32, M, N, K, v2f);
-    const long long z = nz > nzf ? nz : nzf;
+    long long z = nz > nzf ? nz : nzf;
+    if (wgrad_use_pp(EGV_BF16, M, N, K) && wgrad_pp_splits(M, N, K) > z) z = wgrad_pp_splits(M, N, K);
     return z * N * K * 4 + z * N * 4 + (long long)32 * N * 4 + 4096;
 }
 
@@ -377,6 +391,8 @@ extern "C" int egv_gemm_wgrad(int dtype, int M, int N, int K, const void* dY, in
     EGV_CHECK(workspace && workspace_bytes >= egv_gemm_wgrad_workspace_bytes(N, K, M), "egv_gemm_wgrad: workspace too small");
     bool v2;
     int nz = wgrad_plan(dtype, M, N, K, v2);
+    const bool pp = wgrad_use_pp(dtype, M, N, K);
+    if (pp) nz = wgrad_pp_splits(M, N, K);
     const int bk = dtype == EGV_BF16 ? 64 : 32;
     int kper = (M + nz - 1) / nz;
     kper = ((kper + bk - 1) / bk) * bk;
@@ -412,7 +428,7 @@ extern "C" int egv_gemm_wgrad(int dtype, int M, int N, int K, const void* dY, in
         // one split, no scaling: the kernel's column sums ARE the bias gradient (no reduction / copy launch)
         const bool bias_direct = dbias && nz == 1 && scale == 1.0f && gate == nullptr;
         if (dbias) g.colsum = bias_direct ? dbias : bias_part;
-        if (egv_gemm2_launch(g, 1, 1, 1, nz, st)) {
+        if ((pp && egv_gemm4_launch(g, nz, st)) || egv_gemm2_launch(g, 1, 1, 1, nz, st)) {
             egv_prof_end(ph, stream, 2.0 * M * N * K, 10, 2.0 * ((double)M * N + (double)M * K) + 4.0 * N * K);
             bias_fused = dbias != nullptr;
             if (bias_direct) dbias = nullptr;          // done
