@@ -56,23 +56,24 @@ __device__ __forceinline__ PPTile pp_tile(int t, int tiles_n) {
 // decides the count of the phase's s_waitcnt.
 enum { PP_PLAIN = 0, PP_LAST = 1, PP_FIRST_CHAIN = 2, PP_FIRST_COLD = 3, PP_SECOND_CHAIN = 4, PP_SECOND_COLD = 5 };
 
-// extra vector-memory operations issued in phase p of a K-tile of kind `kind` (NSQ stores per quadrant epilogue, NX operand
-// loads per quadrant, 1 bias DMA per tile)
-__host__ __device__ constexpr int pp_extra(int kind, int p, int NSQ, int NX, int x1k) {
-    if (kind == PP_LAST) return p == 1 ? 1 : (p >= 2 ? NX : 0);
-    if (kind == PP_FIRST_CHAIN) return ((p & 1) ? 0 : 2 * NSQ) + (p < 2 ? NX : 0);
-    if (kind == PP_FIRST_COLD) return (x1k == 1 && p < 2) ? NX : 0;
+// extra vector-memory operations issued in phase p of a K-tile of kind `kind` (NSQ stores per quadrant of a deferred epilogue,
+// 1 bias DMA per tile); with a BULK epilogue (residual / GELU' operand kinds) the tile's NST stores are issued between the
+// last K-tile and the next tile's first one
+__host__ __device__ constexpr int pp_extra(int kind, int p, int NSQ, bool bulk) {
+    if (kind == PP_LAST) return p == 1 ? 1 : 0;
+    if (kind == PP_FIRST_CHAIN && !bulk) return (p & 1) ? 0 : 2 * NSQ;
     return 0;
 }
 __host__ __device__ constexpr int pp_prev_kind(int kind) {
     return kind == PP_FIRST_CHAIN ? PP_LAST : kind == PP_SECOND_CHAIN ? PP_FIRST_CHAIN : kind == PP_SECOND_COLD ? PP_FIRST_COLD : PP_PLAIN;
 }
 // operations younger than the unit staged 4 phases ago, at the wait of phase p: the DMAs of the last 4 phases + the extras
-__host__ __device__ constexpr int pp_nwait(int kind, int p, int NSQ, int NX, int x1k) {
+__host__ __device__ constexpr int pp_nwait(int kind, int p, int NSQ, bool bulk) {
     int n = 8;
-    for (int q = 0; q <= p; ++q) n += pp_extra(kind, q, NSQ, NX, x1k);
+    for (int q = 0; q <= p; ++q) n += pp_extra(kind, q, NSQ, bulk);
     if (kind != PP_FIRST_COLD)                      // before a cold first K-tile there is only the prologue (nothing younger)
-        for (int q = p + 1; q < 4; ++q) n += pp_extra(pp_prev_kind(kind), q, NSQ, NX, x1k);
+        for (int q = p + 1; q < 4; ++q) n += pp_extra(pp_prev_kind(kind), q, NSQ, bulk);
+    if (kind == PP_FIRST_CHAIN && bulk) n += 4 * NSQ;  // the previous tile's bulk epilogue (all of its stores) sits between the tiles
     return n;
 }
 
@@ -83,7 +84,7 @@ __host__ __device__ constexpr int pp_nwait(int kind, int p, int NSQ, int NX, int
 template <int X1K, bool PREK, bool ACTK, bool STAMPS = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntiles) {
     constexpr int NSQ = PREK ? 8 : 4;
-    constexpr int NX = X1K ? 4 : 0;
+    constexpr bool BULK = X1K != 0;                                // residual / GELU' operand: epilogue in one piece at the tile's end
     constexpr unsigned int OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -231,17 +232,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
         const unsigned int voff = (unsigned int)min(tb.n0 + lane * 4, g.N - 4) * 4u;
         glds(has_bias ? (const void*)e.bias : g.B, has_bias ? voff : 0u, __builtin_amdgcn_readfirstlane(bias_lds));
     };
-    u32x4_t xq[2][4];                                             // operand vectors of two quadrants in flight: slot = quadrant & 1
-    auto load_x = [&](int q, const PPTile& tl, bool valid) {      // q compile-time
-        const int s = q >> 1, t = (q == 1 || q == 2) ? 1 : 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xq[q & 1][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, q_off(tl, valid, s, i, t, false), 0, 0);
-    };
-
     f32x4_t acc[8][4];                                            // (s*4+i, t*2+j'); written by the first MFMAs of every tile
     bf16x8_t af[4][2], bf0[2][2], bf1[2][2];
 
     // convert + store the two quadrants (s, 0), (s, 1) of the finished tile `tl`: 8 full-line stores (16 with the pre-activation)
+    u32x4_t xop[2][4][2];                                         // bulk epilogue: residual / GELU' operand vectors (s, i, t) of the tile
     auto pair_epilogue = [&](int s, const PPTile& tl) {           // s compile-time
         float bias8[2][8];                                        // the finished tile's bias from this wave's LDS slab
         {
@@ -289,6 +284,27 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] *= gate;
+                if (X1K == 1) {
+                    const u32x4_t r = xop[s][i][t];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { v[2 * k] += __uint_as_float(r[k] << 16); v[2 * k + 1] += __uint_as_float(r[k] & 0xffff0000u); }
+                }
+                if (X1K == 2) {
+                    const u32x4_t r = xop[s][i][t];
+                    if (e.dact == 1) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            v[2 * k] *= dgelu_fast_f(__uint_as_float(r[k] << 16));
+                            v[2 * k + 1] *= dgelu_fast_f(__uint_as_float(r[k] & 0xffff0000u));
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            v[2 * k] *= apply_dact(__uint_as_float(r[k] << 16), e.dact);
+                            v[2 * k + 1] *= apply_dact(__uint_as_float(r[k] & 0xffff0000u), e.dact);
+                        }
+                    }
+                }
                 o[t] = u32x4_t{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
             }
             pair_swap(o[0], o[1], f, sec);
@@ -300,7 +316,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
     // ---- prologue: the first tile's bias (and residual quadrants 0, 1) first, then U0..U3 of K-tile 0 and U0 U1 of K-tile 1
     // (the units the steady-state schedule would have issued before phase 0)
     PPTile cur = pp_tile(first, g.tiles_n);
-    if (X1K == 1) { load_x(0, cur, true); load_x(1, cur, true); }
     stage_unit(0); stage_unit(1); stage_unit(2); stage_unit(3);
     advance_cursor();
     stage_unit(0); stage_unit(1);
@@ -329,10 +344,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
         const unsigned char* buf = smem + ((BUFIDX) & 1) * PP_BUF;                                                         \
         /* ---------------- phase 0: read A sub 0 (U0) + B sub 0 (U1); stage U2 of kt+1; quadrant 0 = (0,0) */             \
         {                                                                                                                  \
-            if (CHAIN) pp_wait_vmcnt<6 + 2 * NX>();         /* the bias DMA of LAST phase 1 (this wave's own slab) landed */ \
-            if (CHAIN) pair_epilogue(0, prev);                                                                             \
-            if (X1K == 1 && FIRSTK) load_x(2, cur, true);                                                                  \
-            if (X1K == 2 && CHAIN) load_x(2, prev, true);                                                                  \
+            if (CHAIN && !BULK) pp_wait_vmcnt<6>();         /* the bias DMA of LAST phase 1 (this wave's own slab) landed */ \
+            if (CHAIN && !BULK) pair_epilogue(0, prev);                                                                             \
             const unsigned char* pa = buf + 0 * PP_UNIT + a_base;                                                          \
             const unsigned char* pb = buf + 1 * PP_UNIT + b_base;                                                          \
             _Pragma("unroll") for (int jp = 0; jp < 2; ++jp) {                                                             \
@@ -344,7 +357,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                 af[i][1] = *reinterpret_cast<const bf16x8_t*>(pa + i * 2048 + swz1);                                       \
             }                                                                                                              \
             stage_unit(2);                                                                                                 \
-            pp_wait_vmcnt<pp_nwait(KIND, 0, NSQ, NX, X1K)>();                                                              \
+            pp_wait_vmcnt<pp_nwait(KIND, 0, NSQ, BULK)>();                                                              \
             __builtin_amdgcn_s_barrier();                                                                                  \
             PP_MFMA(0, bf0, 0, FIRSTK);                                                                                 \
             __builtin_amdgcn_s_barrier();                                                                                  \
@@ -352,8 +365,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
         /* ---------------- phase 1: read B sub 1 (U2); stage U3 of kt+1; quadrant 1 = (0,1) */                            \
         {                                                                                                                  \
             if (LASTK) load_bias(cur);                                                                                    \
-            if (X1K == 1 && FIRSTK) load_x(3, cur, true);                                                                  \
-            if (X1K == 2 && CHAIN) load_x(3, prev, true);                                                                  \
             const unsigned char* pb = buf + 2 * PP_UNIT + b_base;                                                          \
             _Pragma("unroll") for (int jp = 0; jp < 2; ++jp) {                                                             \
                 bf1[jp][0] = *reinterpret_cast<const bf16x8_t*>(pb + jp * 2048 + swz0);                                    \
@@ -361,33 +372,29 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
             }                                                                                                              \
             stage_unit(3);                                                                                                 \
             advance_cursor();                                                                                              \
-            pp_wait_vmcnt<pp_nwait(KIND, 1, NSQ, NX, X1K)>();                                                              \
+            pp_wait_vmcnt<pp_nwait(KIND, 1, NSQ, BULK)>();                                                              \
             __builtin_amdgcn_s_barrier();                                                                                  \
             PP_MFMA(0, bf1, 1, FIRSTK);                                                                                 \
             __builtin_amdgcn_s_barrier();                                                                                  \
         }                                                                                                                  \
         /* ---------------- phase 2: read A sub 1 (U3); stage U0 of kt+2; quadrant 2 = (1,1) */                            \
         {                                                                                                                  \
-            if (CHAIN) pair_epilogue(1, prev);                                                                             \
-            if (X1K == 1 && LASTK) load_x(0, nxt, have_next);                                                              \
-            if (X1K == 2 && LASTK) load_x(0, cur, true);                                                                   \
+            if (CHAIN && !BULK) pair_epilogue(1, prev);                                                                             \
             const unsigned char* pa = buf + 3 * PP_UNIT + a_base;                                                          \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
                 af[i][0] = *reinterpret_cast<const bf16x8_t*>(pa + i * 2048 + swz0);                                       \
                 af[i][1] = *reinterpret_cast<const bf16x8_t*>(pa + i * 2048 + swz1);                                       \
             }                                                                                                              \
             stage_unit(0);                                                                                                 \
-            pp_wait_vmcnt<pp_nwait(KIND, 2, NSQ, NX, X1K)>();                                                              \
+            pp_wait_vmcnt<pp_nwait(KIND, 2, NSQ, BULK)>();                                                              \
             __builtin_amdgcn_s_barrier();                                                                                  \
             PP_MFMA(1, bf1, 1, FIRSTK);                                                                                 \
             __builtin_amdgcn_s_barrier();                                                                                  \
         }                                                                                                                  \
         /* ---------------- phase 3: no reads; stage U1 of kt+2; quadrant 3 = (1,0) */                                     \
         {                                                                                                                  \
-            if (X1K == 1 && LASTK) load_x(1, nxt, have_next);                                                              \
-            if (X1K == 2 && LASTK) load_x(1, cur, true);                                                                   \
             stage_unit(1);                                                                                                 \
-            pp_wait_vmcnt<pp_nwait(KIND, 3, NSQ, NX, X1K)>();                                                              \
+            pp_wait_vmcnt<pp_nwait(KIND, 3, NSQ, BULK)>();                                                              \
             __builtin_amdgcn_s_barrier();                                                                                  \
             PP_MFMA(1, bf0, 0, FIRSTK);                                                                                 \
             __builtin_amdgcn_s_barrier();                                                                                  \
@@ -420,6 +427,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
         PP_KTILE(PP_LAST, kb + KT - 1);
         PP_STAMP(KT);
         if (wr == 0) __builtin_amdgcn_s_barrier();
+        if (BULK) {
+            // all 16 operand vectors first (a load issued after a store would wait for it), then convert + store; the stores
+            // drain under the next tile's first K-tile (counted in its waits)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        xop[s][i][t] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, q_off(cur, true, s, i, t, false), 0, 0);
+            pp_wait_vmcnt<6 + 16>();                               // the bias DMA of LAST phase 1 (16 operand loads are younger)
+            pair_epilogue(0, cur);
+            pair_epilogue(1, cur);
+        }
         prev = cur;
         cur = nxt;
     }
@@ -428,8 +449,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
 #undef PP_STAMP
     // ---- the last tile's epilogue
     pp_wait_vmcnt<0>();                                           // its bias slab (and the dummy DMAs)
-    pair_epilogue(0, prev);
-    pair_epilogue(1, prev);
+    if (!BULK) {
+        pair_epilogue(0, prev);
+        pair_epilogue(1, prev);
+    }
     pp_wait_vmcnt<0>();
 }
 
@@ -476,7 +499,9 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
         hipLaunchKernelGGL((gemm_pp_kernel<X, P, AC>), dim3(grid), dim3(512), PP_LDS, st, g, ntiles);                    \
         return 1;                                                                                                        \
     } while (0)
-    if (e.res1 || e.dact) return 0;                               // residual / GELU' operand epilogues: ring kernel (the operand prefetch does not fit the register budget yet)
+    if (e.res1 && g.K < 1536) return 0;                           // short-K residual GEMMs (attention projections): the 2-workgroup ring kernel hides their epilogue better
+    if (e.res1) PP_LAUNCH(1, false, false);
+    if (e.dact) PP_LAUNCH(2, false, false);
     if (e.pre) PP_LAUNCH(0, true, true);
     if (e.act) PP_LAUNCH(0, false, true);
     static const bool stamps = getenv("EGV_PP_STAMPS") != nullptr;                       // instrumentation build of the plain kind
