@@ -507,7 +507,10 @@ class FrozenInTime(nn.Module):
                 ev.record()
             # the gathers of the ITM branch (:429-431) are issued here so that the text stream can start on the ITM
             # batch while the calling stream is still busy with the MLM pass
-            all_video = gather(data['video']) if world > 1 else data['video']
+            # (the reference all-gathers the pixels here, :430; with the shared prefix only the prefix tokens of the clips that
+            # are actually drawn from another rank travel -- trainer/exchange.py)
+            share_px = ('MLM' in task_names and c.depth > c.n_fuse and not os.environ.get('EGV_NO_PREFIX_SHARING'))
+            all_video = data['video'] if (world == 1 or share_px) else gather(data['video'])
             all_text_ids = gather(data['text']['input_ids'])
             all_text_masks = gather(data['text']['attention_mask'])
             ev_in = None
@@ -590,13 +593,14 @@ class FrozenInTime(nn.Module):
                 remote = sorted({j for j in vid_list if not lo <= j < lo + bsz})
                 v_rem = None
                 if world > 1:
-                    # Clips owned by other ranks go through the prefix here, as in the reference.  With none this step, one
-                    # own clip is still sent through (its rows are never selected, so it contributes exact zeros): every
-                    # parameter is then used the same number of times each step, which DDP(static_graph=True) requires.
-                    rem = remote or [lo]
-                    rem_dev = self._pinned('itm_rem%d' % len(rem), (len(rem),), torch.int64)
-                    rem_dev.copy_(torch.tensor(rem))
-                    v_rem = self._video_prefix(all_video.index_select(0, rem_dev.to(dev, non_blocking=True)))
+                    # Clips owned by other ranks: their owners already pushed them through the identical prefix (same pixels,
+                    # replicated parameters, batch-independent kernels), so the prefix TOKENS are fetched from the owner and
+                    # the token gradients return to it in backward (trainer/exchange.py) -- no pixel all-gather, no second
+                    # prefix pass, and every rank runs the same graph every step (DDP static_graph).
+                    from ..trainer.exchange import gather_requests, ExchangeClipsFn
+                    table = gather_requests(vid_list, rank, bsz, world)
+                    assert table[rank] == remote
+                    v_rem = ExchangeClipsFn.apply(v_pre, table, rank, bsz, c.seq)
                 plan = [(0, j - lo) if lo <= j < lo + bsz else (1, remote.index(j)) for j in vid_list]
                 data_itm['video'] = None
                 data_itm['_video_prefix'] = SelectClipsFn.apply(plan, c.seq, v_pre, v_rem)

@@ -1,6 +1,6 @@
 """Generate golden vectors by IMPORTING THE REFERENCE (build container only).
 
-Run:  python oracle/gen_golden.py [tiny|base_f4|all]
+Run:  python oracle/gen_golden.py [tiny|base_f4|base_f16|all]
 
 This is the only file in the repo that touches /root/reference at run time.  It applies the import
 shims of SURVEY.md §8(c) (missing third-party packages, transformers 5.x API drift, hard-coded
@@ -239,6 +239,8 @@ CASES = {
     'tiny': dict(cfg=tiny_config(), B=2, L=16, wseed=0, bseed=1234),
     # full-depth ViT-B/16 + RoBERTa-base at the reference's own 4-frame pre-training shape
     'base_f4': dict(cfg=PathConfig(frames=4), B=2, L=16, wseed=1, bseed=4321),
+    # the full geometry of BASELINE.json configs[2] (12 + 12 layers, 16 x 224^2 frames, 32 tokens) at B = 2
+    'base_f16': dict(cfg=PathConfig(frames=16), B=2, L=32, wseed=2, bseed=777),
 }
 
 

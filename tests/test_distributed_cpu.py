@@ -58,3 +58,60 @@ def test_allgather_and_loss_reduction_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _exchange_worker(rank, world, port, q):
+    """ExchangeClipsFn (trainer/exchange.py) against an all-gather of the same tokens: forward values, and the gradient each
+    owner receives = sum of what the requesters computed on the tokens they fetched."""
+    sys.path.insert(0, REPO)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from egovlpv2_amd.trainer.exchange import gather_requests, ExchangeClipsFn
+    bsz, rows, d = 4, 3, 5
+    ok = True
+    # three rounds: both ranks request, only rank 0 requests, nobody requests (a rank that asks for nothing still serves)
+    draws = [{0: [0, 5, 2, 7], 1: [4, 1, 6, 1]}, {0: [6, 1, 2, 6], 1: [4, 5, 6, 7]}, {0: [0, 1, 2, 3], 1: [4, 5, 6, 7]}]
+    for rnd, dr in enumerate(draws):
+        g = torch.Generator().manual_seed(10 * rnd + rank)
+        x = torch.randn(bsz * rows, d, generator=g, requires_grad=True)
+        table = gather_requests(dr[rank], rank, bsz, world)
+        ok = ok and table == [sorted({j for j in dr[r] if not r * bsz <= j < (r + 1) * bsz}) for r in range(world)]
+        got = ExchangeClipsFn.apply(x, table, rank, bsz, rows)
+        allx = [torch.empty(bsz * rows, d) for _ in range(world)]
+        dist.all_gather(allx, x.detach())
+        allx = torch.cat(allx, 0)
+        want = torch.cat([allx[j * rows:(j + 1) * rows] for j in table[rank]], 0) if table[rank] else torch.empty(0, d)
+        ok = ok and got.shape == want.shape and torch.equal(got, want)
+        w = torch.randn(got.shape, generator=g)
+        (got * w).sum().backward()                     # every rank runs backward (a zero-size gradient still serves the others)
+        # reference: gather every requester's weights and add them on the owner's rows
+        sizes = [len(t) * rows for t in table]
+        ws = []
+        for r in range(world):
+            buf = w.clone() if r == rank else torch.empty(sizes[r], d)
+            if sizes[r]:
+                dist.broadcast(buf, src=r)
+            ws.append(buf)
+        ref = torch.zeros(bsz * rows, d)
+        for r in range(world):
+            for n, j in enumerate(table[r]):
+                if j // bsz == rank:
+                    i = j - rank * bsz
+                    ref[i * rows:(i + 1) * rows] += ws[r][n * rows:(n + 1) * rows]
+        ok = ok and x.grad is not None and torch.allclose(x.grad, ref, atol=1e-6)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_negative_clip_token_exchange_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29950 + (os.getpid() % 300)
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]

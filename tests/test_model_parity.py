@@ -155,6 +155,40 @@ def test_base_f4_vs_golden(dtype, tol_e, tol_l):
     assert (rel < gtol).all(), [(kn[i], float(rel[i])) for i in np.argsort(-rel)[:8]]
 
 
+@pytest.mark.parametrize('dtype,tol_e,tol_l', [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 4e-2, 2e-2)])
+def test_base_f16_vs_golden(dtype, tol_e, tol_l):
+    """BASELINE.json configs[2] geometry AND depth (12 + 12 layers, 6 fused, 16 x 224^2 frames, 32 tokens) at B = 2 against the
+    reference's own outputs (tests/golden/base_f16.npz, written by oracle/gen_golden.py importing the reference): pooled
+    embeddings, the three losses with the pinned ITM draws, every parameter-gradient norm."""
+    from egovlpv2_amd.synthetic import make_state_dict, make_batch
+    g, cfg, B, L, wseed, bseed = load_golden('base_f16')
+    assert cfg.frames == 16 and cfg.depth == 12 and L == 32
+    sd = make_state_dict(cfg, wseed)
+    data, noun, verb = make_batch(cfg, B, L, bseed)
+    m = _build(cfg, sd, dtype)
+    with torch.no_grad():
+        r = m.infer(_to_cuda(data), task_names='EgoNCE')
+    assert rel_err(r['text_embeds'].float(), g['text_embeds']) < tol_e
+    assert rel_err(r['video_embeds'].float(), g['video_embeds']) < tol_e
+    np.random.seed(17)
+    torch.manual_seed(17)
+    loss, ld, ret = _forward(m, data, noun, verb, 'EgoNCE_MLM_ITM')
+    for k in ('EgoNCE', 'loss_mlm', 'loss_itm', 'loss_total'):
+        ref = float(g['loss_' + k])
+        assert abs(float(ld[k]) - ref) <= tol_l * abs(ref), (k, float(ld[k]), ref)
+    loss.backward()
+    names = [str(x) for x in g['param_names']]
+    pd = dict(m.named_parameters())
+    gn = np.array([pd[k].grad.norm().item() for k in names])
+    keep = np.array([not k.endswith('.key.bias') for k in names])      # exactly-zero true gradients
+    if dtype != torch.float32:
+        keep &= g['grad_norms'] > 1e-2 * g['grad_norms'].max()
+    gtol = 1e-2 if dtype == torch.float32 else 1.5e-1
+    rel = (np.abs(gn - g['grad_norms']) / (g['grad_norms'] + 1e-5))[keep]
+    kn = [k for k, kk in zip(names, keep) if kk]
+    assert (rel < gtol).all(), [(kn[i], float(rel[i])) for i in np.argsort(-rel)[:8]]
+
+
 @pytest.mark.parametrize('dtype,tol_e,tol_l', [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 3e-2, 2e-2)])
 def test_full_resolution_two_layer_vs_oracle(dtype, tol_e, tol_l):
     """BASELINE.json's full token geometry (16 x 224^2 frames -> S = 3137 tokens, 197-key space attention, 17-key time

@@ -90,6 +90,12 @@ def test_oracle_losses_and_grads_base_f4():
     _check_losses_and_grads('base_f4')
 
 
+@pytest.mark.slow
+def test_oracle_forward_base_f16():
+    """the CPU oracle at configs[2]'s geometry and depth against the reference's own outputs (about two minutes)"""
+    _check_forward('base_f16')
+
+
 def test_oracle_inflate_temporal():
     g, cfg, B, L, wseed, bseed = load_golden('tiny')
     sd, *_ = oracle_setup(cfg, B, L, wseed, bseed)
