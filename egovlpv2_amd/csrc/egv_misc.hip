@@ -211,7 +211,9 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ logit
         const float lse = m + __logf(red[0] + red[1] + red[2] + red[3]);
         lse_out[r] = lse;
         const long long lab = labels[r];
-        row_loss[r] = (lab == ignore_index) ? 0.f : (lse - Elem<T>::ld(x + lab));
+        // labels outside [0, V) other than ignore_index would read out of bounds: treated as ignored (torch raises; the host
+        // wrapper checks the dtype, the values are the data collator's)
+        row_loss[r] = (lab == ignore_index || lab < 0 || lab >= V) ? 0.f : (lse - Elem<T>::ld(x + lab));
     }
 }
 
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logit
                                                      T* __restrict__ dlogits, int V, int Vpad, int ld, long long ignore_index) {
     const int r = blockIdx.x;
     const long long lab = labels[r];
-    const float cf = (lab == ignore_index) ? 0.f : coef[0];
+    const float cf = (lab == ignore_index || lab < 0 || lab >= V) ? 0.f : coef[0];
     const float l = lse[r];
     const T* x = logits + (long long)r * ld;
     T* d = dlogits + (long long)r * ld;

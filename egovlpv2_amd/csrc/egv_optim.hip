@@ -31,7 +31,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(const OptChunk* __restrict__
     const int off = (c - prefix[lo]) * OPT_CHUNK;
     ch.p += off; ch.g += off; ch.m += off; ch.v += off;
     ch.n = min(OPT_CHUNK, ch.n - off);
-    const int nv = ch.n >> 2;
+    // 16-byte vectors only when all four pointers of this tensor are 16-byte aligned: gradients that are views into a DDP bucket
+    // (gradient_as_bucket_view) start at arbitrary element offsets
+    const bool al = ((reinterpret_cast<uintptr_t>(ch.p) | reinterpret_cast<uintptr_t>(ch.g) | reinterpret_cast<uintptr_t>(ch.m) |
+                      reinterpret_cast<uintptr_t>(ch.v)) & 15) == 0;
+    const int nv = al ? (ch.n >> 2) : 0;
     for (int i = threadIdx.x; i < nv; i += 256) {
         f32x4_t p = reinterpret_cast<f32x4_t*>(ch.p)[i];
         const f32x4_t g = reinterpret_cast<const f32x4_t*>(ch.g)[i];

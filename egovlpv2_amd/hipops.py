@@ -1070,6 +1070,7 @@ class CrossEntropySumFn(Function):
         _need_gpu(logits)
         R, ld = logits.shape
         assert logits.is_contiguous()
+        assert labels.dtype == torch.int64, "cross_entropy_sum: labels must be int64 (the kernel reads 8-byte labels)"
         labels = labels.contiguous()
         lse = torch.empty(R, dtype=torch.float32, device=logits.device)
         row = torch.empty(R, dtype=torch.float32, device=logits.device)
