@@ -110,3 +110,50 @@ def test_mlm_collate_matches_installed_transformers_and_statistics():
     torch.manual_seed(5)
     mine = mlm_collate(ids[:64])
     assert torch.equal(ref['input_ids'], mine['input_ids']) and torch.equal(ref['labels'], mine['labels'])
+
+
+def test_egoclip_sample_format_and_batch_assembly():
+    """sample dict of EgoClip_EgoMCQ_dataset.py:105-130 and the trainer's per-step assembly
+    (trainer/trainer_egoclip.py:112-139): negatives appended after the positives, the tokenizer call shape, MLM collation."""
+    import torch
+    from egovlpv2_amd.trainer.batch import egoclip_sample, collate_samples, assemble_train_batch, HashTokenizer, tag_vectors
+    from egovlpv2_amd.trainer.collate import mlm_collate
+    g = torch.Generator().manual_seed(0)
+    F, R = 4, 32
+    caps = ['#C C opens the drawer', '#C C picks a knife from the table and cuts the onion on the chopping board slowly', '#O man X walks']
+    negs = ['#C C closes the drawer', '#C C puts the knife down', '#C C looks around']
+    samples = []
+    for i in range(3):
+        v = torch.randn(F, 3, R, R, generator=g)
+        vn = torch.randn(F, 3, R, R, generator=g)
+        samples.append(egoclip_sample(v, caps[i], [i, 5 + i], [i], path=f'v{i}.mp4', neg=(vn, negs[i], [7], [2, 3])))
+    s0 = samples[0]
+    assert set(s0) == {'video', 'text', 'video_neg', 'text_neg', 'meta', 'noun_vec', 'verb_vec', 'noun_vec_neg', 'verb_vec_neg'}
+    assert s0['noun_vec'].shape == (582,) and s0['verb_vec'].shape == (118,) and s0['noun_vec'].sum() == 2 and s0['verb_vec_neg'].sum() == 2
+    nv, vv = tag_vectors([1, 1, 3], [])
+    assert nv.sum() == 2 and vv.sum() == 0                         # multi-hot, duplicates collapse
+    batch = collate_samples(samples)
+    assert batch['video'].shape == (3, F, 3, R, R) and batch['text'] == caps and batch['meta']['paths'] == ['v0.mp4', 'v1.mp4', 'v2.mp4']
+
+    calls = []
+
+    class Rec(HashTokenizer):
+        def __call__(self, text, **kw):
+            calls.append((list(text), kw))
+            return super().__call__(text, **kw)
+    gm = torch.Generator().manual_seed(5)
+    data, n_emb, v_emb = assemble_train_batch(batch, Rec(), generator=gm)
+    # positives first, negatives after (trainer_egoclip.py:113-116)
+    assert calls == [(caps + negs, dict(return_tensors='pt', padding='max_length', max_length=15, truncation=True))]
+    assert torch.equal(data['video'], torch.cat([batch['video'], batch['video_neg']], 0))
+    assert torch.equal(n_emb, torch.cat([batch['noun_vec'], batch['noun_vec_neg']], 0)) and v_emb.shape == (6, 118)
+    ids, am = data['text']['input_ids'], data['text']['attention_mask']
+    assert ids.shape == (6, 15) and ids.dtype == torch.int64 and torch.equal(am, (ids != 1).long())
+    assert (ids[:, 0] == 0).all() and ids[1, -1] == 2               # truncated to 15 with </s> kept
+    assert ((ids == 2).sum(1) == 1).all()
+    ref = mlm_collate(ids, generator=torch.Generator().manual_seed(5))
+    assert torch.equal(data['text_mlm_ids'], ref['input_ids']) and torch.equal(data['text_mlm_labels'], ref['labels'])
+    # without negatives the batch passes through unchanged
+    plain = collate_samples([egoclip_sample(torch.zeros(F, 3, R, R), 'a b', [1], [1])])
+    d2, n2, _ = assemble_train_batch(plain, HashTokenizer(), mlm=False)
+    assert d2['video'].shape[0] == 1 and 'text_mlm_ids' not in d2 and n2.shape == (1, 582)
