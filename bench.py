@@ -237,8 +237,10 @@ def main():
         kinds = {0: 'gemm_kernel<bf16,NT> (generic 128x128)', 1: 'gemm_kernel<bf16,NN> (generic)', 2: 'gemm_kernel<bf16,TN> (generic)',
                  4: 'gemm_kernel<f32,NT>', 5: 'gemm_kernel<f32,NN>', 6: 'gemm_kernel<f32,TN>',
                  8: 'gemm_ring_kernel<256x128> (NT fwd+dgrad, DMA ring)', 10: 'gemm_wgrad_ring_kernel (TN wgrad, 256x128 DMA ring)',
-                 12: 'gemm_pp_kernel (NT fwd+dgrad, persistent ping-pong 256x256)', 13: 'gemm_ring_kernel<128x128> (NT, text-side grids)'}
-        pmc_names = {8: 'gemm_ring_kernel<256x128>', 10: 'gemm_wgrad_ring_kernel', 12: 'gemm_pp_kernel', 13: 'gemm_ring_kernel<128x128>'}
+                 12: 'gemm_pp_kernel (NT fwd+dgrad, persistent ping-pong 256x256)', 13: 'gemm_ring_kernel<128x128> (NT, text-side grids)',
+                 14: 'gemm_wgrad_pp_kernel (TN wgrad, ping-pong 256x256)'}
+        pmc_names = {8: 'gemm_ring_kernel<256x128>', 10: 'gemm_wgrad_ring_kernel', 12: 'gemm_pp_kernel', 13: 'gemm_ring_kernel<128x128>',
+                     14: 'gemm_wgrad_pp_kernel'}
         agg = {}
         for fl, ms, kd, by in recs:
             e = agg.setdefault(kd, [0.0, 0.0, 0, 0.0])

@@ -428,8 +428,10 @@ extern "C" int egv_gemm_wgrad(int dtype, int M, int N, int K, const void* dY, in
         // one split, no scaling: the kernel's column sums ARE the bias gradient (no reduction / copy launch)
         const bool bias_direct = dbias && nz == 1 && scale == 1.0f && gate == nullptr;
         if (dbias) g.colsum = bias_direct ? dbias : bias_part;
-        if ((pp && egv_gemm4_launch(g, nz, st)) || egv_gemm2_launch(g, 1, 1, 1, nz, st)) {
-            egv_prof_end(ph, stream, 2.0 * M * N * K, 10, 2.0 * ((double)M * N + (double)M * K) + 4.0 * N * K);
+        const bool took_pp = pp && egv_gemm4_launch(g, nz, st);
+        if (took_pp || egv_gemm2_launch(g, 1, 1, 1, nz, st)) {
+            egv_prof_end(ph, stream, 2.0 * M * N * K, took_pp ? 14 : 10,       // 14 ping-pong 256x256, 10 ring 256x128
+                         2.0 * ((double)M * N + (double)M * K) + 4.0 * N * K);
             bias_fused = dbias != nullptr;
             if (bias_direct) dbias = nullptr;          // done
         } else {
