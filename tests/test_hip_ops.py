@@ -560,3 +560,120 @@ def test_patch_tokens_from_uint8_clips(ops, dtype):
     a = ops.patch_tokens(u8.cuda(), w, b, cls, pos, tem, dtype)
     r = ops.patch_tokens(ref_in.cuda(), w, b, cls, pos, tem, dtype)
     assert _rel(a, r) < (1e-6 if dtype == torch.float32 else 4e-3)
+
+
+# ---- round 2: persistent ping-pong GEMM / block-level entry points -------------------------------------------------------------
+@pytest.mark.parametrize('N,K,kind', [(2304, 768, 'bias'), (3072, 768, 'gelu'), (768, 3072, 'res'), (768, 2304, 'plain')])
+def test_persistent_gemm_bitwise_equals_ring_gemm(ops, N, K, kind):
+    """The kernel choice depends on the grid size (persistent ping-pong kernel from 64 tiles of 256x256 up, DMA-ring kernels
+    below): both accumulate in the same K order and add the bias after the sum, so the first rows of a full-size call must be
+    bit-identical to a call on those rows alone (what keeps FrozenInTime batch-composition independent in bf16)."""
+    M, m = FULL_M, 1024
+    x = _rnd((M, K), torch.bfloat16, 1.0, 11).cuda()
+    w = _rnd((N, K), torch.float32, 0.05, 12).cuda()
+    b = _rnd((N,), torch.float32, 0.5, 13).cuda() if kind != 'plain' else None
+    res = _rnd((M, N), torch.bfloat16, 1.0, 14).cuda() if kind == 'res' else None
+    act = 'gelu' if kind == 'gelu' else 'none'
+    big = ops.linear(x, w, b, act=act, res1=res)
+    small = ops.linear(x[:m].contiguous(), w, b, act=act, res1=None if res is None else res[:m].contiguous())
+    assert torch.equal(big[:m], small)
+    # and against fp64 on sampled rows of the last (ragged, 8-row) tile
+    rows = torch.arange(M - 8, M)
+    z = x[rows.cuda()].double().cpu() @ w.to(torch.bfloat16).double().cpu().t()
+    if b is not None:
+        z = z + b.double().cpu()
+    ref = gelu64(z) if kind == 'gelu' else z
+    if res is not None:
+        ref = ref + res[rows.cuda()].double().cpu()
+    assert _rel(big[rows.cuda()], ref) < 6e-3
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('fused', [False, True])
+def test_block_entry_points_match_per_op_composition(ops, dtype, fused):
+    """egv_vblock_* / egv_tlayer_* (csrc/egv_block.cpp) against the same block composed from the per-operation entry points:
+    identical forward values (same kernels, same order), gradients equal up to the order of the skip-gradient sums."""
+    dev = 'cuda'
+    B, L, H, D, Hd, Fr, N = 2, 16, 12, 768, 3072, 4, 49
+    S = 1 + Fr * N
+    mk = lambda shape, sc=0.05, seed=0: (_rnd(shape, torch.float32, sc, seed).cuda()).requires_grad_(True)   # noqa: E731
+    seeds = iter(range(100, 400))
+    tp = []
+    for _ in range(4):
+        tp += [mk((D, D), seed=next(seeds)), mk((D,), seed=next(seeds))]
+    tp += [mk((Hd, D), seed=next(seeds)), mk((Hd,), seed=next(seeds)), mk((D, Hd), seed=next(seeds)), mk((D,), seed=next(seeds)),
+           mk((D,), 1.0, next(seeds)), mk((D,), seed=next(seeds)), mk((D,), 1.0, next(seeds)), mk((D,), seed=next(seeds))]
+    if fused:
+        for _ in range(4):
+            tp += [mk((D, D), seed=next(seeds)), mk((D,), seed=next(seeds))]
+        tp += [mk((1,), 1.0, next(seeds))]
+    vp = [mk((3 * D, D), seed=next(seeds)), mk((3 * D,), seed=next(seeds)), mk((D, D), seed=next(seeds)), mk((D,), seed=next(seeds)),
+          mk((3 * D, D), seed=next(seeds)), mk((3 * D,), seed=next(seeds)), mk((D, D), seed=next(seeds)), mk((D,), seed=next(seeds)),
+          mk((Hd, D), seed=next(seeds)), mk((Hd,), seed=next(seeds)), mk((D, Hd), seed=next(seeds)), mk((D,), seed=next(seeds))]
+    for _ in range(3):
+        vp += [mk((D,), 1.0, next(seeds)), mk((D,), seed=next(seeds))]
+    if fused:
+        vp += [mk((2 * D, D), seed=next(seeds)), mk((2 * D,), seed=next(seeds)), mk((D, D), seed=next(seeds)), mk((D,), seed=next(seeds)),
+               mk((D, D), seed=next(seeds)), mk((D,), seed=next(seeds)), mk((D,), 1.0, next(seeds)), mk((D,), seed=next(seeds)), mk((1,), 1.0, next(seeds))]
+    hid0 = _rnd((B * L, D), torch.float32, 1.0, 1).cuda()
+    x0 = _rnd((B * S, D), torch.float32, 1.0, 2).cuda()
+    m = torch.ones(B, L, device=dev)
+    m[0, -3:] = 0
+    mask = ((1 - m) * torch.finfo(torch.float32).min).contiguous()
+
+    def text_ref(hid, P, enc):
+        q, k, v = ops.linear(hid, P[0], P[1]), ops.linear(hid, P[2], P[3]), ops.linear(hid, P[4], P[5])
+        ctx = ops.plain_attention(q, k, v, B, H, L, L, 0.125, mask=mask)
+        if enc is None:
+            a = ops.linear(ctx, P[6], P[7], res1=hid)
+        else:
+            a0 = ops.linear(ctx, P[6], P[7])
+            cq, ck, cv = ops.linear(a0, P[16], P[17]), ops.linear(enc, P[18], P[19]), ops.linear(enc, P[20], P[21])
+            cctx = ops.plain_attention(cq, ck, cv, B, H, L, S, 0.125, mask=None)
+            a = ops.linear(cctx, P[22], P[23], gate=P[24], res1=a0, res2=hid)
+        a = ops.layernorm(a, P[12], P[13], 1e-5)
+        return ops.layernorm(ops.mlp(a, P[8], P[9], P[10], P[11], res=a), P[14], P[15], 1e-5)
+
+    def video_ref(x, P, y):
+        h, xs = ops.layernorm_skip(x, P[12], P[13], 1e-5)
+        tr = ops.linear(ops.divided_attention(ops.linear(h, P[0], P[1]), B, Fr, N, H, 'time'), P[2], P[3], res1=xs)
+        s_ctx = ops.divided_attention(ops.linear(ops.layernorm(tr, P[14], P[15], 1e-5), P[4], P[5]), B, Fr, N, H, 'space')
+        if y is None:
+            sr = ops.linear(s_ctx, P[6], P[7], res1=xs)
+        else:
+            s = ops.linear(s_ctx, P[6], P[7])
+            kv = ops.linear(y, P[18], P[19])
+            hs, ss = ops.layernorm_skip(s, P[24], P[25], 1e-5)
+            o = ops.plain_attention(ops.linear(hs, P[20], P[21]), kv[:, :D], kv[:, D:], B, H, S, L, 0.125, mask=mask)
+            sr = ops.linear(o, P[22], P[23], gate=P[26], res1=ss, res2=xs)
+        h2, srs = ops.layernorm_skip(sr, P[16], P[17], 1e-5)
+        return ops.mlp(h2, P[8], P[9], P[10], P[11], res=srs)
+
+    for name in ('text', 'video'):
+        P = tp if name == 'text' else vp
+        outs = []
+        for which in ('ref', 'blk'):
+            for p in P:
+                p.grad = None
+            hid = hid0.to(dtype).detach().requires_grad_(True)
+            x = x0.to(dtype).detach().requires_grad_(True)
+            if name == 'text':
+                enc = x if fused else None
+                out = text_ref(hid, P, enc) if which == 'ref' else ops.text_layer(hid, mask, P, B, L, H, Hd, 1e-5, enc=enc, S=S)
+            else:
+                y = hid if fused else None
+                out = video_ref(x, P, y) if which == 'ref' else ops.video_block(x, P, B, Fr, N, H, Hd, 1e-5, y=y, y_mask=mask if fused else None, L=L)
+            out.backward(_rnd(tuple(out.shape), torch.float32, 1.0, 9).cuda().to(dtype))
+            torch.cuda.synchronize()
+            outs.append((out.detach().clone(), None if hid.grad is None else hid.grad.clone(), None if x.grad is None else x.grad.clone(),
+                         [p.grad.clone() for p in P]))
+        (o0, h0, xg0, g0), (o1, h1, xg1, g1) = outs
+        assert torch.equal(o0, o1), name
+        tol = 1e-5 if dtype == torch.float32 else 1e-2
+        for a, bb in ((h0, h1), (xg0, xg1)):
+            if a is not None:
+                assert _rel(bb, a.double().cpu()) < tol, name
+        for i, (a, bb) in enumerate(zip(g0, g1)):
+            if not (name == 'text' and i in (3, 19)):     # key biases have an exactly-zero true gradient: noise / noise
+                # (the gate gradients are dot products of two noisy bf16 vectors: a looser bound)
+                assert _rel(bb, a.double().cpu()) < (1e-5 if dtype == torch.float32 else (1e-1 if a.numel() == 1 else 2e-2)), (name, i)
