@@ -288,6 +288,7 @@ class FrozenInTime(nn.Module):
         return x.reshape(B, rows_per_sample, -1)[:, 0].contiguous()
 
     def _proj_mlp(self, x, prefix):
+        """txt_proj / vid_proj (model.py:105-115)"""
         x = ops.linear(x, self.p(prefix + '.0.weight'), None, act='relu')
         x = self._lin(x, prefix + '.2', act='relu')
         return self._lin(x, prefix + '.4')

@@ -124,9 +124,10 @@ def test_tiny_egonce_only_step_fp32():
             assert pd[k].grad is None, k
 
 
-@pytest.mark.parametrize('dtype,tol_e,tol_l', [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 4e-2, 2e-2)])
+@pytest.mark.parametrize('dtype,tol_e,tol_l', [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 2e-2, 5e-3)])
 def test_base_f4_vs_golden(dtype, tol_e, tol_l):
-    """full-depth ViT-B/16 + RoBERTa-base at 4 x 224^2 frames against the reference's own outputs."""
+    """full-depth ViT-B/16 + RoBERTa-base at 4 x 224^2 frames against the reference's own outputs.  (bf16 storage: measured
+    1.3e-2 on the pooled embeddings, <= 1.2e-3 on the losses -- tools/bf16_error.py; the bounds keep a margin.)"""
     from egovlpv2_amd.synthetic import make_state_dict, make_batch
     g, cfg, B, L, wseed, bseed = load_golden('base_f4')
     sd = make_state_dict(cfg, wseed)
@@ -155,7 +156,7 @@ def test_base_f4_vs_golden(dtype, tol_e, tol_l):
     assert (rel < gtol).all(), [(kn[i], float(rel[i])) for i in np.argsort(-rel)[:8]]
 
 
-@pytest.mark.parametrize('dtype,tol_e,tol_l', [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 4e-2, 2e-2)])
+@pytest.mark.parametrize('dtype,tol_e,tol_l', [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 2e-2, 5e-3)])
 def test_base_f16_vs_golden(dtype, tol_e, tol_l):
     """BASELINE.json configs[2] geometry AND depth (12 + 12 layers, 6 fused, 16 x 224^2 frames, 32 tokens) at B = 2 against the
     reference's own outputs (tests/golden/base_f16.npz, written by oracle/gen_golden.py importing the reference): pooled
