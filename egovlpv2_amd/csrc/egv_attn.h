@@ -86,3 +86,4 @@ static inline egv::AttnArgs to_args(const egv_attn_desc* d) {
 int egv_attn_fwd_mfma(const egv::AttnArgs& a, int B, hipStream_t st);
 int egv_attn_dq_mfma(const egv::AttnArgs& a, int B, hipStream_t st);
 int egv_attn_dkv_mfma(const egv::AttnArgs& a, int B, hipStream_t st);
+int egv_attn_bwd_fused_mfma(const egv::AttnArgs& a, int B, hipStream_t st);

@@ -778,3 +778,17 @@ extern "C" int egv_attn_bwd_dkv(int dtype, const egv_attn_desc* d, void* stream)
     }
     return 0;
 }
+
+// dQ, dK, dV and delta of one grouped launch in a single kernel (bf16, other side <= 224 rows, no mask / dropout / split).
+// Returns 0 if enqueued, 1 if the shape is not covered (nothing enqueued: use egv_attn_bwd_dq + egv_attn_bwd_dkv), -1 on error.
+// The extra CLS query's delta must already be in d->delta (one-query egv_attn_bwd_dq first).
+extern "C" int egv_attn_bwd_fused(int dtype, const egv_attn_desc* d, void* stream) {
+    if (check_desc(d, "egv_attn_bwd_fused")) return -1;
+    EGV_CHECK(d->lse && d->delta && d->dO && d->dQ && d->dK && d->dV, "egv_attn_bwd_fused: missing lse/delta/dO/dQ/dK/dV");
+    if (dtype != EGV_BF16) return 1;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    AttnArgs a = to_args(d);
+    if (!egv_attn_bwd_fused_mfma(a, d->B, st)) return 1;
+    EGV_LAUNCH_CHECK();
+    return 0;
+}

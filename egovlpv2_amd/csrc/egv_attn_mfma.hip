@@ -15,6 +15,7 @@
 //
 // Every output row is written exactly once as 8-byte packed bf16 (4 consecutive head columns per lane).
 #include "egv_attn.h"
+#include <cstdlib>
 
 #ifndef EGV_KK_BARRIER
 #define EGV_KK_BARRIER
@@ -538,6 +539,240 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_mfma_kernel(const AttnArgs a
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward, fused: dQ, dK, dV (and delta) of the divided space attention in ONE pass over the score tiles.
+//
+// Key-owned like attn_dkv_mfma_kernel: the queries [extra CLS query ; row set] sit transposed in LDS (Q^T, dO^T), every one of
+// the 8 waves owns up to two 16-key tiles (K / V fragments from global, kept in registers) -- the row set's key tiles
+// round-robin over the waves, plus one more tile that holds only the extra CLS KEY (its dK / dV belong to the one-key launch;
+// its column is needed for dQ).  Per pair of query tiles a wave computes S = Q K^T and dP = dO V^T once, P and dS once, and uses
+// them three times:
+//   dV^T += dO^T P, dK^T += Q^T dS      (reduction over the queries = the C rows: the C layout IS the B operand, as above)
+//   dQ^T += K^T dS^T                     (reduction over the wave's 32 keys = the C columns: the dS tile goes through a
+//                                         per-wave LDS scratch [key][query] and comes back with the transposing read)
+// dQ is summed over the waves in an fp32 LDS accumulator [query pair][32][64] WITHOUT atomics: in step s wave w works on query
+// pair (s + w) mod 8, so no two waves touch the same pair in a step, a barrier separates the steps, and the order in which the
+// waves add into a pair is fixed -- the result does not depend on scheduling.  One bf16 store pass at the end.
+// delta = rowsum(dO o O) of the row-set queries is computed while staging (and stored for the CLS-key launch that follows);
+// the CLS query's delta comes from the one-query launch before.
+// Against the dQ + dK/dV kernel pair: one staging of Q / dO instead of two stagings of two operands each, 10 instead of 14
+// MFMAs and one exp instead of two per 16 x 16 score tile.
+// ------------------------------------------------------------------------------------------------
+constexpr int DSP = 48;                          // pitch (bytes) of a dS^T scratch row: 16 queries (bf16) + 16 B pad
+constexpr int XP = 68;                           // float pitch of a dQ accumulator row (64 head dims + pad)
+constexpr int XPAIR = 32 * XP * 4;               // accumulator bytes of one query pair
+constexpr int FNW = 8;                           // waves of the fused kernel
+
+// transposing fragment read from a tile T[a][b] (b contiguous, `pitch` bytes per a): lane (fr, fg) receives
+// T[a0 + fg*8 .. +7][b0 + fr]
+__device__ __forceinline__ bf16x8_t ld_tr_ab(const unsigned char* s, int pitch, int a0, int b0, int fr, int fg) {
+    const unsigned char* p = s + (a0 + fg * 8 + (fr >> 2)) * pitch + (b0 + (fr & 3) * 4) * 2;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + 4 * pitch));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// workgroup barrier that orders LDS traffic only (global stores stay in flight, unlike __syncthreads)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NT>
+__global__ __launch_bounds__(64 * FNW) void attn_bwd_fused_kernel(const AttnArgs a) {
+    constexpr int VP = vt_pitch(NT);
+    constexpr int NW = FNW, NTHR = 64 * NW, NP = NT / 2;
+    static_assert(NP <= NW, "one query pair per wave and step");
+    const float sc2 = a.scale * LOG2E;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sQt = smem;                       // [64][VP]  Q transposed
+    unsigned char* sGt = sQt + 64 * VP;              // [64][VP]  dO transposed
+    float* sL = reinterpret_cast<float*>(sGt + 64 * VP);   // [NT*16] lse (log2 domain)
+    float* sD = sL + NT * 16;                        // [NT*16] delta
+    unsigned char* sDS = reinterpret_cast<unsigned char*>(sD + NT * 16);      // [NW][2 query tiles][32 keys][DSP]
+    unsigned char* sAcc = sDS + NW * 2 * 32 * DSP;   // [NP][32][XP] fp32 dQ accumulators; first the K rows of the own tiles ([NW][32][RP])
+    static_assert(NW * 32 * RP <= NP * XPAIR, "K scratch fits the accumulator");
+
+    const int tid = threadIdx.x, lane = tid & 63, w = wave_id();
+    const int fr = lane & 15, fg = lane >> 4;
+    const int p = blockIdx.y, b = p / a.G, g = p % a.G, h = blockIdx.z;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.Q);
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.K);
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.V);
+    const bf16_t* O = reinterpret_cast<const bf16_t*>(a.O);
+    const bf16_t* dO = reinterpret_cast<const bf16_t*>(a.dO);
+    bf16_t* dQ = reinterpret_cast<bf16_t*>(a.dQ);
+    bf16_t* dK = reinterpret_cast<bf16_t*>(a.dK);
+    bf16_t* dV = reinterpret_cast<bf16_t*>(a.dV);
+    const int hq = a.qoff + h * HD, hk = a.koff + h * HD, hv = a.voff + h * HD, ho = a.ooff + h * HD;
+    const int hdq = a.dqoff + h * HD, hdk = a.dkoff + h * HD, hdv = a.dvoff + h * HD;
+    const int ntot = a.q.n + a.extra;               // queries incl. the extra CLS query (row 0)
+
+    stage_rows_t<NT, NTHR>(sQt, Q, a.ldq, hq, a, a.q, b, g, ntot, tid);
+    stage_rows_t<NT, NTHR>(sGt, dO, a.ldo, ho, a, a.q, b, g, ntot, tid);
+    for (int i = tid; i < NT * 16; i += NTHR) {
+        float l = INFINITY, d = 0.f;                 // padded query rows: exp(s - inf) = 0
+        if (i < ntot) {
+            const long long row = other_row(a, a.q, b, g, i);
+            l = a.lse[row * a.H + h] * LOG2E;
+            if (a.extra && i == 0) {
+                d = a.delta[row * a.H + h];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const bf16x8_t x = *reinterpret_cast<const bf16x8_t*>(dO + row * a.ldo + ho + c * 8);
+                    const bf16x8_t y = *reinterpret_cast<const bf16x8_t*>(O + row * a.ldo + ho + c * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) d += (float)x[e] * (float)y[e];
+                }
+                a.delta[row * a.H + h] = d;
+            }
+        }
+        sL[i] = l;
+        sD[i] = d;
+    }
+
+    // own key tiles: j = w, w + NW; j < nkt: row-set keys, j == nkt (with extra): the CLS key alone
+    const int nkt = (a.k.n + 15) >> 4;
+    bf16x8_t kf[2][2], vf[2][2];
+    bool live[2], kval[2], part[2];
+    long long krow[2];
+    unsigned char* ksc = sAcc + w * 32 * RP;
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const int j = w + o * NW;
+        const bool patch = j < nkt;
+        live[o] = j < nkt + a.extra;
+        const int key = j * 16 + fr;
+        kval[o] = patch ? key < a.k.n : (live[o] && fr == 0);
+        part[o] = !patch || (j * 16 + 16 > a.k.n);
+        krow[o] = patch ? rs_row(a.k, b, g, kval[o] ? key : 0) : ((long long)b * a.extra_bs + a.extra_row);
+        kf[o][0] = ld_frag_global(K + krow[o] * a.ldk + hk + fg * 8, kval[o]);
+        kf[o][1] = ld_frag_global(K + krow[o] * a.ldk + hk + 32 + fg * 8, kval[o]);
+        vf[o][0] = ld_frag_global(V + krow[o] * a.ldv + hv + fg * 8, kval[o]);
+        vf[o][1] = ld_frag_global(V + krow[o] * a.ldv + hv + 32 + fg * 8, kval[o]);
+        *reinterpret_cast<bf16x8_t*>(ksc + (o * 16 + fr) * RP + fg * 16) = kf[o][0];
+        *reinterpret_cast<bf16x8_t*>(ksc + (o * 16 + fr) * RP + 64 + fg * 16) = kf[o][1];
+    }
+    __syncthreads();
+    bf16x8_t kT[4];                                  // K^T fragments of the wave's 32 keys: A operand of dQ^T
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) kT[dt] = ld_tr_ab(ksc, RP, 0, dt * 16, fr, fg);
+    lds_barrier();                                   // the scratch becomes the dQ accumulator
+
+    f32x4_t ov[2][4], ok[2][4];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) ov[o][dt] = ok[o][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    unsigned char* dsc = sDS + w * 2 * 32 * DSP;
+    const int npair = (ntot + 31) >> 5;              // live query pairs
+
+#pragma unroll 1
+    for (int step = 0; step < NW; ++step) {
+        const int kk = (step + w) & (NW - 1);
+        if (kk < npair) {                            // uniform per wave
+            f32x4_t pr[2][2], dr[2][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int t = 2 * kk + u;
+                const bool tl = t * 16 < ntot;
+                bf16x8_t qa0, qa1, ga0, ga1;
+                f32x4_t lse, dl;
+                if (tl) {
+                    qa0 = ld_frag_tr<NT>(sQt, t * 16, 0, fr, fg);
+                    qa1 = ld_frag_tr<NT>(sQt, t * 16, 1, fr, fg);
+                    ga0 = ld_frag_tr<NT>(sGt, t * 16, 0, fr, fg);
+                    ga1 = ld_frag_tr<NT>(sGt, t * 16, 1, fr, fg);
+                    lse = *reinterpret_cast<const f32x4_t*>(sL + t * 16 + fg * 4);
+                    dl = *reinterpret_cast<const f32x4_t*>(sD + t * 16 + fg * 4);
+                }
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    f32x4_t acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                    if (tl && live[o]) {                                               // uniform per wave
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, kf[o][0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, kf[o][1], acc, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga0, vf[o][0], dp, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga1, vf[o][1], dp, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float pj = exp2_fast(acc[r] * sc2 - lse[r]);       // padding query rows: lse = +inf -> 0
+                            acc[r] = pj;
+                            dp[r] = pj * (dp[r] - dl[r]);
+                        }
+                        if (part[o]) {                                                 // padding key columns must not reach dQ
+                            asm volatile("" ::: "memory");
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { acc[r] = kval[o] ? acc[r] : 0.f; dp[r] = kval[o] ? dp[r] : 0.f; }
+                        }
+                    }
+                    pr[u][o] = acc;
+                    dr[u][o] = dp;
+                    // dS^T scratch: [key o*16 + fr][queries fg*4 .. +3]
+                    u32x2_t pk = {pack2(dp[0], dp[1]), pack2(dp[2], dp[3])};
+                    *reinterpret_cast<u32x2_t*>(dsc + u * 32 * DSP + (o * 16 + fr) * DSP + fg * 8) = pk;
+                }
+            }
+            // dV^T += dO^T P, dK^T += Q^T dS over this pair of query tiles
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8_t gt = ld_frag_t<NT>(sGt, dt * 16 + fr, kk, fg);
+                const bf16x8_t qt = ld_frag_t<NT>(sQt, dt * 16 + fr, kk, fg);
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    if (live[o]) {
+                        ov[o][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt, pack8(pr[0][o], pr[1][o]), ov[o][dt], 0, 0, 0);
+                        ok[o][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, pack8(dr[0][o], dr[1][o]), ok[o][dt], 0, 0, 0);
+                    }
+                }
+            }
+            // dQ^T of this query pair += K^T dS^T over this wave's 32 keys (step 0: the wave is the pair's first writer)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float* accp = reinterpret_cast<float*>(sAcc + kk * XPAIR);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bf16x8_t dst = ld_tr_ab(dsc + u * 32 * DSP, DSP, 0, 0, fr, fg);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    float* ap = accp + (u * 16 + fr) * XP + dt * 16 + fg * 4;
+                    f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+                    if (step != 0) c = *reinterpret_cast<const f32x4_t*>(ap);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[dt], dst, c, 0, 0, 0);
+                    *reinterpret_cast<f32x4_t*>(ap) = c;
+                }
+            }
+        }
+        lds_barrier();
+    }
+
+    // dQ: accumulators -> bf16 rows (16 threads per query, 4 head dims each)
+    for (int e = tid; e < npair * 32 * 16; e += NTHR) {
+        const int i = e >> 4, d4 = (e & 15) * 4;
+        if (i < ntot && !(a.extra && i == 0)) {
+            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(sAcc + (i >> 5) * XPAIR + ((i & 31) * XP + d4) * 4);
+            const long long row = rs_row(a.q, b, g, i - a.extra);
+            st_bf16x4(dQ + row * a.lddq + hdq + d4, v[0] * a.scale, v[1] * a.scale, v[2] * a.scale, v[3] * a.scale);
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const int j = w + o * NW;
+        if (j < nkt && kval[o]) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                st_bf16x4(dV + krow[o] * a.lddv + hdv + dt * 16 + fg * 4, ov[o][dt][0], ov[o][dt][1], ov[o][dt][2], ov[o][dt][3]);
+                st_bf16x4(dK + krow[o] * a.lddk + hdk + dt * 16 + fg * 4, ok[o][dt][0] * a.scale, ok[o][dt][1] * a.scale,
+                          ok[o][dt][2] * a.scale, ok[o][dt][3] * a.scale);
+            }
+        }
+    }
+}
+
+template <int NT> constexpr size_t fused_lds() {
+    return (size_t)2 * 64 * vt_pitch(NT) + 2 * NT * 16 * 4 + (size_t)FNW * 2 * 32 * DSP + (size_t)(NT / 2) * XPAIR;
+}
+
 template <int NT> constexpr size_t fwd_lds() { return (size_t)NT * 16 * RP + 64 * vt_pitch(NT); }
 template <int NT> constexpr size_t dq_lds() { return (size_t)2 * 64 * vt_pitch(NT); }
 template <int NT> constexpr size_t dkv_lds() { return (size_t)2 * 64 * vt_pitch(NT) + 2 * NT * 16 * 4; }
@@ -618,5 +853,19 @@ int egv_attn_dkv_mfma(const AttnArgs& a, int B, hipStream_t st) {
     if (ntot <= 32) EGV_MFMA_LAUNCH(attn_dkv_mfma_kernel, dkv_lds, 2, 0);
     else if (ntot <= 64) EGV_MFMA_LAUNCH(attn_dkv_mfma_kernel, dkv_lds, 4, 0);
     else EGV_MFMA_LAUNCH(attn_dkv_mfma_kernel, dkv_lds, 14, 0);
+    return 1;
+}
+
+// dQ + dK/dV of a divided-attention launch in one kernel (no mask, no dropout, no split); 1 if enqueued.  Only the long
+// other side (space attention: 196 patches + CLS) -- for the 17-row time attention a one-wave fused kernel measured no faster
+// than the pair (both are bound by the global round trips of one wave, and the pair runs at twice the occupancy).
+int egv_attn_bwd_fused_mfma(const AttnArgs& a, int B, hipStream_t st) {
+    const int ntot = a.q.n + a.extra;
+    const int own = (a.k.n + 15) / 16 + a.extra;
+    if (!aligned_ok(a) || (a.lddq % 4) || (a.dqoff % 4) || (a.lddk % 4) || (a.lddv % 4) || (a.dkoff % 4) || (a.dvoff % 4)) return 0;
+    if (a.mask || a.drop_p > 0.f || a.nsplit > 1 || ntot > 224 || ntot <= 64 || own > 2 * FNW || !a.delta || !a.lse) return 0;
+    constexpr size_t lds = fused_lds<14>();
+    set_lds(attn_bwd_fused_kernel<14>, lds);
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<14>), dim3(1, B * a.G, a.H), dim3(64 * FNW), lds, st, a);
     return 1;
 }

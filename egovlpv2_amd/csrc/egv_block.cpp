@@ -11,6 +11,7 @@
 // library-owned pool (created once, never destroyed); no other state is kept.
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "../../include/egovlp_hip.h"
@@ -160,17 +161,21 @@ struct Divided {
             d.delta = delta;
         };
         egv_attn_desc d;
-        fill(d, qkv, const_cast<void*>(O), lse); grads(d); groups(d);
-        BCHK(egv_attn_bwd_dq(dt, &d, st));
         const int ns = nsplit_for(S);
-        fill(d, qkv, const_cast<void*>(O), lse); grads(d);
+        fill(d, qkv, const_cast<void*>(O), lse); grads(d);  // CLS query over all S keys (also its delta, which the group launch reads)
         d.G = 1;
         rowset(d.q_bs, d.q_base, d.q_gs, d.q_is, d.q_n, S, 0, 0, 1, 1);
         rowset(d.k_bs, d.k_base, d.k_gs, d.k_is, d.k_n, S, 0, 0, 1, S);
         d.nsplit = ns; d.ws = (float*)ws; d.ws_bytes = wsb;
         BCHK(egv_attn_bwd_dq(dt, &d, st));
         fill(d, qkv, const_cast<void*>(O), lse); grads(d); groups(d);
-        BCHK(egv_attn_bwd_dkv(dt, &d, st));
+        static const bool fused = !getenv("EGV_ATTN_FUSED_BWD") || atoi(getenv("EGV_ATTN_FUSED_BWD")) != 0;
+        const int fr = fused ? egv_attn_bwd_fused(dt, &d, st) : 1;
+        if (fr < 0) return fr;
+        if (fr == 1) {
+            BCHK(egv_attn_bwd_dq(dt, &d, st));
+            BCHK(egv_attn_bwd_dkv(dt, &d, st));
+        }
         fill(d, qkv, const_cast<void*>(O), lse); grads(d);  // CLS key <- all S queries
         d.G = 1;
         rowset(d.q_bs, d.q_base, d.q_gs, d.q_is, d.q_n, S, 0, 0, 1, S);

@@ -563,6 +563,9 @@ def _nsplit_for(n_other):
     return 1 if n_other <= 224 else max(2, min(32, n_other // 384))     # 8 splits at S = 3137: the combine pass stays short
 
 
+FUSED_ATTN_BWD = os.environ.get('EGV_ATTN_FUSED_BWD', '1') != '0'
+
+
 class DividedAttnFn(Function):
     """Divided space / time attention core of VarAttention (video_transformer.py:121-150) on the fused qkv buffer
     [B*S, 3*D]: CLS query over all S keys, patch queries over [CLS ; own frame | own patch column]."""
@@ -614,15 +617,20 @@ class DividedAttnFn(Function):
         cls1, allS = _rowset(S, 0, 0, 1, 1), _rowset(S, 0, 0, 1, S)
         dt = _dt(qkv)
         kw = dict(dO=dO, dQ=dQ, dK=dK, dV=dV, delta=delta)
-        d1 = _mk_desc(Q, K, V, O, lse, B, G, H, gset, gset, (S, 0), scale, **kw)
-        check(lib.egv_attn_bwd_dq(dt, C.byref(d1), _st()), 'egv_attn_bwd_dq(groups)')
         ns = _nsplit_for(S)
         ws, nb = _split_ws(1, B, 1, H, 1, ns, qkv.device)
         d2 = _mk_desc(Q, K, V, O, lse, B, 1, H, cls1, allS, None, scale, nsplit=ns, ws=ws, ws_bytes=nb, **kw)
         check(lib.egv_attn_bwd_dq(dt, C.byref(d2), _st()), 'egv_attn_bwd_dq(cls)')
-        # key-owned: group keys <- [CLS query ; group queries];  CLS key <- all S queries (split + reduce)
-        d3 = _mk_desc(Q, K, V, O, lse, B, G, H, gset, gset, (S, 0), scale, **kw)
-        check(lib.egv_attn_bwd_dkv(dt, C.byref(d3), _st()), 'egv_attn_bwd_dkv(groups)')
+        # groups: dQ, dK, dV (and delta) in one kernel where the shape allows it (bf16; the CLS query's delta is in place);
+        # otherwise query-owned dQ, then key-owned group keys <- [CLS query ; group queries]
+        d1 = _mk_desc(Q, K, V, O, lse, B, G, H, gset, gset, (S, 0), scale, **kw)
+        rc = lib.egv_attn_bwd_fused(dt, C.byref(d1), _st()) if FUSED_ATTN_BWD else 1
+        if rc == 1:
+            check(lib.egv_attn_bwd_dq(dt, C.byref(d1), _st()), 'egv_attn_bwd_dq(groups)')
+            check(lib.egv_attn_bwd_dkv(dt, C.byref(d1), _st()), 'egv_attn_bwd_dkv(groups)')
+        else:
+            check(rc, 'egv_attn_bwd_fused(groups)')
+        # CLS key <- all S queries (split + reduce)
         nsplit = _nsplit_for(S)
         ws, nb = _dkv_ws(B, 1, H, 1, nsplit, qkv.device)
         d4 = _mk_desc(Q, K, V, O, lse, B, 1, H, allS, cls1, None, scale, nsplit=nsplit, ws=ws, ws_bytes=nb, **kw)

@@ -520,6 +520,27 @@ def test_full_size_divided_attention_sampled_problems_bf16(ops):
     assert _rel(o2[:, 0], o1[:, 0]) < 6e-3                     # CLS row: same value, different summation order
 
 
+def test_fused_attention_backward_matches_kernel_pair(ops):
+    """dQ / dK / dV of the space attention from the one-pass kernel (attn_bwd_fused_kernel) against the dQ + dK/dV kernel pair on
+    the same bf16 inputs (same bf16 roundings of P and dS, different summation order), and run-to-run bitwise reproducibility
+    (the cross-wave dQ sum has a fixed order, no atomics)."""
+    for (B, Fr, N, H) in [(2, 3, 70, 3), (1, 2, 196, 2), (2, 2, 223, 1), (1, 1, 65, 1)]:
+        S = 1 + Fr * N
+        qkv = _rnd((B * S, 3 * H * 64), torch.bfloat16, 1.0, 11).cuda().requires_grad_(True)
+        do = _rnd((B * S, H * 64), torch.bfloat16, 1.0, 12).cuda()
+        grads = {}
+        try:
+            for fused in (False, True, True):
+                ops.FUSED_ATTN_BWD = fused
+                o = ops.divided_attention(qkv, B, Fr, N, H, 'space')
+                g, = torch.autograd.grad(o, qkv, do)
+                grads.setdefault(fused, []).append(g)
+        finally:
+            ops.FUSED_ATTN_BWD = True
+        assert torch.equal(grads[True][0], grads[True][1]), (B, Fr, N, H)
+        assert _rel(grads[True][0], grads[False][0].double().cpu()) < 4e-3, (B, Fr, N, H)
+
+
 def test_prepare_weights_matches_per_tensor_casts(ops):
     """egv_cast_weights (one launch for all Linear weights of a step) must produce exactly the copies the lazy per-tensor
     path makes, and seed both caches; non-qualifying tensors are left alone."""
