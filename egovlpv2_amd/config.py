@@ -24,6 +24,8 @@ class PathConfig:
     vocab: int = 50265
     max_pos: int = 514
     proj_dim: int = 4096
+    proj_style: str = 'mlp'    # 'mlp': Linear-ReLU-Linear-ReLU-Linear heads of the pre-training model (model.py:105-115);
+                               # 'linear': txt ReLU-Linear / vid Linear of the fine-tune variant (model_epic_charades.py:116-119)
     pad_id: int = 1
     eps_video: float = 1e-5    # nn.LayerNorm default wins over the eps=1e-6 partial (video_transformer.py:250,279)
     eps_text: float = 1e-5     # roberta-base layer_norm_eps

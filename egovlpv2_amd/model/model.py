@@ -288,7 +288,10 @@ class FrozenInTime(nn.Module):
         return x.reshape(B, rows_per_sample, -1)[:, 0].contiguous()
 
     def _proj_mlp(self, x, prefix):
-        """txt_proj / vid_proj (model.py:105-115)"""
+        """txt_proj / vid_proj (model.py:105-115); cfg.proj_style 'linear': the fine-tune variant's txt ReLU-Linear / vid Linear
+        (model_epic_charades.py:116-119)"""
+        if self.cfg.proj_style == 'linear':
+            return self._lin(torch.relu(x), 'txt_proj.1') if prefix == 'txt_proj' else self._lin(x, 'vid_proj.0')
         x = ops.linear(x, self.p(prefix + '.0.weight'), None, act='relu')
         x = self._lin(x, prefix + '.2', act='relu')
         return self._lin(x, prefix + '.4')
@@ -430,7 +433,7 @@ class FrozenInTime(nn.Module):
         if task_names is not None:
             self.task_names = task_names
         c = self.cfg
-        if 'EgoNCE' in self.task_names:
+        if 'EgoNCE' in self.task_names or 'Dual' in self.task_names:                                # 'Dual': model_epic_charades.py:196-203
             text_embeddings, join = self._fork_text(lambda: self.compute_text(text_data),
                                                     uses=(text_data['input_ids'], text_data['attention_mask']))
             video_embeddings = self.compute_video(video_data)

@@ -83,12 +83,18 @@ def param_shapes(cfg: PathConfig, tasks: str = 'EgoNCE_MLM_ITM') -> "OrderedDict
         s[p + 'mlp.fc2.bias'] = (D,)
     s[v + 'norm.weight'] = (D,)
     s[v + 'norm.bias'] = (D,)
-    for nm in ('txt_proj', 'vid_proj'):
-        s[nm + '.0.weight'] = (P, D)
-        s[nm + '.2.weight'] = (P, P)
-        s[nm + '.2.bias'] = (P,)
-        s[nm + '.4.weight'] = (P, P)
-        s[nm + '.4.bias'] = (P,)
+    if getattr(cfg, 'proj_style', 'mlp') == 'linear':         # model_epic_charades.py:116-119
+        s['txt_proj.1.weight'] = (P, D)
+        s['txt_proj.1.bias'] = (P,)
+        s['vid_proj.0.weight'] = (P, D)
+        s['vid_proj.0.bias'] = (P,)
+    else:
+        for nm in ('txt_proj', 'vid_proj'):
+            s[nm + '.0.weight'] = (P, D)
+            s[nm + '.2.weight'] = (P, P)
+            s[nm + '.2.bias'] = (P,)
+            s[nm + '.4.weight'] = (P, P)
+            s[nm + '.4.bias'] = (P,)
     if fused:
         for nm in ('cross_modal_text_transform', 'cross_modal_video_transform',
                    'cross_modal_video_pooler.dense', 'cross_modal_text_pooler.dense'):
@@ -185,3 +191,9 @@ def make_batch(cfg: PathConfig, batch: int, text_len: int, seed: int = 1234, mlm
     noun[:, 11] = 1.0 - noun[:, 7]
     verb[:, 5] = 1.0 - verb[:, 3]
     return data, noun, verb
+
+
+def make_relation(B: int, seed: int) -> torch.Tensor:
+    """per-pair caption relevancy in (0.1, 1] (the `relation` field of an EPIC-Kitchens MIR sample,
+    EpicKitchens_MIR_dataset.py:110,176): weights of AdaptiveMaxMarginRankingLoss in the fine-tune variant"""
+    return 0.1 + 0.9 * torch.rand(B, generator=_gen('relation', seed), dtype=torch.float32)

@@ -1,6 +1,6 @@
 """Generate golden vectors by IMPORTING THE REFERENCE (build container only).
 
-Run:  python oracle/gen_golden.py [tiny|base_f4|base_f16|all]
+Run:  python oracle/gen_golden.py [tiny|base_f4|base_f16|dual_tiny|dual_base_f4|all]
 
 This is the only file in the repo that touches /root/reference at run time.  It applies the import
 shims of SURVEY.md §8(c) (missing third-party packages, transformers 5.x API drift, hard-coded
@@ -25,7 +25,7 @@ REF = '/root/reference/EgoVLPv2'
 sys.path.insert(0, REPO)
 
 from egovlpv2_amd.config import PathConfig, tiny_config        # noqa: E402
-from egovlpv2_amd.synthetic import make_state_dict, make_batch  # noqa: E402
+from egovlpv2_amd.synthetic import make_state_dict, make_batch, make_relation  # noqa: E402
 
 
 def import_reference():
@@ -64,6 +64,7 @@ def import_reference():
     import model.model as mm
     from model import roberta as rb, video_transformer as vt
     import model.loss as ml
+    import model.model_epic_charades as mec
     from trainer.trainer_egoclip import AllGather_multi
     rb.RobertaModel.init_weights = lambda self: self.apply(self._init_weights)
     rb.RobertaModel.get_extended_attention_mask = lambda self, m, shape, device=None, dtype=None: \
@@ -71,10 +72,13 @@ def import_reference():
     rb.RobertaModel.get_head_mask = lambda self, hm, n, *a, **k: [None] * n
     vt.config_yaml['use_checkpoint'] = False          # re-entrant recompute only; numerics unchanged
     rb.config_yaml['use_checkpoint'] = False
-    return types.SimpleNamespace(mm=mm, rb=rb, vt=vt, ml=ml, AllGather_multi=AllGather_multi)
+    mec.config['use_checkpoint'] = False
+    return types.SimpleNamespace(mm=mm, mec=mec, rb=rb, vt=vt, ml=ml, AllGather_multi=AllGather_multi)
 
 
-def build_reference(R, cfg: PathConfig):
+def build_reference(R, cfg: PathConfig, dual=False):
+    """dual=False: model/model.py FrozenInTime; dual=True: the fine-tune variant model/model_epic_charades.py (task 'Dual')"""
+    M = R.mec if dual else R.mm
     from transformers import RobertaConfig
     depth, n_fuse = cfg.depth, cfg.n_fuse
 
@@ -96,12 +100,14 @@ def build_reference(R, cfg: PathConfig):
                                                 time_init=kw.get('time_init', 'zeros'),
                                                 dim_text=cfg.dim if i >= depth - n_fuse else None)
         return net
-    R.mm.SpaceTimeTransformer = stt
-    ycfg = dict(R.mm.config, use_checkpoint=False, num_layers=depth, num_fuse_block=n_fuse, drop_rate=0.0)
+    M.SpaceTimeTransformer = stt
+    ycfg = dict(M.config, use_checkpoint=False, num_layers=depth, num_fuse_block=n_fuse, drop_rate=0.0)
     try:
-        m = R.mm.FrozenInTime(video_params={'model': 'SpaceTimeTransformer', 'num_frames': cfg.frames, 'pretrained': True},
-                              text_params={'model': 'roberta-base', 'pretrained': True, 'input': 'text'},
-                              projection='minimal', projection_dim=cfg.proj_dim, load_checkpoint="", config=ycfg)
+        kw = dict(task_names='Dual') if dual else {}
+        m = M.FrozenInTime(video_params={'model': 'SpaceTimeTransformer', 'num_frames': cfg.frames, 'pretrained': True,
+                                         'drop_path_rate': 0.0},
+                           text_params={'model': 'roberta-base', 'pretrained': True, 'input': 'text'},
+                           projection='minimal', projection_dim=cfg.proj_dim, load_checkpoint="", config=ycfg, **kw)
     finally:
         torch.load = orig_load
     return m
@@ -234,6 +240,43 @@ def run_case(R, name, cfg, B, L, wseed, bseed, out_dir):
     print(name, full_ld, 'egonce_only', float(loss.detach()), 'saved', len(out), 'arrays')
 
 
+def run_dual_case(R, name, cfg, B, L, wseed, bseed, out_dir):
+    """The fine-tune variant (model_epic_charades.py:410-444): Dual forward + backward with the loss of configs/ft/epic.json
+    (AdaptiveMaxMarginRankingLoss on data['relation']) and of configs/ft/charades.json (NormSoftmaxLoss)."""
+    torch.manual_seed(0)
+    m = build_reference(R, cfg, dual=True).eval()
+    sd = make_state_dict(cfg, wseed, tasks='Dual')
+    ref_sd = m.state_dict()
+    assert sorted(ref_sd) == sorted(sd), (sorted(set(ref_sd) - set(sd))[:5], sorted(set(sd) - set(ref_sd))[:5])
+    m.load_state_dict(sd, strict=True)
+    names = [k for k, _ in m.named_parameters()]
+    data, _, _ = make_batch(cfg, B, L, bseed)
+    data['relation'] = make_relation(B, bseed)
+    out = {'meta_cfg': np.array([cfg.depth, cfg.n_fuse, cfg.img, cfg.frames, B, L, wseed, bseed]), 'param_names': np.array(names),
+           'relation': data['relation'].numpy()}
+    enable_cpu_forward()
+    args = types.SimpleNamespace(world_size=1, rank=0)
+    for ds, loss_fn in (('epic', R.ml.AdaptiveMaxMarginRankingLoss(margin=0.2)), ('charades', R.ml.NormSoftmaxLoss())):
+        m.zero_grad()
+        loss, ld, ret = m(data, R.AllGather_multi.apply, 1, args, {}, loss_fn, 0, task_names='Dual', dataset_name=ds)
+        loss.backward()
+        out[f'{ds}_loss'] = np.array(float(loss.detach()), dtype=np.float64)
+        out[f'{ds}_sim_v2t'] = ret['sim_v2t'].detach().numpy()
+        out[f'{ds}_grad_norms'] = np.array([(p.grad.norm().item() if p.grad is not None else -1.0) for _, p in m.named_parameters()],
+                                           dtype=np.float64)
+        pd = dict(m.named_parameters())
+        for k in ('txt_proj.1.weight', 'vid_proj.0.bias', 'video_model.cls_token', 'text_model.embeddings.LayerNorm.weight'):
+            out[f'{ds}_grad_slice::' + k] = sl(pd[k].grad, 64)
+        print(name, ds, float(loss.detach()))
+    with torch.no_grad():
+        r = m.infer(data, task_names='Dual', ret={})
+    out['text_embeds'] = r['text_embeds'].numpy()
+    out['video_embeds'] = r['video_embeds'].numpy()
+    os.makedirs(out_dir, exist_ok=True)
+    np.savez_compressed(os.path.join(out_dir, name + '.npz'), **out)
+    print(name, 'saved', len(out), 'arrays')
+
+
 CASES = {
     # BASELINE.json configs[0] shapes (all three losses so that the fusion path is pinned too)
     'tiny': dict(cfg=tiny_config(), B=2, L=16, wseed=0, bseed=1234),
@@ -241,6 +284,11 @@ CASES = {
     'base_f4': dict(cfg=PathConfig(frames=4), B=2, L=16, wseed=1, bseed=4321),
     # the full geometry of BASELINE.json configs[2] (12 + 12 layers, 16 x 224^2 frames, 32 tokens) at B = 2
     'base_f16': dict(cfg=PathConfig(frames=16), B=2, L=32, wseed=2, bseed=777),
+}
+DUAL_CASES = {
+    # fine-tune variant (256-d heads, Dual task): tiny depth and the full ViT-B/16 + RoBERTa-base towers at 4 frames
+    'dual_tiny': dict(cfg=tiny_config(proj_dim=256, proj_style='linear'), B=3, L=16, wseed=3, bseed=99),
+    'dual_base_f4': dict(cfg=PathConfig(frames=4, proj_dim=256, proj_style='linear'), B=3, L=16, wseed=4, bseed=98),
 }
 
 
@@ -251,3 +299,6 @@ if __name__ == '__main__':
     for nm, c in CASES.items():
         if which in ('all', nm):
             run_case(R, nm, c['cfg'], c['B'], c['L'], c['wseed'], c['bseed'], out_dir)
+    for nm, c in DUAL_CASES.items():
+        if which in ('all', nm):
+            run_dual_case(R, nm, c['cfg'], c['B'], c['L'], c['wseed'], c['bseed'], out_dir)

@@ -36,7 +36,7 @@ def make_cfg(**kw):
     """Shape/config record.  Defaults = the reference architecture (ViT-B/16 + RoBERTa-base,
     model/model.py:73-83, EgoNCE_MLM_ITM_Config.yml)."""
     c = dict(depth=12, n_fuse=6, img=224, patch=16, frames=16, dim=768, heads=12, mlp_ratio=4,
-             vocab=50265, max_pos=514, proj_dim=4096, pad_id=1,
+             vocab=50265, max_pos=514, proj_dim=4096, proj_style='mlp', pad_id=1,
              eps_video=1e-5, eps_text=1e-5, eps_model_norm=1e-6, eps_mlm=1e-12)
     c.update(kw)
     c = SimpleNamespace(**c)
@@ -244,14 +244,22 @@ def _proj_mlp(x, sd, prefix):
     return _lin(x, sd, prefix + '.4')
 
 
+def _proj(x, sd, prefix, cfg):
+    """projection heads: the pre-training MLP, or the fine-tune variant's txt ReLU-Linear / vid Linear
+    (model_epic_charades.py:116-119)"""
+    if getattr(cfg, 'proj_style', 'mlp') == 'linear':
+        return _lin(torch.relu(x), sd, 'txt_proj.1') if prefix == 'txt_proj' else _lin(x, sd, 'vid_proj.0')
+    return _proj_mlp(x, sd, prefix)
+
+
 def compute_text(sd, text, cfg):
-    """model.py:491-505."""
-    return _proj_mlp(text_features(sd, text['input_ids'], text['attention_mask'], cfg)[:, 0], sd, 'txt_proj')
+    """model.py:491-505 (model_epic_charades.py:447-460)."""
+    return _proj(text_features(sd, text['input_ids'], text['attention_mask'], cfg)[:, 0], sd, 'txt_proj', cfg)
 
 
 def compute_video(sd, video, cfg):
-    """model.py:524-530."""
-    return _proj_mlp(video_features(sd, video, cfg), sd, 'vid_proj')
+    """model.py:524-530 (model_epic_charades.py:481-487)."""
+    return _proj(video_features(sd, video, cfg), sd, 'vid_proj', cfg)
 
 
 def fused_stack(sd, video, input_ids, attention_mask, cfg, trace=None):
@@ -326,6 +334,41 @@ def egonce(x, sim_v, sim_n, temperature=0.05, noun=True, verb=True):
     li = torch.log((i_sm * mb).sum(1)).mean()
     lj = torch.log((j_sm * mb).sum(1)).mean()
     return -li - lj, mb, temperature
+
+
+def norm_softmax_loss(x, temperature=0.05):
+    """NormSoftmaxLoss.forward (loss.py:19-31): returns (loss, temperature)."""
+    li = torch.diag(torch.log_softmax(x / temperature, dim=1)).mean()
+    lj = torch.diag(torch.log_softmax(x.t() / temperature, dim=1)).mean()
+    return -li - lj, temperature
+
+
+def max_margin_ranking_loss(x, weight=None, margin=0.2, adaptive=False):
+    """MaxMarginRankingLoss / AdaptiveMaxMarginRankingLoss with fix_norm=True (loss.py:73-99 / :110-143): the mean over all
+    off-diagonal (i, j) of relu(m_i - (x_ii - x_ij)) and of relu(m_i - (x_ii - x_ji)), m_i = margin (* weight_i)."""
+    n = x.shape[0]
+    d = torch.diag(x).unsqueeze(1)
+    m = margin * weight.to(x.dtype).unsqueeze(1) if adaptive else margin
+    off = ~torch.eye(n, dtype=torch.bool)
+    rows = torch.relu(m - (d - x))[off]
+    cols = torch.relu(m - (d - x.t()))[off]
+    return torch.cat([rows, cols]).mean()
+
+
+def dual_forward_loss(sd, data, cfg, dataset_name='charades', margin=0.2, temperature=0.05):
+    """FrozenInTime.forward of the fine-tune variant, single rank (model_epic_charades.py:410-444) with the loss the reference
+    configs pair with it: epic -> AdaptiveMaxMarginRankingLoss(margin) on data['relation'] (configs/ft/epic.json:57-62),
+    charades -> NormSoftmaxLoss (configs/ft/charades.json:57-61).  Returns (loss, sim, text_embeds, video_embeds)."""
+    te = compute_text(sd, data['text'], cfg)
+    ve = compute_video(sd, data['video'], cfg)
+    x = sim_matrix(te, ve)
+    if dataset_name == 'epic':
+        loss = max_margin_ranking_loss(x, data['relation'], margin, adaptive=True)
+    elif dataset_name == 'charades':
+        loss, _ = norm_softmax_loss(x, temperature)
+    else:
+        raise NameError(dataset_name)
+    return loss, x, te, ve
 
 
 def itm_sample(data, itm_labels_perm, weights_v2t, weights_t2v, all_video, all_ids, all_masks, rank):

@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 from egovlpv2_amd.config import PathConfig
-from egovlpv2_amd.synthetic import make_state_dict, make_batch
+from egovlpv2_amd.synthetic import make_state_dict, make_batch, make_relation
 from oracle import ref_model as O
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
@@ -16,6 +16,20 @@ def load_golden(name):
     depth, n_fuse, img, frames, B, L, wseed, bseed = [int(x) for x in g['meta_cfg']]
     cfg = PathConfig(depth=depth, n_fuse=n_fuse, img=img, frames=frames)
     return g, cfg, B, L, wseed, bseed
+
+
+def load_golden_dual(name):
+    """fixtures of the fine-tune variant (model_epic_charades.py): 256-d 'linear' heads, task Dual"""
+    g = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+    depth, n_fuse, img, frames, B, L, wseed, bseed = [int(x) for x in g['meta_cfg']]
+    cfg = PathConfig(depth=depth, n_fuse=n_fuse, img=img, frames=frames, proj_dim=256, proj_style='linear')
+    return g, cfg, B, L, wseed, bseed
+
+
+def dual_batch(cfg, B, L, bseed):
+    data, _, _ = make_batch(cfg, B, L, bseed)
+    data['relation'] = make_relation(B, bseed)
+    return data
 
 
 def oracle_setup(cfg, B, L, wseed, bseed, requires_grad=False, tasks='EgoNCE_MLM_ITM'):

@@ -157,3 +157,27 @@ def test_egoclip_sample_format_and_batch_assembly():
     plain = collate_samples([egoclip_sample(torch.zeros(F, 3, R, R), 'a b', [1], [1])])
     d2, n2, _ = assemble_train_batch(plain, HashTokenizer(), mlm=False)
     assert d2['video'].shape[0] == 1 and 'text_mlm_ids' not in d2 and n2.shape == (1, 582)
+
+
+def test_ranking_losses_of_the_finetune_variant_match_the_reference_values():
+    """NormSoftmaxLoss / (Adaptive)MaxMarginRankingLoss (reference model/loss.py:13-31,:65-143) on the similarity matrices the
+    imported reference produced (tests/golden/dual_*.npz) reproduce its loss values; the fix_norm=False form equals the plain
+    2 n^2-term mean."""
+    import os
+    import numpy as np
+    import torch
+    from egovlpv2_amd.model.loss import NormSoftmaxLoss, MaxMarginRankingLoss, AdaptiveMaxMarginRankingLoss
+    for name in ('dual_tiny', 'dual_base_f4'):
+        g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', name + '.npz'))
+        x = torch.tensor(g['epic_sim_v2t'])
+        w = torch.tensor(g['relation'])
+        assert abs(float(AdaptiveMaxMarginRankingLoss(margin=0.2)(x, w)) - float(g['epic_loss'])) < 1e-6
+        loss, temp = NormSoftmaxLoss()(torch.tensor(g['charades_sim_v2t']))
+        assert abs(float(loss) - float(g['charades_loss'])) < 1e-5 and temp == 0.05
+        n = x.shape[0]
+        d = torch.diag(x)
+        terms = [max(0.0, 0.2 - float(d[i] - x[i, j])) for i in range(n) for j in range(n)] + \
+                [max(0.0, 0.2 - float(d[i] - x[j, i])) for i in range(n) for j in range(n)]
+        assert abs(float(MaxMarginRankingLoss(0.2, fix_norm=False)(x)) - sum(terms) / len(terms)) < 1e-6
+        off = [t for k, t in enumerate(terms) if (k % (n * n)) // n != (k % (n * n)) % n]
+        assert abs(float(MaxMarginRankingLoss(0.2)(x)) - sum(off) / len(off)) < 1e-6

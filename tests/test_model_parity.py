@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import load_golden, oracle_setup, rel_err
+from helpers import load_golden, load_golden_dual, dual_batch, oracle_setup, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -371,3 +371,53 @@ def test_odd_batch_sizes_vs_oracle_fp32(B):
     for k in ('EgoNCE', 'loss_mlm', 'loss_itm', 'loss_total'):
         assert abs(float(ld[k]) - float(old[k])) <= 1e-3 * abs(float(old[k])), (k, float(ld[k]), float(old[k]))
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
+@pytest.mark.parametrize('name', ['dual_tiny', 'dual_base_f4'])
+@pytest.mark.parametrize('dtype,tol_e,tol_l,tol_g', [(torch.float32, 1e-3, 1e-3, 5e-3), (torch.bfloat16, 2e-2, 2e-2, 0.15)])
+def test_dual_finetune_variant_vs_golden(name, dtype, tol_e, tol_l, tol_g):
+    """Fine-tune variant (reference model/model_epic_charades.py, task Dual): embeddings, similarity and both dataset losses
+    against the imported reference's values; the whole gradient against the oracle's (itself pinned to the reference's
+    per-parameter gradient norms by test_oracle_golden.py)."""
+    from oracle import ref_model as O
+    from egovlpv2_amd.model.model_epic_charades import FrozenInTime
+    from egovlpv2_amd.model.loss import AdaptiveMaxMarginRankingLoss, NormSoftmaxLoss
+    from egovlpv2_amd.trainer.trainer_egoclip import AllGather_multi
+    from egovlpv2_amd.synthetic import make_state_dict
+    g, cfg, B, L, wseed, bseed = load_golden_dual(name)
+    sd = make_state_dict(cfg, wseed, 'Dual')
+    m = FrozenInTime({'model': 'SpaceTimeTransformer', 'num_frames': cfg.frames, 'pretrained': True, 'drop_path_rate': 0.0},
+                     {'model': 'roberta-base', 'pretrained': True, 'input': 'text'}, path_config=cfg, compute_dtype=dtype)
+    m.load_state_dict({k: v.detach() for k, v in sd.items()}, strict=True)
+    m = m.cuda().eval()
+    data = dual_batch(cfg, B, L, bseed)
+    dev = {'video': data['video'].cuda(), 'text': {k: v.cuda() for k, v in data['text'].items()}, 'relation': data['relation'].cuda()}
+    args = types.SimpleNamespace(world_size=1, rank=0)
+    with torch.no_grad():
+        r = m.infer(dev, task_names='Dual')
+    assert rel_err(r['text_embeds'].float(), g['text_embeds']) < tol_e
+    assert rel_err(r['video_embeds'].float(), g['video_embeds']) < tol_e
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    oc = O.make_cfg(**cfg.as_dict())
+    for ds, fn in (('epic', AdaptiveMaxMarginRankingLoss(margin=0.2)), ('charades', NormSoftmaxLoss())):
+        m.zero_grad()
+        loss, ld, ret = m(dev, AllGather_multi.apply, 1, args, {}, fn, 0, task_names='Dual', dataset_name=ds)
+        ref = float(g[f'{ds}_loss'])
+        assert abs(float(loss.detach()) - ref) <= tol_l * abs(ref) + (0 if dtype == torch.float32 else 2e-3), (ds, float(loss.detach()), ref)
+        assert rel_err(ret['sim_v2t'], g[f'{ds}_sim_v2t']) < tol_e * 3
+        loss.backward()
+        for v in sd.values():
+            v.grad = None
+        oloss, _, _, _ = O.dual_forward_loss(sd, data, oc, ds)
+        oloss.backward()
+        num = den = dot = gg = 0.0
+        for k, p in m.named_parameters():
+            if sd[k].grad is None:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, k      # fusion layers: unused by the Dual task
+                continue
+            a, b = p.grad.detach().double().cpu(), sd[k].grad.double()
+            num += float((a - b).pow(2).sum()); den += float(b.pow(2).sum()); dot += float((a * b).sum()); gg += float(a.pow(2).sum())
+        assert math.sqrt(num / den) < tol_g, (ds, math.sqrt(num / den))
+        assert dot / math.sqrt(gg * den) > (0.999 if dtype == torch.float32 else 0.99), ds

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import ref_model as O
-from helpers import load_golden, oracle_setup, rel_err
+from helpers import load_golden, load_golden_dual, dual_batch, oracle_setup, rel_err
 
 TOL = 2e-5
 
@@ -101,3 +101,37 @@ def test_oracle_inflate_temporal():
     sd, *_ = oracle_setup(cfg, B, L, wseed, bseed)
     out = O.inflate_temporal_embed(sd['video_model.temporal_embed'], int(g['inflate_frames']))
     assert rel_err(out[0, :, :8], g['inflate_slice']) < 1e-6
+
+
+@pytest.mark.parametrize('name', ['dual_tiny', 'dual_base_f4'])
+def test_oracle_dual_variant(name):
+    """Fine-tune variant (model_epic_charades.py:410-444): embeddings, similarity, the epic (adaptive max-margin on `relation`)
+    and charades (NormSoftmax) losses and every parameter-gradient norm against the imported reference."""
+    from egovlpv2_amd.synthetic import make_state_dict
+    g, cfg, B, L, wseed, bseed = load_golden_dual(name)
+    sd = make_state_dict(cfg, wseed, 'Dual')
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    data = dual_batch(cfg, B, L, bseed)
+    assert np.array_equal(data['relation'].numpy(), g['relation'])
+    oc = O.make_cfg(**cfg.as_dict())
+    names = [str(x) for x in g['param_names']]
+    for ds in ('epic', 'charades'):
+        for v in sd.values():
+            v.grad = None
+        loss, x, te, ve = O.dual_forward_loss(sd, data, oc, ds)
+        ref = float(g[f'{ds}_loss'])
+        assert abs(float(loss.detach()) - ref) <= 1e-5 * abs(ref) + 1e-6, (ds, float(loss.detach()), ref)
+        assert rel_err(x, g[f'{ds}_sim_v2t']) < TOL
+        assert rel_err(te, g['text_embeds']) < TOL and rel_err(ve, g['video_embeds']) < TOL
+        loss.backward()
+        gn = np.array([(sd[k].grad.norm().item() if sd[k].grad is not None else -1.0) for k in names])
+        refn = g[f'{ds}_grad_norms']
+        assert np.array_equal(gn < 0, refn < 0), "same set of parameters without gradient (the fusion layers are unused)"
+        live = refn >= 0
+        assert np.allclose(gn[live], refn[live], rtol=3e-4, atol=1e-7), np.abs(gn[live] / np.maximum(refn[live], 1e-12) - 1).max()
+        for key in g.files:
+            if key.startswith(f'{ds}_grad_slice::'):
+                k = key.split('::', 1)[1]
+                assert rel_err(sd[k].grad.reshape(-1)[:64], g[key]) < 2e-4, key
