@@ -119,7 +119,7 @@ def main():
     ap.add_argument('--frames', type=int, default=16)
     ap.add_argument('--text-len', type=int, default=32)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
-    ap.add_argument('--drop-rate', type=float, default=0.1, help='RoBERTa dropout in the train step (yml drop_rate)')
+    ap.add_argument('--drop-rate', type=float, default=0.1, help='RoBERTa dropout in the train step (pretrained roberta-base config: 0.1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gemm-events', action='store_true')
     ap.add_argument('--force-ddp', action='store_true', help='wrap in DDP + RCCL even at world size 1 (test aid)')
@@ -154,7 +154,7 @@ def main():
     from egovlpv2_amd.model.loss import EgoNCE
     from egovlpv2_amd.trainer.trainer_egoclip import AllGather_multi
 
-    cfg = PathConfig(frames=a.frames, drop_rate=a.drop_rate)     # EgoClip_pretrain.yml drop_rate (RoBERTa side, train mode)
+    cfg = PathConfig(frames=a.frames, drop_rate=a.drop_rate)     # roberta-base hidden / attention dropout (train mode)
     tasks = 'EgoNCE' if a.workload == 'dual' else 'EgoNCE_MLM_ITM'
     dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
     model = FrozenInTime({'model': 'SpaceTimeTransformer', 'num_frames': cfg.frames, 'pretrained': True},

@@ -31,8 +31,11 @@ class PathConfig:
     eps_text: float = 1e-5     # roberta-base layer_norm_eps
     eps_model_norm: float = 1e-6   # model.py:154-155
     eps_mlm: float = 1e-12     # BertPredictionHeadTransform with default RobertaConfig (heads.py:41)
-    drop_rate: float = 0.0     # RoBERTa hidden/attention dropout in train mode (yml drop_rate = 0.1, model.py:135-136);
-                               # 0 here so that parity cases are deterministic -- FrozenInTime(config=yml) passes the yml value
+    drop_rate: float = 0.0     # RoBERTa hidden / attention-probability dropout in train mode.  In the reference the text tower is
+                               # RobertaModel.from_pretrained('roberta-base') (model.py:68), i.e. the pretrained config's fixed 0.1
+                               # -- the yml drop_rate only reaches bert_config, which feeds the dropout-free MLMHead
+                               # (model.py:127-137).  FrozenInTime(...) therefore sets 0.1 whatever the yml says; 0 here so that
+                               # parity cases built from a PathConfig are deterministic.
 
     @property
     def n_patches(self) -> int:

@@ -36,6 +36,7 @@ DEFAULT_YML = dict(input_image_embed_size=768, vocab_size=50265, mlm_prob=0.15, 
                    hidden_size=768, num_heads=12, num_layers=12, mlp_ratio=4, drop_rate=0.1, num_fuse_block=6,
                    use_checkpoint=True, decay_power='cosine', end_lr=1e-7, warmup_steps=0.1)
 config = dict(DEFAULT_YML)
+ROBERTA_BASE_DROPOUT = 0.1     # hidden_dropout_prob = attention_probs_dropout_prob of the pretrained roberta-base config (model.py:68)
 
 F32_MIN = torch.finfo(torch.float32).min
 
@@ -137,7 +138,7 @@ class FrozenInTime(nn.Module):
                                      frames=video_params['num_frames'], dim=embed_dim, heads=self.config['num_heads'],
                                      mlp_ratio=self.config['mlp_ratio'], vocab=self.config['vocab_size'],
                                      proj_dim=projection_dim, img=video_params.get('img_size', 224),
-                                     drop_rate=self.config['drop_rate'])
+                                     drop_rate=ROBERTA_BASE_DROPOUT)
         self.cfg = path_config
         if self.cfg.head_dim != 64:
             raise NotImplementedError("attention kernels are built for head_dim 64")
@@ -298,7 +299,9 @@ class FrozenInTime(nn.Module):
 
     # ------------------------------------------------------------------ text side
     def _drop_p(self) -> float:
-        """hidden_dropout_prob = attention_probs_dropout_prob = yml drop_rate (model.py:135-136), train mode only"""
+        """hidden / attention-probability dropout of the text tower, train mode only: the pretrained roberta-base value (the
+        constructor sets cfg.drop_rate = 0.1; the yml drop_rate does not reach the text tower in the reference, model.py:68 vs
+        :127-137)"""
         return float(self.cfg.drop_rate) if self.training else 0.0
 
     def _drop_seed(self) -> int:
@@ -555,8 +558,10 @@ class FrozenInTime(nn.Module):
             pos_len = bsz // 2
             itm_labels = torch.cat([torch.ones(pos_len), torch.zeros(bsz - pos_len)])
             itm_labels = itm_labels[torch.randperm(itm_labels.size(0))]
-            # ONE device->host copy (started above); negatives are drawn on the host with the reference's RNG consumption
-            # order (np.random.rand then torch.multinomial per negative, model.py:459-468) instead of one sync per sample.
+            # ONE device->host copy (started above); negatives are drawn on the host in the reference's ORDER of draws
+            # (randperm, then np.random.rand and torch.multinomial per negative, model.py:438,459-468) instead of one sync per
+            # sample.  All draws use the CPU generators; the reference's multinomial runs on the CUDA generator when the weights
+            # live on a GPU, so equal seeds give equal negatives only against a CPU run of the reference (the golden fixtures).
             ev.synchronize()
             w_cpu = w_host
             vid_idx = torch.arange(bsz) + rank * bsz

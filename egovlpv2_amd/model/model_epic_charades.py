@@ -10,7 +10,7 @@ import torch
 
 from .. import hipops as ops
 from ..config import PathConfig
-from .model import FrozenInTime as _PretrainModel, DEFAULT_YML, sim_matrix, sim_matrix_batch_val   # noqa: F401
+from .model import FrozenInTime as _PretrainModel, DEFAULT_YML, ROBERTA_BASE_DROPOUT, sim_matrix, sim_matrix_batch_val   # noqa: F401
 
 
 class FrozenInTime(_PretrainModel):
@@ -26,7 +26,7 @@ class FrozenInTime(_PretrainModel):
             path_config = PathConfig(depth=yml['num_layers'], n_fuse=yml['num_fuse_block'], frames=video_params['num_frames'],
                                      dim=embed_dim, heads=yml['num_heads'], mlp_ratio=yml['mlp_ratio'], vocab=yml['vocab_size'],
                                      proj_dim=256, proj_style='linear', img=video_params.get('img_size', 224),
-                                     drop_rate=yml['drop_rate'])
+                                     drop_rate=ROBERTA_BASE_DROPOUT)
         if path_config.proj_style != 'linear':
             raise ValueError("the fine-tune variant uses proj_style='linear' heads")
         super().__init__(video_params, text_params, projection_dim=path_config.proj_dim, load_checkpoint=load_checkpoint,

@@ -70,18 +70,10 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._tables = {}
 
-    def _table(self, gi, group):
-        """device table (one 32-byte record per tensor) + chunk prefix; rebuilt only when a pointer changed"""
+    def _table(self, gi, plist):
+        """device table (one 32-byte record per tensor) + chunk prefix for the tensors of one launch; rebuilt only when a
+        pointer changed"""
         import numpy as np
-        plist = [p for p in group['params'] if p.grad is not None]
-        if not plist:
-            return None, None, 0, 0
-        for p in plist:
-            st = self.state[p]
-            if 'exp_avg' not in st:
-                st['step'] = 0
-                st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
         arr = np.zeros(len(plist), dtype=[('p', '<u8'), ('g', '<u8'), ('m', '<u8'), ('v', '<u8'), ('n', '<i4'), ('pad', '<i4')])
         arr['p'] = [p.data_ptr() for p in plist]
         arr['g'] = [p.grad.data_ptr() for p in plist]
@@ -110,19 +102,30 @@ class FusedAdamW(torch.optim.Optimizer):
         from ._lib import lib, check
         loss = closure() if closure is not None else None
         for gi, group in enumerate(self.param_groups):
-            table, prefix, nt, nchunks = self._table(gi, group)
-            if not nt:
-                continue
-            plist = [p for p in group['params'] if p.grad is not None]
-            t = self.state[plist[0]]['step'] + 1
-            for p in plist:
-                self.state[p]['step'] = t
+            # 'step' is per parameter, as in HF AdamW: a tensor that had no gradient in some steps (task subsets, unused
+            # fusion layers, a resumed optimiser state) keeps its own bias correction.  Tensors are launched together per
+            # distinct step value -- one launch per group in the usual case where they all agree.
+            by_step = {}
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if 'exp_avg' not in st:
+                    st['step'] = 0
+                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                by_step.setdefault(int(st['step']), []).append(p)
             b1, b2 = group['betas']
             lr = group['lr']
-            step_size = lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t) if group['correct_bias'] else lr
-            check(lib.egv_adamw_step(table.data_ptr(), prefix.data_ptr(), nt, nchunks, float(lr), float(step_size), float(b1), float(b2), float(group['eps']),
-                                     float(group['weight_decay']), float(grad_scale), torch.cuda.current_stream().cuda_stream),
-                  'egv_adamw_step')
+            for si, (t0, plist) in enumerate(sorted(by_step.items())):
+                table, prefix, nt, nchunks = self._table((gi, si), plist)
+                t = t0 + 1
+                for p in plist:
+                    self.state[p]['step'] = t
+                step_size = lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t) if group['correct_bias'] else lr
+                check(lib.egv_adamw_step(table.data_ptr(), prefix.data_ptr(), nt, nchunks, float(lr), float(step_size), float(b1), float(b2),
+                                         float(group['eps']), float(group['weight_decay']), float(grad_scale),
+                                         torch.cuda.current_stream().cuda_stream), 'egv_adamw_step')
         ops.invalidate_weight_cache()          # the fp32 masters changed: bf16 compute copies are stale
         return loss
 

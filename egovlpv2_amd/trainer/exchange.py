@@ -12,7 +12,8 @@ and the gradient of those tokens travels back to the owner in backward, where it
 of the same prefix.  Values are identical to the reference's (the prefix is a function of the pixels and of replicated
 parameters only, and the kernels are batch-composition independent); parameter gradients are identical after DDP's
 averaging because the owner's contribution replaces the requester's (the sum over ranks is unchanged).  The ITM draw itself
-keeps the reference's RNG order (model/model.py:459-468) -- it happens before this exchange, per rank, on the host.
+keeps the reference's order of draws (model/model.py:459-468; CPU generators, see FrozenInTime.forward) -- it happens before this
+exchange, per rank, on the host.
 """
 from __future__ import annotations
 

@@ -181,3 +181,45 @@ def test_ranking_losses_of_the_finetune_variant_match_the_reference_values():
         assert abs(float(MaxMarginRankingLoss(0.2, fix_norm=False)(x)) - sum(terms) / len(terms)) < 1e-6
         off = [t for k, t in enumerate(terms) if (k % (n * n)) // n != (k % (n * n)) % n]
         assert abs(float(MaxMarginRankingLoss(0.2)(x)) - sum(off) / len(off)) < 1e-6
+
+
+class _OpaqueConfig:
+    """stands in for the ConfigParser object the reference trainer pickles under 'config' (base_trainer.py:412-436)"""
+
+    def __init__(self):
+        self.name = 'EgoClip_4f'
+
+
+def test_load_checkpoint_roundtrip_with_pickled_config_module_prefix_and_frame_inflation(tmp_path):
+    """FrozenInTime(load_checkpoint=...) (model.py:158-176): a checkpoint written the way the reference trainer writes it --
+    'config' is an arbitrary pickled object (torch >= 2.6 needs weights_only=False for it), keys carry DistributedDataParallel's
+    'module.' prefix, and the temporal embedding has 2 frames while the model is built for 4 (bilinear inflation, :532-563;
+    values checked against oracle.inflate_temporal_embed, itself pinned by tests/golden)."""
+    import torch
+    from egovlpv2_amd.config import tiny_config
+    from egovlpv2_amd.model.model import FrozenInTime
+    from egovlpv2_amd.synthetic import make_state_dict
+    from oracle import ref_model as O
+    cfg2 = tiny_config(frames=2)
+    sd2 = make_state_dict(cfg2, 5)
+    path = str(tmp_path / 'ckpt.pth')
+    torch.save({'arch': 'FrozenInTime', 'epoch': 3, 'config': _OpaqueConfig(),
+                'state_dict': {'module.' + k: v for k, v in sd2.items()}}, path)
+    cfg4 = tiny_config(frames=4)
+    vp = {'model': 'SpaceTimeTransformer', 'num_frames': 4, 'pretrained': True}
+    tp = {'model': 'roberta-base', 'pretrained': True, 'input': 'text'}
+    m = FrozenInTime(vp, tp, path_config=cfg4, load_checkpoint=path, compute_dtype=torch.float32)
+    got = m.state_dict()
+    for k, v in sd2.items():
+        if k == 'video_model.temporal_embed':
+            want = O.inflate_temporal_embed(v, 4, 'bilinear')
+            assert got[k].shape == (1, 4, cfg4.dim) and torch.allclose(got[k], want, atol=1e-6)
+        else:
+            assert torch.equal(got[k], v), k
+    # 'zeros' inflation and truncation (load_f > curr_f)
+    m0 = FrozenInTime(vp, tp, path_config=cfg4, load_checkpoint=path, load_temporal_fix='zeros', compute_dtype=torch.float32)
+    te = m0.state_dict()['video_model.temporal_embed']
+    assert torch.equal(te[:, :2], sd2['video_model.temporal_embed']) and float(te[:, 2:].abs().max()) == 0.0
+    torch.save({'config': _OpaqueConfig(), 'state_dict': make_state_dict(cfg4, 6)}, path)
+    m1 = FrozenInTime({**vp, 'num_frames': 2}, tp, path_config=cfg2, load_checkpoint=path, compute_dtype=torch.float32)
+    assert torch.equal(m1.state_dict()['video_model.temporal_embed'], make_state_dict(cfg4, 6)['video_model.temporal_embed'][:, :2])

@@ -76,6 +76,42 @@ def test_fused_adamw_matches_oracle():
 
 
 @pytest.mark.gpu
+def test_fused_adamw_keeps_a_step_count_per_parameter():
+    """HF AdamW semantics: 'step' (and with it the bias correction) advances only for parameters that had a gradient.  Two
+    tensors of one group get gradients on different subsets of the steps; both must follow the oracle update with their own t.
+    Also: a 1-element tensor in front of a larger one inside one flat buffer (a DDP bucket view) makes the second tensor's
+    gradient 4-byte aligned only -- the kernel must take its scalar path for it."""
+    from egovlpv2_amd.set_optim_schedule import FusedAdamW
+    from oracle.ref_optim import adamw_step
+    torch.manual_seed(1)
+    a = torch.nn.Parameter(torch.randn(1000, device='cuda'))
+    b = torch.nn.Parameter(torch.randn(3, 700, device='cuda'))
+    flat = torch.zeros(1 + 2100, device='cuda')                          # gradient "bucket": [1 pad element | b.grad]
+    opt = FusedAdamW([a, b], lr=1e-2, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01)
+    ref = {n: p.detach().double().cpu().clone() for n, p in (('a', a), ('b', b))}
+    st = {n: [torch.zeros_like(v), torch.zeros_like(v), 0] for n, v in ref.items()}
+    for step in range(1, 8):
+        gen = torch.Generator().manual_seed(100 + step)
+        ga, gb = torch.randn(1000, generator=gen), torch.randn(3, 700, generator=gen)
+        a.grad = ga.cuda() if step % 2 == 1 else None                    # a: steps 1, 3, 5, 7
+        if step != 2:                                                    # b: every step but the second
+            flat[1:].copy_(gb.reshape(-1))
+            b.grad = flat[1:].view(3, 700)
+            assert b.grad.data_ptr() % 16 != 0
+        else:
+            b.grad = None
+        for n, g, has in (('a', ga, step % 2 == 1), ('b', gb, step != 2)):
+            if has:
+                st[n][2] += 1
+                adamw_step(ref[n], g.double(), st[n][0], st[n][1], st[n][2], 1e-2, (0.9, 0.98), 1e-8, 0.01)
+        opt.step()
+    assert opt.state[a]['step'] == 4 and opt.state[b]['step'] == 6
+    for n, p in (('a', a), ('b', b)):
+        err = (p.detach().double().cpu() - ref[n]).abs().max().item()
+        assert err < 2e-6, (n, err)
+
+
+@pytest.mark.gpu
 def test_checkpoint_resume_continues_fused_adamw(tmp_path):
     """base_trainer.py:412-495 format with the HIP optimiser: save after 2 steps, resume into a fresh model/optimiser,
     one more step on both -> identical parameters (state keys 'step'/'exp_avg'/'exp_avg_sq' as in HF AdamW)."""
