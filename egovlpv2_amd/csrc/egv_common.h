@@ -72,6 +72,19 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float readlane_f(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
+
+// wave-wide sum with DPP lane exchanges inside the 16-lane rows (no LDS traffic, unlike the bpermute butterfly of wave_sum) and
+// four v_readlane for the rows; every lane returns the same value.  All 64 lanes must be active.
+template <int CTRL> __device__ __forceinline__ float dpp_mov_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_mov_f<0xB1>(v);       // quad_perm [1,0,3,2]
+    v += dpp_mov_f<0x4E>(v);       // quad_perm [2,3,0,1]
+    v += dpp_mov_f<0x141>(v);      // row_half_mirror
+    v += dpp_mov_f<0x140>(v);      // row_mirror
+    return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
+}
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
