@@ -90,6 +90,7 @@ PROTOTYPES = {
     'egv_cast_transpose': (i32, [vp, vp, i32, i32, vp]),
     'egv_transpose': (i32, [i32, i32, vp, vp, i32, i32, i32, vp]),
     'egv_cast_weights': (i32, [vp, vp, i32, i32, vp]),
+    'egv_stream_create': (i32, [i32, C.POINTER(vp)]),
     'egv_attn_split_workspace_bytes': (i64, [i32, i32, i32, i32, i32, i32]),
     'egv_attn_fwd': (i32, [i32, C.POINTER(AttnDesc), vp]),
     'egv_attn_bwd_dq': (i32, [i32, C.POINTER(AttnDesc), vp]),

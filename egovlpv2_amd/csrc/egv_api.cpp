@@ -19,6 +19,19 @@ void egv_set_error(const char* fmt, ...) {
 
 extern "C" int egv_abi_version(void) { return 1; }
 
+extern "C" int egv_stream_create(int priority, void** stream) {
+    if (!stream) { egv_set_error("egv_stream_create: null output pointer"); return -1; }
+    int least = 0, greatest = 0;
+    hipDeviceGetStreamPriorityRange(&least, &greatest);          // numerically: greatest <= least
+    if (priority > least) priority = least;
+    if (priority < greatest) priority = greatest;
+    hipStream_t s = nullptr;
+    const hipError_t e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority);
+    if (e != hipSuccess) { egv_set_error("egv_stream_create: %s", hipGetErrorString(e)); return -1; }
+    *stream = reinterpret_cast<void*>(s);
+    return 0;
+}
+
 // ---- per-launch HIP-event timing of the GEMM kernels, on the stream they are launched on ----
 namespace {
 struct Rec { hipEvent_t a, b; double flops, bytes; int kind; };

@@ -241,8 +241,22 @@ def dot(a, b):
     return out
 
 
-# ---- weight-gradient stream -----------------------------------------------------------------------------
+# ---- companion streams ------------------------------------------------------------------------------------
 _wg_streams = {}
+
+
+def companion_stream(device):
+    """A stream for work that runs beside the calling stream (weight gradients, the text tower).  HIP priority
+    EGV_SIDE_PRIORITY (default 1 = low: the companions' workgroups only take CUs the calling stream's kernels leave free;
+    0 = a plain torch stream)."""
+    prio = int(os.environ.get('EGV_SIDE_PRIORITY', '1'))
+    if prio == 0:
+        return torch.cuda.Stream(device=device)
+    h = C.c_void_p()
+    with torch.cuda.device(device):
+        check(lib.egv_stream_create(prio, C.byref(h)), 'egv_stream_create')
+    return torch.cuda.ExternalStream(h.value, device=device)
+
 
 
 def _wgrad_fork(M, fn, uses):
@@ -258,7 +272,7 @@ def _wgrad_fork(M, fn, uses):
     key = (cur.device.index, cur.cuda_stream)
     st = _wg_streams.get(key)
     if st is None:
-        st = _wg_streams[key] = torch.cuda.Stream(device=cur.device)
+        st = _wg_streams[key] = companion_stream(cur.device)
     st.wait_stream(cur)
     for t in uses:
         if t is not None:
@@ -733,7 +747,7 @@ def _side_stream_ptr():
     key = (cur.device.index, cur.cuda_stream)
     st = _wg_streams.get(key)
     if st is None:
-        st = _wg_streams[key] = torch.cuda.Stream(device=cur.device)
+        st = _wg_streams[key] = companion_stream(cur.device)
     return st.cuda_stream
 
 

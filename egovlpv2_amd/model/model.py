@@ -194,7 +194,7 @@ class FrozenInTime(nn.Module):
             return fn(), (lambda: None)
         main = torch.cuda.current_stream()
         if getattr(self, '_side', None) is None or self._side.device != main.device:
-            self._side = torch.cuda.Stream(device=main.device)
+            self._side = ops.companion_stream(main.device)
         side = self._side
         if after is None:
             side.wait_stream(main)

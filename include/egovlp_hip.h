@@ -39,6 +39,11 @@ extern "C" {
 int egv_abi_version(void);
 const char* egv_last_error(void);
 
+/* A non-blocking HIP stream for companion work (weight gradients, the text tower) at HIP priority `priority`:
+ * -1 high, 0 normal, 1 low (hipDeviceGetStreamPriorityRange on gfx950).  Low-priority companions only take the CUs the
+ * calling stream's kernels leave free.  The handle is a hipStream_t; it lives until process exit. */
+int egv_stream_create(int priority, void** stream);
+
 /* ---- GEMM with fused epilogue: every nn.Linear / Conv2d(k=s=16) on the path ------------------------
  * C[M,N] = epi( sum_k Aop[m,k] * Bop[n,k] ),  Aop = A[M,K] (a_trans=0) or A[K,M] (a_trans=1), same for B.
  *   forward  x W^T + b : a_trans=0, b_trans=0        (video_transformer.py:53,56,120,152,160,166,183;

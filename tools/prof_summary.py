@@ -11,6 +11,23 @@ if view is None:
 cols = [c[1] for c in db.execute(f"pragma table_info('{view}')")]
 namecol = 'name' if 'name' in cols else 'kernel_name'
 rows = db.execute(f"select {namecol}, start, end from {view}").fetchall()
+# GPU busy time = union of all kernel intervals; per HIP stream: sum of its kernels (how the work is spread over the streams)
+if 'stream_id' in cols:
+    iv = sorted(db.execute(f"select start, end, stream_id from {view}").fetchall())
+    busy, cur_s, cur_e = 0, None, None
+    per_stream = collections.defaultdict(float)
+    for s0, e0, sid in iv:
+        per_stream[sid] += (e0 - s0) / 1e6
+        if cur_e is None or s0 > cur_e:
+            if cur_e is not None:
+                busy += cur_e - cur_s
+            cur_s, cur_e = s0, e0
+        else:
+            cur_e = max(cur_e, e0)
+    busy += (cur_e - cur_s) if cur_e is not None else 0
+    span = (max(e for _, e, _ in iv) - min(s0 for s0, _, _ in iv)) / 1e6
+    print(f"Kernel-interval union (GPU busy) {busy / 1e6 / steps:.1f} ms/step of a {span / steps:.1f} ms/step trace span; per stream (ms/step): "
+          + ", ".join(f"stream {k}: {v / steps:.1f}" for k, v in sorted(per_stream.items(), key=lambda kv: -kv[1])[:4]) + "\n")
 agg = collections.defaultdict(list)
 for n, s, e in rows:
     n = re.sub(r'\(.*$', '', n)
