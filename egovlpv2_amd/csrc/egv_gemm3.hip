@@ -45,9 +45,9 @@ constexpr int PP_LDS = 2 * PP_BUF + 16384; // + 1 KiB per wave of dummy DMA targ
 struct PPTile {
     int m0, n0;
 };
-__device__ __forceinline__ PPTile pp_tile(int t, int tiles_n) {
+__device__ __forceinline__ PPTile pp_tile(int t, int tiles_n, int bm) {
     PPTile r;
-    r.m0 = (t / tiles_n) * 256;
+    r.m0 = (t / tiles_n) * bm;
     r.n0 = (t % tiles_n) * 256;
     return r;
 }
@@ -81,9 +81,14 @@ __host__ __device__ constexpr int pp_nwait(int kind, int p, int NSQ, bool bulk) 
 //   X1K : 0 none, 1 residual res1 added (forward of proj / fc2), 2 activation-derivative operand aux multiplied (dgrad)
 //   PREK: also store the pre-activation (fc1) -- doubles the stores of a tile
 //   ACTK: e.act may be non-zero
-template <int X1K, bool PREK, bool ACTK, bool STAMPS = false>
+//   IM  : 16-row fragments per A sub-tile and wave row: 4 = 256-row tiles; 3 = 192-row tiles (wave tile 96 x 64, 12 MFMAs per
+//         phase, 12 KB A units) for the N = 768 GEMMs, whose 98 x 3 = 294 tiles of 256 rows leave the second round of a
+//         224-workgroup grid one third full (131 x 3 = 393 tiles of 3/4 the work: 1.5 instead of 2 tile-times)
+template <int X1K, bool PREK, bool ACTK, bool STAMPS = false, int IM = 4>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntiles) {
-    constexpr int NSQ = PREK ? 8 : 4;
+    static_assert(IM == 4 || IM == 3, "A sub-tile of 4 or 3 fragments");
+    constexpr int BM = IM * 64, WM = IM * 32, SM = IM * 16;        // tile rows, rows per wave row, rows per A sub-tile and wave row
+    constexpr int NSQ = PREK ? 2 * IM : IM;
     constexpr bool BULK = X1K != 0;                                // residual / GELU' operand: epilogue in one piece at the tile's end
     constexpr unsigned int OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -108,15 +113,26 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
     const int schunk = ((lane & 7) ^ srow) * 8;                   // element offset inside the 64-wide K-tile
     unsigned int soff[4][2];                                      // byte offsets (from A / B) of this lane's source rows: [unit][piece]
     auto set_stage_tile = [&](int t) {
-        const PPTile tl = pp_tile(t, g.tiles_n);
+        const PPTile tl = pp_tile(t, g.tiles_n, BM);
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int rho = (p * 8 + wave) * 8 + srow;            // 0..127
-            // A units: rho -> tile row (rho>>6)*128 + sub*64 + (rho&63)
-            const int ra0 = min(tl.m0 + (rho >> 6) * 128 + (rho & 63), g.M - 1);
-            const int ra1 = min(tl.m0 + (rho >> 6) * 128 + 64 + (rho & 63), g.M - 1);
-            soff[0][p] = (unsigned int)(ra0 * g.lda + schunk) * 2u;
-            soff[3][p] = (unsigned int)(ra1 * g.lda + schunk) * 2u;
+            if constexpr (IM == 4) {
+                // A units: rho -> tile row (rho>>6)*128 + sub*64 + (rho&63)
+                const int ra0 = min(tl.m0 + (rho >> 6) * 128 + (rho & 63), g.M - 1);
+                const int ra1 = min(tl.m0 + (rho >> 6) * 128 + 64 + (rho & 63), g.M - 1);
+                soff[0][p] = (unsigned int)(ra0 * g.lda + schunk) * 2u;
+                soff[3][p] = (unsigned int)(ra1 * g.lda + schunk) * 2u;
+            } else {
+                // 96-row A units: this wave stages rows wave*12 .. +11 -- piece 0 = 8 rows, piece 1 = 4 rows (lanes 0..31 only);
+                // unit row ra -> tile row (ra/48)*96 + sub*48 + ra%48; source chunk (lane&7) ^ (ra&7) (the reads' swizzle)
+                const int ra = min(wave * 12 + p * 8 + srow, 95);
+                const int ra0 = min(tl.m0 + (ra / 48) * 96 + (ra % 48), g.M - 1);
+                const int ra1 = min(tl.m0 + (ra / 48) * 96 + 48 + (ra % 48), g.M - 1);
+                const int sch = ((lane & 7) ^ (ra & 7)) * 8;
+                soff[0][p] = (unsigned int)(ra0 * g.lda + sch) * 2u;
+                soff[3][p] = (unsigned int)(ra1 * g.lda + sch) * 2u;
+            }
             // B units: rho = wc'*32 + j'*16 + q -> column wc'*64 + sub*32 + (q>>2)*8 + j'*4 + (q&3)
             const int wcp = rho >> 5, jp = (rho >> 4) & 1, q = rho & 15;
             const int cb0 = min(tl.n0 + wcp * 64 + (q >> 2) * 8 + jp * 4 + (q & 3), g.N - 1);
@@ -143,12 +159,27 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                      : "v"(voff), "s"(base), "s"(lds_dst)
                      : "memory");
     };
+    auto glds_half = [&](const void* base, unsigned int voff, unsigned int lds_dst) {      // lanes 0..31 only (512 bytes)
+        unsigned int keep;
+        unsigned long long ex;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_mov_b64 %1, exec\n\ts_mov_b32 exec_hi, 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+                     "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep), "=&s"(ex)
+                     : "v"(voff), "s"(base), "s"(lds_dst)
+                     : "memory");
+    };
     auto stage_unit = [&](int u) {                                // u is a compile-time constant at every call site
         const unsigned int live = s_tile_seq < my_tiles ? ~0u : 0u;   // past my last tile: harmless DMAs into the dummy slab keep
                                                                        // the vmcnt arithmetic uniform
         const unsigned int dst = lds0 + (s_gkt & 1) * PP_BUF + u * PP_UNIT + wave * 1024;
         const void* base = (u == 0 || u == 3) ? g.A : g.B;
         const unsigned int koff = (unsigned int)s_kt * 128u;
+        if (IM == 3 && (u == 0 || u == 3)) {                      // 96-row A unit: 1.5 KiB per wave
+            const unsigned int dsta = lds0 + (s_gkt & 1) * PP_BUF + u * PP_UNIT + wave * 1536;
+            glds(base, (soff[u][0] + koff) & live, __builtin_amdgcn_readfirstlane(dummy_lds + ((dsta - dummy_lds) & live)));
+            glds_half(base, (soff[u][1] + koff) & live, __builtin_amdgcn_readfirstlane(dummy_lds + ((dsta + 1024 - dummy_lds) & live)));
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const unsigned int voff = (soff[u][p] + koff) & live;
@@ -167,7 +198,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
 
     // ---- fragment read offsets (bytes inside a K-tile buffer)
     const int swz0 = ((0 * 4 + fg) ^ (fr & 7)) * 16, swz1 = ((1 * 4 + fg) ^ (fr & 7)) * 16;
-    const int a_base = (wr * 64 + fr) * 128;                      // + i*2048 ; unit U0 (sub 0) / U3 (sub 1)
+    const int a_base = (wr * SM + fr) * 128;                      // + i*2048 ; unit U0 (sub 0) / U3 (sub 1)
     const int b_base = (wc * 32 + fr) * 128;                      // + j'*2048 ; unit U1 (sub 0) / U2 (sub 1)
 
     // ---- epilogue operands: buffer descriptors (range = whole matrix; offset 2^31 is out of range by construction: such
@@ -186,8 +217,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
     // Byte offset = per-lane constant + a wave-uniform term (one v_add per access, nothing kept per tile).  Rows >= M fall
     // outside the descriptor's range by themselves; columns >= N (N % 64 == 0: both halves of a lane agree) are sent there.
     const int lane_col = wc * 64 + fg * 8;
-    const unsigned int lane_c = (unsigned int)((wr * 128 + fr) * g.ldc + lane_col) * 2u;
-    const unsigned int lane_r = (unsigned int)((wr * 128 + fr) * e.ldr + lane_col) * 2u;
+    const unsigned int lane_c = (unsigned int)((wr * WM + fr) * g.ldc + lane_col) * 2u;
+    const unsigned int lane_r = (unsigned int)((wr * WM + fr) * e.ldr + lane_col) * 2u;
     // stores: a lane pair (rows fr, fr^8) trades halves so that ONE store instruction writes 8 CONSECUTIVE rows x 128 contiguous bytes (the
     // wave's whole 64-column slab of a row) instead of 16 rows x 64: the CU's store path is issue-bound on lines per instruction
     // (measured: 12.4k -> 8.7k cycles for the 128 KB of a tile).  Lane (fr, fg): row (fr & 7) [+8 for the second store of
@@ -201,8 +232,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
         const int fr_ = l & 15, fg_ = l >> 4;
         const int ld = out ? g.ldc : e.ldr;
         const int pair_col = wc * 64 + (fr_ >> 3) * 32 + fg_ * 8;
-        const unsigned int lane_part = (__umul24((unsigned int)(wr * 128 + (fr_ & 7)), (unsigned int)ld) + (unsigned int)pair_col) * 2u;
-        const unsigned int sterm = (unsigned int)((tl.m0 + s * 64 + i * 16 + second * 8) * ld + tl.n0) * 2u;
+        const unsigned int lane_part = (__umul24((unsigned int)(wr * WM + (fr_ & 7)), (unsigned int)ld) + (unsigned int)pair_col) * 2u;
+        const unsigned int sterm = (unsigned int)((tl.m0 + s * SM + i * 16 + second * 8) * ld + tl.n0) * 2u;
         return (tl.n0 + pair_col < g.N) ? lane_part + sterm : OOB;
     };
     // (a, b) of this lane = (t = 0, t = 1) vectors of its row  ->  (first, second) store vectors
@@ -218,7 +249,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
     };
     auto q_off = [&](const PPTile& tl, bool valid, int s, int i, int t, bool out) -> unsigned int {
         const int ld = out ? g.ldc : e.ldr;
-        const unsigned int sterm = (unsigned int)((tl.m0 + s * 64 + i * 16) * ld + tl.n0 + t * 32) * 2u;
+        const unsigned int sterm = (unsigned int)((tl.m0 + s * SM + i * 16) * ld + tl.n0 + t * 32) * 2u;
         return (valid && tl.n0 + lane_col < g.N) ? (out ? lane_c : lane_r) + sterm : OOB;
     };
 
@@ -232,11 +263,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
         const unsigned int voff = (unsigned int)min(tb.n0 + lane * 4, g.N - 4) * 4u;
         glds(has_bias ? (const void*)e.bias : g.B, has_bias ? voff : 0u, __builtin_amdgcn_readfirstlane(bias_lds));
     };
-    f32x4_t acc[8][4];                                            // (s*4+i, t*2+j'); written by the first MFMAs of every tile
-    bf16x8_t af[4][2], bf0[2][2], bf1[2][2];
+    f32x4_t acc[2 * IM][4];                                       // (s*IM+i, t*2+j'); written by the first MFMAs of every tile
+    bf16x8_t af[IM][2], bf0[2][2], bf1[2][2];
 
     // convert + store the two quadrants (s, 0), (s, 1) of the finished tile `tl`: 8 full-line stores (16 with the pre-activation)
-    u32x4_t xop[2][4][2];                                         // bulk epilogue: residual / GELU' operand vectors (s, i, t) of the tile
+    u32x4_t xop[2][IM][2];                                         // bulk epilogue: residual / GELU' operand vectors (s, i, t) of the tile
     auto pair_epilogue = [&](int s, const PPTile& tl) {           // s compile-time
         float bias8[2][8];                                        // the finished tile's bias from this wave's LDS slab
         {
@@ -250,13 +281,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < IM; ++i) {
             u32x4_t f, sec;
             if (PREK) {                                           // pre-activation first, in its own pass (register budget)
                 u32x4_t pr[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const f32x4_t a0 = acc[s * 4 + i][t * 2 + 0], a1 = acc[s * 4 + i][t * 2 + 1];
+                    const f32x4_t a0 = acc[s * IM + i][t * 2 + 0], a1 = acc[s * IM + i][t * 2 + 1];
                     pr[t] = u32x4_t{pack_bf16x2(a0[0] + bias8[t][0], a0[1] + bias8[t][1]), pack_bf16x2(a0[2] + bias8[t][2], a0[3] + bias8[t][3]),
                                     pack_bf16x2(a1[0] + bias8[t][4], a1[1] + bias8[t][5]), pack_bf16x2(a1[2] + bias8[t][6], a1[3] + bias8[t][7])};
                 }
@@ -270,8 +301,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                 float v[8];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    v[k] = acc[s * 4 + i][t * 2 + 0][k] + bias8[t][k];            // (sum over K) + bias: the ring kernels' order, bit for bit
-                    v[4 + k] = acc[s * 4 + i][t * 2 + 1][k] + bias8[t][4 + k];
+                    v[k] = acc[s * IM + i][t * 2 + 0][k] + bias8[t][k];            // (sum over K) + bias: the ring kernels' order, bit for bit
+                    v[4 + k] = acc[s * IM + i][t * 2 + 1][k] + bias8[t][4 + k];
                 }
                 if (ACTK) {
                     if (e.act == 1) {
@@ -315,7 +346,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
 
     // ---- prologue: the first tile's bias (and residual quadrants 0, 1) first, then U0..U3 of K-tile 0 and U0 U1 of K-tile 1
     // (the units the steady-state schedule would have issued before phase 0)
-    PPTile cur = pp_tile(first, g.tiles_n);
+    PPTile cur = pp_tile(first, g.tiles_n, BM);
     stage_unit(0); stage_unit(1); stage_unit(2); stage_unit(3);
     advance_cursor();
     stage_unit(0); stage_unit(1);
@@ -330,10 +361,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
     do {                                                                                                                   \
         __builtin_amdgcn_s_setprio(1);                                                                                     \
         _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                                   \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                      \
+        _Pragma("unroll") for (int i = 0; i < IM; ++i)                                                                     \
         _Pragma("unroll") for (int jp = 0; jp < 2; ++jp)                                                                   \
-            acc[(S) * 4 + i][(T) * 2 + jp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                      \
-                BF[jp][kh], af[i][kh], ((ZERO) && kh == 0) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[(S) * 4 + i][(T) * 2 + jp], 0, 0, 0); \
+            acc[(S) * IM + i][(T) * 2 + jp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                     \
+                BF[jp][kh], af[i][kh], ((ZERO) && kh == 0) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[(S) * IM + i][(T) * 2 + jp], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                                     \
     } while (0)
 #define PP_KTILE(KIND, BUFIDX)                                                                                             \
@@ -352,7 +383,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                 bf0[jp][0] = *reinterpret_cast<const bf16x8_t*>(pb + jp * 2048 + swz0);                                    \
                 bf0[jp][1] = *reinterpret_cast<const bf16x8_t*>(pb + jp * 2048 + swz1);                                    \
             }                                                                                                              \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
+            _Pragma("unroll") for (int i = 0; i < IM; ++i) {                                                               \
                 af[i][0] = *reinterpret_cast<const bf16x8_t*>(pa + i * 2048 + swz0);                                       \
                 af[i][1] = *reinterpret_cast<const bf16x8_t*>(pa + i * 2048 + swz1);                                       \
             }                                                                                                              \
@@ -381,7 +412,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
         {                                                                                                                  \
             if (CHAIN && !BULK) pair_epilogue(1, prev);                                                                             \
             const unsigned char* pa = buf + 3 * PP_UNIT + a_base;                                                          \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
+            _Pragma("unroll") for (int i = 0; i < IM; ++i) {                                                               \
                 af[i][0] = *reinterpret_cast<const bf16x8_t*>(pa + i * 2048 + swz0);                                       \
                 af[i][1] = *reinterpret_cast<const bf16x8_t*>(pa + i * 2048 + swz1);                                       \
             }                                                                                                              \
@@ -405,7 +436,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
     bool have_next = false;
     for (int ts = 0; ts < my_tiles; ++ts) {
         have_next = ts + 1 < my_tiles;
-        nxt = pp_tile(first + (have_next ? ts + 1 : ts) * G, g.tiles_n);
+        nxt = pp_tile(first + (have_next ? ts + 1 : ts) * G, g.tiles_n, BM);
         // the second wave row runs one barrier behind the first inside a tile (ping-pong); the skew is applied per tile (and
         // undone by the first row at the tile's end) so that both rows cross the tile boundary together
         if (wr == 1) __builtin_amdgcn_s_barrier();
@@ -433,11 +464,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < IM; ++i)
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
                         xop[s][i][t] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, q_off(cur, true, s, i, t, false), 0, 0);
-            pp_wait_vmcnt<6 + 16>();                               // the bias DMA of LAST phase 1 (16 operand loads are younger)
+            pp_wait_vmcnt<6 + 4 * IM>();                               // the bias DMA of LAST phase 1 (16 operand loads are younger)
             pair_epilogue(0, cur);
             pair_epilogue(1, cur);
         }
@@ -475,9 +506,7 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
     if (e.res1 && (e.gate || e.dact || e.act || e.pre)) return 0;
     if (e.dact && (e.act || e.pre)) return 0;
     if (e.pre && !e.act) return 0;
-    g.tiles_m = (g.M + 255) / 256;
     g.tiles_n = (g.N + 255) / 256;
-    const int ntiles = g.tiles_m * g.tiles_n;
     static int ncu = 0;
     if (!ncu) {
         hipDeviceProp_t prop;
@@ -486,12 +515,26 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
         (void)hipGetDeviceProperties(&prop, dev);
         ncu = prop.multiProcessorCount > 0 ? (prop.multiProcessorCount / 8) * 8 : 256;
         // The persistent workgroups own their CU (144 KB LDS, 512 threads x 252 VGPRs): kernels of the text / weight-gradient
-        // streams can only run beside them on CUs the grid leaves free.  7/8 of the CUs measured best for the training step
-        // (93.3 -> 91.9 ms; flat down to 5/8).  EGV_PP_CUS overrides.
-        ncu = getenv("EGV_PP_CUS") ? (atoi(getenv("EGV_PP_CUS")) / 8) * 8 : (ncu * 7 / 8 / 8) * 8;
+        // streams can only run beside them on CUs the grid leaves free.  The grid is trimmed per call (below) to the smallest
+        // size that keeps the number of rounds; EGV_PP_CUS caps it (with untrimmed grids 7/8 of the CUs measured best).
+        if (getenv("EGV_PP_CUS")) ncu = (atoi(getenv("EGV_PP_CUS")) / 8) * 8;
         if (ncu < 8) ncu = 8;
     }
-    int grid = ncu;
+    // tile height: 192-row tiles where they shorten the walk (rounds x tile work, + 6 % for the smaller tile's lower operand
+    // reuse); only the plain and the residual epilogue kinds are built for them
+    static const bool allow192 = !getenv("EGV_PP_BM192") || atoi(getenv("EGV_PP_BM192")) != 0;
+    const bool kind192 = !e.dact && !e.pre && !e.act && !getenv("EGV_PP_STAMPS");
+    const int t256 = ((g.M + 255) / 256) * g.tiles_n, t192 = ((g.M + 191) / 192) * g.tiles_n;
+    const double c256 = (double)((t256 + ncu - 1) / ncu), c192 = (double)((t192 + ncu - 1) / ncu) * 0.75 * 1.06;
+    const bool use192 = allow192 && kind192 && t256 >= ncu && c192 < c256;
+    g.tiles_m = use192 ? (g.M + 191) / 192 : (g.M + 255) / 256;
+    const int ntiles = g.tiles_m * g.tiles_n;
+    // the smallest grid (multiple of 8: the XCD-aware walk) that keeps the number of rounds: the walk takes as long, and the CUs it
+    // does not take serve the companion streams
+    const int rounds = (ntiles + ncu - 1) / ncu;
+    static const bool trim = !getenv("EGV_PP_TRIM") || atoi(getenv("EGV_PP_TRIM")) != 0;
+    int grid = trim ? (((ntiles + rounds - 1) / rounds + 7) / 8) * 8 : ncu;
+    if (grid > ncu) grid = ncu;
     if (ntiles < grid) grid = ((ntiles + 7) / 8) * 8;
 #define PP_LAUNCH(X, P, AC)                                                                                              \
     do {                                                                                                                 \
@@ -505,6 +548,20 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
         return 1;                                                                                                        \
     } while (0)
     if (e.res1 && g.K < 1536) return 0;                           // short-K residual GEMMs (attention projections): the 2-workgroup ring kernel hides their epilogue better
+#define PP_LAUNCH192(X)                                                                                                  \
+    do {                                                                                                                 \
+        static bool attr = false;                                                                                        \
+        if (!attr) {                                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<X, false, false, false, 3>),          \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);                               \
+            attr = true;                                                                                                 \
+        }                                                                                                                \
+        hipLaunchKernelGGL((gemm_pp_kernel<X, false, false, false, 3>), dim3(grid), dim3(512), PP_LDS, st, g, ntiles);   \
+        return 1;                                                                                                        \
+    } while (0)
+    if (use192 && e.res1) PP_LAUNCH192(1);
+    if (use192) PP_LAUNCH192(0);
+#undef PP_LAUNCH192
     if (e.res1) PP_LAUNCH(1, false, false);
     if (e.dact) PP_LAUNCH(2, false, false);
     if (e.pre) PP_LAUNCH(0, true, true);

@@ -584,10 +584,10 @@ def test_patch_tokens_from_uint8_clips(ops, dtype):
 
 
 # ---- round 2: persistent ping-pong GEMM / block-level entry points -------------------------------------------------------------
-@pytest.mark.parametrize('N,K,kind', [(2304, 768, 'bias'), (3072, 768, 'gelu'), (768, 3072, 'res'), (768, 2304, 'plain')])
+@pytest.mark.parametrize('N,K,kind', [(2304, 768, 'bias'), (3072, 768, 'gelu'), (768, 3072, 'res'), (768, 2304, 'plain'), (768, 768, 'plain')])
 def test_persistent_gemm_bitwise_equals_ring_gemm(ops, N, K, kind):
-    """The kernel choice depends on the grid size (persistent ping-pong kernel from 64 tiles of 256x256 up, DMA-ring kernels
-    below): both accumulate in the same K order and add the bias after the sum, so the first rows of a full-size call must be
+    """The kernel choice depends on the grid size (persistent ping-pong kernel from 64 tiles of 256x256 up -- with 192-row tiles
+    for the N = 768 shapes at full M -- DMA-ring kernels below): all accumulate in the same K order and add the bias after the sum, so the first rows of a full-size call must be
     bit-identical to a call on those rows alone (what keeps FrozenInTime batch-composition independent in bf16)."""
     M, m = FULL_M, 1024
     x = _rnd((M, K), torch.bfloat16, 1.0, 11).cuda()
