@@ -547,7 +547,8 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
         hipLaunchKernelGGL((gemm_pp_kernel<X, P, AC>), dim3(grid), dim3(512), PP_LDS, st, g, ntiles);                    \
         return 1;                                                                                                        \
     } while (0)
-    if (e.res1 && g.K < 1536) return 0;                           // short-K residual GEMMs (attention projections): the 2-workgroup ring kernel hides their epilogue better
+    static const int res_min_k = getenv("EGV_PP_RES_MINK") ? atoi(getenv("EGV_PP_RES_MINK")) : 1536;
+    if (e.res1 && g.K < res_min_k && !(use192 && g.K >= res_min_k / 2)) return 0;   // short-K residual GEMMs on 256-row tiles: the 2-workgroup ring kernel hides their epilogue better
 #define PP_LAUNCH192(X)                                                                                                  \
     do {                                                                                                                 \
         static bool attr = false;                                                                                        \
