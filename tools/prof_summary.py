@@ -26,6 +26,18 @@ if 'stream_id' in cols:
             cur_e = max(cur_e, e0)
     busy += (cur_e - cur_s) if cur_e is not None else 0
     span = (max(e for _, e, _ in iv) - min(s0 for s0, _, _ in iv)) / 1e6
+    # idle gaps of the busiest stream (the critical path of a step): total and the largest ones with their neighbours
+    main = max(per_stream, key=per_stream.get)
+    ks = sorted(db.execute(f"select start, end, {namecol} from {view} where stream_id = ?", (main,)).fetchall())
+    gaps = [(ks[i + 1][0] - ks[i][1], ks[i][2], ks[i + 1][2]) for i in range(len(ks) - 1) if ks[i + 1][0] > ks[i][1]]
+    tot_gap = sum(g0 for g0, _, _ in gaps if g0 < 50e6)
+    big = sorted([g0 for g0 in gaps if g0[0] < 50e6], reverse=True)[:int(6 * steps)]
+    print(f"Stream {main}: idle between its kernels {tot_gap / 1e6 / steps:.1f} ms/step; gaps > 100 us: "
+          f"{sum(g0 for g0, _, _ in gaps if 100e3 < g0 < 50e6) / 1e6 / steps:.1f} ms/step, 20-100 us: {sum(g0 for g0, _, _ in gaps if 20e3 < g0 <= 100e3) / 1e6 / steps:.1f}, "
+          f"< 20 us: {sum(g0 for g0, _, _ in gaps if g0 <= 20e3) / 1e6 / steps:.1f}")
+    for g0, a, b in big[:12]:
+        print(f"   gap {g0 / 1e3:8.1f} us after `{re.sub(r'[(<].*$', '', a)[:50]}` before `{re.sub(r'[(<].*$', '', b)[:50]}`")
+    print()
     print(f"Kernel-interval union (GPU busy) {busy / 1e6 / steps:.1f} ms/step of a {span / steps:.1f} ms/step trace span; per stream (ms/step): "
           + ", ".join(f"stream {k}: {v / steps:.1f}" for k, v in sorted(per_stream.items(), key=lambda kv: -kv[1])[:4]) + "\n")
 agg = collections.defaultdict(list)
