@@ -781,7 +781,7 @@ extern "C" int egv_attn_bwd_dkv(int dtype, const egv_attn_desc* d, void* stream)
 
 // dQ, dK, dV and delta of one grouped launch in a single kernel (bf16, other side <= 224 rows, no mask / dropout / split).
 // Returns 0 if enqueued, 1 if the shape is not covered (nothing enqueued: use egv_attn_bwd_dq + egv_attn_bwd_dkv), -1 on error.
-// The extra CLS query's delta must already be in d->delta (one-query egv_attn_bwd_dq first).
+// Independent of the one-query (CLS) launches: it computes every delta it needs and stores those of the row-set queries.
 extern "C" int egv_attn_bwd_fused(int dtype, const egv_attn_desc* d, void* stream) {
     if (check_desc(d, "egv_attn_bwd_fused")) return -1;
     EGV_CHECK(d->lse && d->delta && d->dO && d->dQ && d->dK && d->dV, "egv_attn_bwd_fused: missing lse/delta/dO/dQ/dK/dV");

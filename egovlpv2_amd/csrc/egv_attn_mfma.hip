@@ -553,8 +553,8 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_mfma_kernel(const AttnArgs a
 // dQ is summed over the waves in an fp32 LDS accumulator [query pair][32][64] WITHOUT atomics: in step s wave w works on query
 // pair (s + w) mod 8, so no two waves touch the same pair in a step, a barrier separates the steps, and the order in which the
 // waves add into a pair is fixed -- the result does not depend on scheduling.  One bf16 store pass at the end.
-// delta = rowsum(dO o O) of the row-set queries is computed while staging (and stored for the CLS-key launch that follows);
-// the CLS query's delta comes from the one-query launch before.
+// delta = rowsum(dO o O) of every query is computed while staging; the row-set queries' values are stored for the CLS-key launch
+// that follows (the CLS query's own delta is stored by the one-query launch, which may run beside this kernel).
 // Against the dQ + dK/dV kernel pair: one staging of Q / dO instead of two stagings of two operands each, 10 instead of 14
 // MFMAs and one exp instead of two per 16 x 16 score tile.
 // ------------------------------------------------------------------------------------------------
@@ -614,18 +614,14 @@ __global__ __launch_bounds__(64 * FNW) void attn_bwd_fused_kernel(const AttnArgs
         if (i < ntot) {
             const long long row = other_row(a, a.q, b, g, i);
             l = a.lse[row * a.H + h] * LOG2E;
-            if (a.extra && i == 0) {
-                d = a.delta[row * a.H + h];
-            } else {
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const bf16x8_t x = *reinterpret_cast<const bf16x8_t*>(dO + row * a.ldo + ho + c * 8);
-                    const bf16x8_t y = *reinterpret_cast<const bf16x8_t*>(O + row * a.ldo + ho + c * 8);
+            for (int c = 0; c < 8; ++c) {
+                const bf16x8_t x = *reinterpret_cast<const bf16x8_t*>(dO + row * a.ldo + ho + c * 8);
+                const bf16x8_t y = *reinterpret_cast<const bf16x8_t*>(O + row * a.ldo + ho + c * 8);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) d += (float)x[e] * (float)y[e];
-                }
-                a.delta[row * a.H + h] = d;
+                for (int e = 0; e < 8; ++e) d += (float)x[e] * (float)y[e];
             }
+            if (!(a.extra && i == 0)) a.delta[row * a.H + h] = d;     // the CLS query's delta is stored by its own (one-query) launch
         }
         sL[i] = l;
         sD[i] = d;

@@ -129,8 +129,8 @@ int egv_attn_bwd_dq(int dtype, const egv_attn_desc* d, void* stream);
 long long egv_attn_bwd_dkv_workspace_bytes(int B, int G, int H, int k_n, int nsplit);
 int egv_attn_bwd_dkv(int dtype, const egv_attn_desc* d, void* stream);
 /* dQ + dK/dV + delta of one grouped launch in a single kernel (bf16 divided video attention: no mask, dropout or split).
- * 0 = enqueued, 1 = shape not covered (nothing enqueued; call the two functions above), -1 = error.  With an extra CLS row the
- * one-query egv_attn_bwd_dq launch must run first (it provides the CLS query's delta). */
+ * 0 = enqueued, 1 = shape not covered (nothing enqueued; call the two functions above), -1 = error.  It stores delta of the
+ * row-set queries only and does not read d->delta: the one-query (CLS) launches can run beside it on another stream. */
 int egv_attn_bwd_fused(int dtype, const egv_attn_desc* d, void* stream);
 
 /* ---- patch embedding pre/post (video_transformer.py:78-83,356-371; model.py:212-231,296-317) ---- */
