@@ -782,12 +782,18 @@ extern "C" int egv_attn_bwd_dkv(int dtype, const egv_attn_desc* d, void* stream)
 // dQ, dK, dV and delta of one grouped launch in a single kernel (bf16, other side <= 224 rows, no mask / dropout / split).
 // Returns 0 if enqueued, 1 if the shape is not covered (nothing enqueued: use egv_attn_bwd_dq + egv_attn_bwd_dkv), -1 on error.
 // Independent of the one-query (CLS) launches: it computes every delta it needs and stores those of the row-set queries.
+// With a workspace (d->ws, egv_attn_bwd_fused_workspace_bytes) and an extra row it ALSO produces that row's dQ, dK and dV (per-
+// group partials summed by a second small launch), i.e. it then replaces the two one-row launches as well.
+extern "C" long long egv_attn_bwd_fused_workspace_bytes(int B, int G, int H) { return (long long)B * G * H * 3 * HD * 4; }
 extern "C" int egv_attn_bwd_fused(int dtype, const egv_attn_desc* d, void* stream) {
     if (check_desc(d, "egv_attn_bwd_fused")) return -1;
     EGV_CHECK(d->lse && d->delta && d->dO && d->dQ && d->dK && d->dV, "egv_attn_bwd_fused: missing lse/delta/dO/dQ/dK/dV");
     if (dtype != EGV_BF16) return 1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     AttnArgs a = to_args(d);
+    a.nsplit = 1;
+    if (d->ws && d->extra)
+        EGV_CHECK(d->ws_bytes >= egv_attn_bwd_fused_workspace_bytes(d->B, d->G, d->H), "egv_attn_bwd_fused: workspace too small");
     if (!egv_attn_bwd_fused_mfma(a, d->B, st)) return 1;
     EGV_LAUNCH_CHECK();
     return 0;

@@ -606,6 +606,7 @@ __global__ __launch_bounds__(64 * FNW) void attn_bwd_fused_kernel(const AttnArgs
     const int hq = a.qoff + h * HD, hk = a.koff + h * HD, hv = a.voff + h * HD, ho = a.ooff + h * HD;
     const int hdq = a.dqoff + h * HD, hdk = a.dkoff + h * HD, hdv = a.dvoff + h * HD;
     const int ntot = a.q.n + a.extra;               // queries incl. the extra CLS query (row 0)
+    const bool cls_out = a.ws != nullptr && a.extra;     // also produce the extra row's gradients (as per-group partials)
 
     stage_rows_t<NT, NTHR>(sQt, Q, a.ldq, hq, a, a.q, b, g, ntot, tid);
     stage_rows_t<NT, NTHR>(sGt, dO, a.ldo, ho, a, a.q, b, g, ntot, tid);
@@ -702,6 +703,10 @@ __global__ __launch_bounds__(64 * FNW) void attn_bwd_fused_kernel(const AttnArgs
                             for (int r = 0; r < 4; ++r) { acc[r] = kval[o] ? acc[r] : 0.f; dp[r] = kval[o] ? dp[r] : 0.f; }
                         }
                     }
+                    if (cls_out && g != 0 && kk == 0 && u == 0 && (w + o * NW == nkt) && lane == 0) {
+                        acc[0] = 0.f;                      // (CLS query, CLS key) belongs to every group: counted in group 0 only
+                        dp[0] = 0.f;
+                    }
                     pr[u][o] = acc;
                     dr[u][o] = dp;
                     // dS^T scratch: [key o*16 + fr][queries fg*4 .. +3]
@@ -742,6 +747,25 @@ __global__ __launch_bounds__(64 * FNW) void attn_bwd_fused_kernel(const AttnArgs
         lds_barrier();
     }
 
+    // the extra (CLS) row's share of this group: dQ of the CLS query over this group's keys, dK / dV of the CLS key under this
+    // group's queries -> fp32 partials [problem][head][3][64], summed over the groups by attn_cls_reduce_kernel
+    if (cls_out) {
+        float* pw = a.ws + ((long long)p * a.H + h) * 3 * HD;
+        if (tid < 16) {
+            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(sAcc + (tid * 4) * 4);
+            *reinterpret_cast<f32x4_t*>(pw + tid * 4) = v * a.scale;
+        }
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            if (w + o * NW == nkt && fr == 0) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    *reinterpret_cast<f32x4_t*>(pw + HD + dt * 16 + fg * 4) = ok[o][dt] * a.scale;
+                    *reinterpret_cast<f32x4_t*>(pw + 2 * HD + dt * 16 + fg * 4) = ov[o][dt];
+                }
+            }
+        }
+    }
     // dQ: accumulators -> bf16 rows (16 threads per query, 4 head dims each)
     for (int e = tid; e < npair * 32 * 16; e += NTHR) {
         const int i = e >> 4, d4 = (e & 15) * 4;
@@ -763,6 +787,21 @@ __global__ __launch_bounds__(64 * FNW) void attn_bwd_fused_kernel(const AttnArgs
             }
         }
     }
+}
+
+// dQ / dK / dV of the extra (CLS) row = sum over the G groups of attn_bwd_fused_kernel's partials, in group order
+__global__ __launch_bounds__(64) void attn_cls_reduce_kernel(const AttnArgs a) {
+    const int b = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
+    float s[3] = {0.f, 0.f, 0.f};
+    for (int g = 0; g < a.G; ++g) {
+        const float* pw = a.ws + (((long long)b * a.G + g) * a.H + h) * 3 * HD;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s[k] += pw[k * HD + d];
+    }
+    const long long row = (long long)b * a.extra_bs + a.extra_row;
+    reinterpret_cast<bf16_t*>(a.dQ)[row * a.lddq + a.dqoff + h * HD + d].v = f2bf(s[0]);
+    reinterpret_cast<bf16_t*>(a.dK)[row * a.lddk + a.dkoff + h * HD + d].v = f2bf(s[1]);
+    reinterpret_cast<bf16_t*>(a.dV)[row * a.lddv + a.dvoff + h * HD + d].v = f2bf(s[2]);
 }
 
 template <int NT> constexpr size_t fused_lds() {
@@ -860,8 +899,10 @@ int egv_attn_bwd_fused_mfma(const AttnArgs& a, int B, hipStream_t st) {
     const int own = (a.k.n + 15) / 16 + a.extra;
     if (!aligned_ok(a) || (a.lddq % 4) || (a.dqoff % 4) || (a.lddk % 4) || (a.lddv % 4) || (a.dkoff % 4) || (a.dvoff % 4)) return 0;
     if (a.mask || a.drop_p > 0.f || a.nsplit > 1 || ntot > 224 || ntot <= 64 || own > 2 * FNW || !a.delta || !a.lse) return 0;
+    if (a.ws && a.extra && a.extra_row != 0) return 0;            // partials of the extra row: written for the CLS-first layout only
     constexpr size_t lds = fused_lds<14>();
     set_lds(attn_bwd_fused_kernel<14>, lds);
     hipLaunchKernelGGL((attn_bwd_fused_kernel<14>), dim3(1, B * a.G, a.H), dim3(64 * FNW), lds, st, a);
+    if (a.ws && a.extra) hipLaunchKernelGGL(attn_cls_reduce_kernel, dim3(B, a.H), dim3(64), 0, st, a);
     return 1;
 }

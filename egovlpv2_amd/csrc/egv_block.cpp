@@ -138,6 +138,8 @@ struct Divided {
         long long a = egv_attn_split_workspace_bytes(0, B, 1, H, 1, ns), b = egv_attn_split_workspace_bytes(1, B, 1, H, 1, ns),
                   c = egv_attn_bwd_dkv_workspace_bytes(B, 1, H, 1, ns);
         long long m = a > b ? a : b;
+        const long long f = egv_attn_bwd_fused_workspace_bytes(B, space ? Fr : N, H);
+        if (f > m) m = f;
         return m > c ? m : c;
     }
     int fwd(const void* qkv, void* O, float* lse, void* ws, long long wsb, void* st) const {
@@ -162,17 +164,24 @@ struct Divided {
         };
         egv_attn_desc d;
         const int ns = nsplit_for(S);
-        fill(d, qkv, const_cast<void*>(O), lse); grads(d);  // CLS query over all S keys (also its delta, which the group launch reads)
+        // groups: dQ, dK, dV in one pass where the shape allows it (bf16 space attention); with the workspace that kernel also
+        // produces the CLS row's gradients (per-group partials + one small sum) and nothing else is launched
+        static const bool fused = !getenv("EGV_ATTN_FUSED_BWD") || atoi(getenv("EGV_ATTN_FUSED_BWD")) != 0;
+        static const bool fused_cls = !getenv("EGV_ATTN_FUSED_CLS") || atoi(getenv("EGV_ATTN_FUSED_CLS")) != 0;
+        fill(d, qkv, const_cast<void*>(O), lse); grads(d); groups(d);
+        if (fused_cls && wsb >= egv_attn_bwd_fused_workspace_bytes(B, d.G, H)) { d.ws = (float*)ws; d.ws_bytes = wsb; }
+        int fr = fused ? egv_attn_bwd_fused(dt, &d, st) : 1;
+        if (fr < 0) return fr;
+        if (fr == 0 && d.ws) return 0;
+        const bool groups_done = fr == 0;
+        fill(d, qkv, const_cast<void*>(O), lse); grads(d);  // CLS query over all S keys (also its delta, which the key-owned group launch reads)
         d.G = 1;
         rowset(d.q_bs, d.q_base, d.q_gs, d.q_is, d.q_n, S, 0, 0, 1, 1);
         rowset(d.k_bs, d.k_base, d.k_gs, d.k_is, d.k_n, S, 0, 0, 1, S);
         d.nsplit = ns; d.ws = (float*)ws; d.ws_bytes = wsb;
         BCHK(egv_attn_bwd_dq(dt, &d, st));
-        fill(d, qkv, const_cast<void*>(O), lse); grads(d); groups(d);
-        static const bool fused = !getenv("EGV_ATTN_FUSED_BWD") || atoi(getenv("EGV_ATTN_FUSED_BWD")) != 0;
-        const int fr = fused ? egv_attn_bwd_fused(dt, &d, st) : 1;
-        if (fr < 0) return fr;
-        if (fr == 1) {
+        if (!groups_done) {
+            fill(d, qkv, const_cast<void*>(O), lse); grads(d); groups(d);
             BCHK(egv_attn_bwd_dq(dt, &d, st));
             BCHK(egv_attn_bwd_dkv(dt, &d, st));
         }

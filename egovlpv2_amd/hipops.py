@@ -578,6 +578,7 @@ def _nsplit_for(n_other):
 
 
 FUSED_ATTN_BWD = os.environ.get('EGV_ATTN_FUSED_BWD', '1') != '0'
+FUSED_ATTN_CLS = os.environ.get('EGV_ATTN_FUSED_CLS', '1') != '0'     # the one-pass kernel also produces the CLS row's gradients
 
 
 class DividedAttnFn(Function):
@@ -631,19 +632,26 @@ class DividedAttnFn(Function):
         cls1, allS = _rowset(S, 0, 0, 1, 1), _rowset(S, 0, 0, 1, S)
         dt = _dt(qkv)
         kw = dict(dO=dO, dQ=dQ, dK=dK, dV=dV, delta=delta)
+        # groups: dQ, dK, dV (and delta) in one kernel where the shape allows it (bf16 space attention); given a workspace it also
+        # produces the CLS row's three gradients, and nothing else is launched
+        rc = 1
+        if FUSED_ATTN_BWD:
+            nbf = lib.egv_attn_bwd_fused_workspace_bytes(B, G, H)
+            wsf = torch.empty(nbf // 4, dtype=torch.float32, device=qkv.device) if FUSED_ATTN_CLS else None
+            d1 = _mk_desc(Q, K, V, O, lse, B, G, H, gset, gset, (S, 0), scale, ws=wsf, ws_bytes=nbf if wsf is not None else 0, **kw)
+            rc = lib.egv_attn_bwd_fused(dt, C.byref(d1), _st())
+            if rc not in (0, 1):
+                check(rc, 'egv_attn_bwd_fused(groups)')
+            if rc == 0 and wsf is not None:
+                return dqkv, None, None, None, None, None
         ns = _nsplit_for(S)
         ws, nb = _split_ws(1, B, 1, H, 1, ns, qkv.device)
         d2 = _mk_desc(Q, K, V, O, lse, B, 1, H, cls1, allS, None, scale, nsplit=ns, ws=ws, ws_bytes=nb, **kw)
         check(lib.egv_attn_bwd_dq(dt, C.byref(d2), _st()), 'egv_attn_bwd_dq(cls)')
-        # groups: dQ, dK, dV (and delta) in one kernel where the shape allows it (bf16; the CLS query's delta is in place);
-        # otherwise query-owned dQ, then key-owned group keys <- [CLS query ; group queries]
-        d1 = _mk_desc(Q, K, V, O, lse, B, G, H, gset, gset, (S, 0), scale, **kw)
-        rc = lib.egv_attn_bwd_fused(dt, C.byref(d1), _st()) if FUSED_ATTN_BWD else 1
-        if rc == 1:
+        if rc == 1:                                  # query-owned dQ, then key-owned group keys <- [CLS query ; group queries]
+            d1 = _mk_desc(Q, K, V, O, lse, B, G, H, gset, gset, (S, 0), scale, **kw)
             check(lib.egv_attn_bwd_dq(dt, C.byref(d1), _st()), 'egv_attn_bwd_dq(groups)')
             check(lib.egv_attn_bwd_dkv(dt, C.byref(d1), _st()), 'egv_attn_bwd_dkv(groups)')
-        else:
-            check(rc, 'egv_attn_bwd_fused(groups)')
         # CLS key <- all S queries (split + reduce)
         nsplit = _nsplit_for(S)
         ws, nb = _dkv_ws(B, 1, H, 1, nsplit, qkv.device)

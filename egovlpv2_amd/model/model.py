@@ -190,7 +190,7 @@ class FrozenInTime(nn.Module):
         queued on the calling stream so far.  `uses`: tensors allocated on the calling stream that fn reads -- they are
         recorded on the side stream, otherwise the caching allocator may recycle them while side-stream kernels (forward
         or backward) are still queued.  Returns (out, join); join() orders the calling stream after fn's work only."""
-        if not self._overlap():
+        if not self._overlap() or os.environ.get('EGV_TEXT_STREAM', '1') == '0':
             return fn(), (lambda: None)
         main = torch.cuda.current_stream()
         if getattr(self, '_side', None) is None or self._side.device != main.device:

@@ -130,7 +130,10 @@ long long egv_attn_bwd_dkv_workspace_bytes(int B, int G, int H, int k_n, int nsp
 int egv_attn_bwd_dkv(int dtype, const egv_attn_desc* d, void* stream);
 /* dQ + dK/dV + delta of one grouped launch in a single kernel (bf16 divided video attention: no mask, dropout or split).
  * 0 = enqueued, 1 = shape not covered (nothing enqueued; call the two functions above), -1 = error.  It stores delta of the
- * row-set queries only and does not read d->delta: the one-query (CLS) launches can run beside it on another stream. */
+ * row-set queries only and does not read d->delta.  With d->ws (>= egv_attn_bwd_fused_workspace_bytes) and an extra row at
+ * extra_row == 0 it also writes that row's dQ / dK / dV (sum of per-group partials in group order: deterministic), replacing
+ * the one-query egv_attn_bwd_dq and the one-key egv_attn_bwd_dkv launches of the CLS row. */
+long long egv_attn_bwd_fused_workspace_bytes(int B, int G, int H);
 int egv_attn_bwd_fused(int dtype, const egv_attn_desc* d, void* stream);
 
 /* ---- patch embedding pre/post (video_transformer.py:78-83,356-371; model.py:212-231,296-317) ---- */

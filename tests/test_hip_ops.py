@@ -522,23 +522,31 @@ def test_full_size_divided_attention_sampled_problems_bf16(ops):
 
 def test_fused_attention_backward_matches_kernel_pair(ops):
     """dQ / dK / dV of the space attention from the one-pass kernel (attn_bwd_fused_kernel) against the dQ + dK/dV kernel pair on
-    the same bf16 inputs (same bf16 roundings of P and dS, different summation order), and run-to-run bitwise reproducibility
-    (the cross-wave dQ sum has a fixed order, no atomics)."""
+    the same bf16 inputs (same bf16 roundings of P and dS, different summation order), run-to-run bitwise reproducibility (the
+    cross-wave dQ sum has a fixed order, no atomics), and the CLS row's gradients from the kernel's per-group partials against the
+    one-query / one-key launches."""
     for (B, Fr, N, H) in [(2, 3, 70, 3), (1, 2, 196, 2), (2, 2, 223, 1), (1, 1, 65, 1)]:
         S = 1 + Fr * N
         qkv = _rnd((B * S, 3 * H * 64), torch.bfloat16, 1.0, 11).cuda().requires_grad_(True)
         do = _rnd((B * S, H * 64), torch.bfloat16, 1.0, 12).cuda()
         grads = {}
         try:
-            for fused in (False, True, True):
-                ops.FUSED_ATTN_BWD = fused
+            for fused, cls in ((False, False), (True, True), (True, True), (True, False)):
+                ops.FUSED_ATTN_BWD, ops.FUSED_ATTN_CLS = fused, cls
                 o = ops.divided_attention(qkv, B, Fr, N, H, 'space')
                 g, = torch.autograd.grad(o, qkv, do)
-                grads.setdefault(fused, []).append(g)
+                grads.setdefault((fused, cls), []).append(g)
         finally:
-            ops.FUSED_ATTN_BWD = True
-        assert torch.equal(grads[True][0], grads[True][1]), (B, Fr, N, H)
-        assert _rel(grads[True][0], grads[False][0].double().cpu()) < 4e-3, (B, Fr, N, H)
+            ops.FUSED_ATTN_BWD = ops.FUSED_ATTN_CLS = True
+        assert torch.equal(grads[(True, True)][0], grads[(True, True)][1]), (B, Fr, N, H)
+        ref = grads[(False, False)][0].double().cpu()
+        assert _rel(grads[(True, True)][0], ref) < 4e-3, (B, Fr, N, H)
+        assert _rel(grads[(True, False)][0], ref) < 4e-3, (B, Fr, N, H)
+        # the CLS row (first row of every sample): its dQ / dK / dV come from the per-group partials of the one-pass kernel
+        cls_rows = torch.arange(B) * S
+        assert _rel(grads[(True, True)][0][cls_rows.cuda()], ref[cls_rows]) < 4e-3, (B, Fr, N, H)
+        patch = torch.ones(B * S, dtype=torch.bool); patch[cls_rows] = False
+        assert torch.equal(grads[(True, True)][0][patch.cuda()], grads[(True, False)][0][patch.cuda()]), "patch rows do not depend on who writes the CLS row"
 
 
 def test_prepare_weights_matches_per_tensor_casts(ops):

@@ -39,7 +39,7 @@ def main():
             dO = torch.randn(B * S, H * 64, device=dev).bfloat16()
             res = {}
             for fused in (False, True):
-                ops.FUSED_ATTN_BWD = fused
+                ops.FUSED_ATTN_BWD = ops.FUSED_ATTN_CLS = fused
                 out = ops.divided_attention(qkv, B, Fr, N, H, mode)
                 g, = torch.autograd.grad(out, qkv, dO)
                 res[fused] = g.float()
