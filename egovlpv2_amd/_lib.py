@@ -93,6 +93,8 @@ PROTOTYPES = {
     'egv_stream_create': (i32, [i32, C.POINTER(vp)]),
     'egv_attn_split_workspace_bytes': (i64, [i32, i32, i32, i32, i32, i32]),
     'egv_attn_fwd': (i32, [i32, C.POINTER(AttnDesc), vp]),
+    'egv_attn_fwd_extra_workspace_bytes': (i64, [i32, i32, i32]),
+    'egv_attn_fwd_covers_extra': (i32, [i32, C.POINTER(AttnDesc)]),
     'egv_attn_bwd_dq': (i32, [i32, C.POINTER(AttnDesc), vp]),
     'egv_attn_bwd_dkv_workspace_bytes': (i64, [i32, i32, i32, i32, i32]),
     'egv_attn_bwd_dkv': (i32, [i32, C.POINTER(AttnDesc), vp]),

@@ -83,7 +83,8 @@ static inline egv::AttnArgs to_args(const egv_attn_desc* d) {
 
 
 // MFMA launchers (egv_attn_mfma.hip): return 1 if the problem shape is covered (and the kernel was enqueued), else 0.
-int egv_attn_fwd_mfma(const egv::AttnArgs& a, int B, hipStream_t st);
+int egv_attn_fwd_mfma(const egv::AttnArgs& a, int B, hipStream_t st);     // 2: the extra row's partial states were written too
+bool egv_attn_fwd_cls_ok(const egv::AttnArgs& a);
 int egv_attn_dq_mfma(const egv::AttnArgs& a, int B, hipStream_t st);
 int egv_attn_dkv_mfma(const egv::AttnArgs& a, int B, hipStream_t st);
 int egv_attn_bwd_fused_mfma(const egv::AttnArgs& a, int B, hipStream_t st);

@@ -668,13 +668,36 @@ extern "C" long long egv_attn_split_workspace_bytes(int which, int B, int G, int
     return (long long)nsplit * B * G * n_own * H * per * 4;
 }
 
+// egv_attn_fwd with nsplit <= 1, an extra row and a workspace of this size also computes the extra row AS A QUERY over the
+// union of the groups' keys (the CLS query of the divided attention) when egv_attn_fwd_covers_extra says so
+extern "C" long long egv_attn_fwd_extra_workspace_bytes(int B, int G, int H) { return (long long)B * G * H * 66 * 4; }
+extern "C" int egv_attn_fwd_covers_extra(int dtype, const egv_attn_desc* d) {
+    if (dtype != EGV_BF16 || !d || !d->ws) return 0;
+    AttnArgs a = to_args(d);
+    return egv_attn_fwd_cls_ok(a) ? 1 : 0;
+}
+
 extern "C" int egv_attn_fwd(int dtype, const egv_attn_desc* d, void* stream) {
     if (check_desc(d, "egv_attn_fwd")) return -1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     AttnArgs a = to_args(d);
-    if (dtype == EGV_BF16 && a.nsplit == 1 && egv_attn_fwd_mfma(a, d->B, st)) {
-        EGV_LAUNCH_CHECK();
-        return 0;
+    if (dtype == EGV_BF16 && a.nsplit == 1) {
+        if (d->ws && egv_attn_fwd_cls_ok(a))
+            EGV_CHECK(d->ws_bytes >= egv_attn_fwd_extra_workspace_bytes(d->B, d->G, d->H), "egv_attn_fwd: workspace too small for the extra row's partial states");
+        const int r = egv_attn_fwd_mfma(a, d->B, st);
+        if (r) {
+            EGV_LAUNCH_CHECK();
+            if (r == 2) {                        // the extra row as a query: combine its G partial states (one per group)
+                AttnArgs c = a;
+                c.q = RowSet{a.extra_bs, a.extra_row, 0, 1, 1};
+                c.nsplit = a.G;
+                c.G = 1;
+                const long long n = (long long)d->B * d->H;
+                hipLaunchKernelGGL(attn_fwd_combine_kernel<bf16_t>, dim3((int)((n + 3) / 4)), dim3(256), 0, st, c, d->B);
+                EGV_LAUNCH_CHECK();
+            }
+            return 0;
+        }
     }
     if (a.nsplit > 1)
         EGV_CHECK(d->ws && d->ws_bytes >= egv_attn_split_workspace_bytes(0, d->B, d->G, d->H, d->q_n, a.nsplit),

@@ -171,12 +171,17 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnArgs a
     __syncthreads();
 
     const int nqt = (a.q.n + 15) >> 4;
+    // cls_out (unsplit launch with an extra row and a workspace): the extra row is also a QUERY of this group -- the CLS query of
+    // the divided attention sees all S keys = the union of the groups' keys -- handled as one more own tile whose one live row
+    // leaves a partial softmax state (max, sum, 64 outputs) per group for attn_fwd_combine_kernel; the CLS KEY counts in group 0
+    const bool cls_out = !MASK && a.nsplit == 1 && a.ws != nullptr && a.extra;
     const int t0 = (blockIdx.x / a.nsplit) * tiles_per_wg;
-    const int t1 = min(nqt, t0 + tiles_per_wg);
+    const int t1 = min(nqt + (cls_out ? 1 : 0), t0 + tiles_per_wg);
     for (int qt = t0 + w; qt < t1; qt += NW) {
+        const bool is_cls = qt == nqt;                                          // uniform
         const int q = qt * 16 + fr;
-        const bool qv = q < a.q.n;
-        const long long qrow = qv ? rs_row(a.q, b, g, q) : 0;
+        const bool qv = is_cls ? fr == 0 : q < a.q.n;
+        const long long qrow = is_cls ? ((long long)b * a.extra_bs + a.extra_row) : (qv ? rs_row(a.q, b, g, q) : 0);
         const bf16x8_t q0 = ld_frag_global(Q + qrow * a.ldq + hq + fg * 8, qv);
         const bf16x8_t q1 = ld_frag_global(Q + qrow * a.ldq + hq + 32 + fg * 8, qv);
         f32x4_t s[NT];
@@ -193,6 +198,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnArgs a
                 s[t] = acc;
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (is_cls && g != 0 && fg == 0) s[0][0] = -INFINITY;              // the CLS key (key 0) is counted in group 0
             // pass B: row maximum of the raw scores (the scale is positive, so it commutes with max)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -284,7 +290,14 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnArgs a
             }
             EGV_KK_BARRIER
         }
-        if (qv && a.nsplit > 1) {
+        if (is_cls) {
+            if (qv) {                                                          // ws[group][b][head][66]: the layout of a G-way split, one query per sample
+                float* dst = a.ws + (((long long)g * (gridDim.y / a.G) + b) * a.H + h) * 66;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4_t*>(dst + 2 + dt * 16 + fg * 4) = o[dt];
+                if (fg == 0) { dst[0] = m * LN2; dst[1] = l; }
+            }
+        } else if (qv && a.nsplit > 1) {
             const long long nrows = (long long)gridDim.y * a.q.n;
             const long long orow = (long long)p * a.q.n + q;
             float* dst = a.ws + (((long long)split * nrows + orow) * a.H + h) * 66;
@@ -848,7 +861,19 @@ static inline void own_split(int n_own, int& nw, int& tpw, int& chunks) {
         }                                                                                                    \
     } while (0)
 
-int egv_attn_fwd_mfma(const AttnArgs& a, int B, hipStream_t st) {
+// the unsplit launch also treats the extra row as a QUERY of every group (partial softmax states in a.ws, one per group): the
+// groups must partition the keys the extra query sees (divided attention: query row set == key row set), long key side only
+bool egv_attn_fwd_cls_ok(const AttnArgs& a) {
+    const int nall = a.k.n + a.extra;
+    const bool same = a.q.bs == a.k.bs && a.q.base == a.k.base && a.q.gs == a.k.gs && a.q.is == a.k.is && a.q.n == a.k.n;
+    return aligned_ok(a) && a.nsplit == 1 && a.ws && a.extra && a.extra_row == 0 && !a.mask && a.drop_p <= 0.f && same && nall > 64 &&
+           nall <= 224 && (a.q.n + 15) / 16 <= 15;
+}
+
+int egv_attn_fwd_mfma(const AttnArgs& ain, int B, hipStream_t st) {
+    AttnArgs a = ain;
+    const bool cls = egv_attn_fwd_cls_ok(a);
+    if (!cls && a.nsplit == 1) a.ws = nullptr;                     // the kernel keys the extra-query path on ws
     const int nall = a.k.n + a.extra;
     const int ntot = a.nsplit > 1 ? ((((nall + a.nsplit - 1) / a.nsplit) + 15) & ~15) : nall;
     if (!aligned_ok(a) || ntot > 224) return 0;
@@ -858,9 +883,9 @@ int egv_attn_fwd_mfma(const AttnArgs& a, int B, hipStream_t st) {
     chunks *= a.nsplit;
     if (ntot <= 32) EGV_MFMA_LAUNCH(attn_fwd_mfma_kernel, fwd_lds, 2, 0);
     else if (ntot <= 64) EGV_MFMA_LAUNCH(attn_fwd_mfma_kernel, fwd_lds, 4, 0);
-    else if (ntot > 192 && ntot <= 208 && a.nsplit == 1) EGV_MFMA_LAUNCH(attn_fwd_mfma_kernel, fwd_lds, 14, 13);     // 196 patches + CLS: 13 live tiles known at compile time (-20 % on the forward; measured slower on the two backward kernels)
-    else EGV_MFMA_LAUNCH(attn_fwd_mfma_kernel, fwd_lds, 14, 0);
-    return 1;
+    else if (ntot > 192 && ntot <= 208 && a.nsplit == 1) { if (cls) ++tpw; EGV_MFMA_LAUNCH(attn_fwd_mfma_kernel, fwd_lds, 14, 13); }     // 196 patches + CLS: 13 live tiles known at compile time (-20 % on the forward; measured slower on the two backward kernels)
+    else { if (cls) ++tpw; EGV_MFMA_LAUNCH(attn_fwd_mfma_kernel, fwd_lds, 14, 0); }
+    return cls ? 2 : 1;
 }
 
 int egv_attn_dq_mfma(const AttnArgs& a, int B, hipStream_t st) {

@@ -138,15 +138,21 @@ struct Divided {
         long long a = egv_attn_split_workspace_bytes(0, B, 1, H, 1, ns), b = egv_attn_split_workspace_bytes(1, B, 1, H, 1, ns),
                   c = egv_attn_bwd_dkv_workspace_bytes(B, 1, H, 1, ns);
         long long m = a > b ? a : b;
-        const long long f = egv_attn_bwd_fused_workspace_bytes(B, space ? Fr : N, H);
+        const long long f = egv_attn_bwd_fused_workspace_bytes(B, space ? Fr : N, H), f2 = egv_attn_fwd_extra_workspace_bytes(B, space ? Fr : N, H);
         if (f > m) m = f;
+        if (f2 > m) m = f2;
         return m > c ? m : c;
     }
     int fwd(const void* qkv, void* O, float* lse, void* ws, long long wsb, void* st) const {
         egv_attn_desc d;
         fill(d, qkv, O, lse);
         groups(d);
+        static const bool fused_cls = !getenv("EGV_ATTN_FUSED_CLS") || atoi(getenv("EGV_ATTN_FUSED_CLS")) != 0;
+        if (fused_cls && wsb >= egv_attn_fwd_extra_workspace_bytes(B, d.G, H)) { d.ws = (float*)ws; d.ws_bytes = wsb; }
+        const bool covers = d.ws && egv_attn_fwd_covers_extra(dt, &d);
+        if (!covers) { d.ws = nullptr; d.ws_bytes = 0; }
         BCHK(egv_attn_fwd(dt, &d, st));
+        if (covers) return 0;                    // the group launch handled the CLS query too
         fill(d, qkv, O, lse);                    // CLS query over all S keys
         d.G = 1;
         rowset(d.q_bs, d.q_base, d.q_gs, d.q_is, d.q_n, S, 0, 0, 1, 1);

@@ -602,7 +602,19 @@ class DividedAttnFn(Function):
             G, gset = N, _rowset(S, 1, 1, N, Fr)
         dt = _dt(qkv)
         d1 = _mk_desc(Q, K, V, O, lse, B, G, H, gset, gset, (S, 0), scale)
+        covers = False
+        if FUSED_ATTN_CLS:                       # the group launch can also serve the CLS query (per-group partial softmax states)
+            nbx = lib.egv_attn_fwd_extra_workspace_bytes(B, G, H)
+            wsx = torch.empty(nbx // 4, dtype=torch.float32, device=qkv.device)
+            dx = _mk_desc(Q, K, V, O, lse, B, G, H, gset, gset, (S, 0), scale, ws=wsx, ws_bytes=nbx)
+            covers = lib.egv_attn_fwd_covers_extra(dt, C.byref(dx)) == 1
+            if covers:
+                d1 = dx
         check(lib.egv_attn_fwd(dt, C.byref(d1), _st()), 'egv_attn_fwd(groups)')
+        if covers:
+            ctx.cfg = (B, Fr, N, H, mode)
+            ctx.save_for_backward(qkv, O, lse)
+            return O
         ns = _nsplit_for(S)
         ws, nb = _split_ws(0, B, 1, H, 1, ns, qkv.device)
         d2 = _mk_desc(Q, K, V, O, lse, B, 1, H, _rowset(S, 0, 0, 1, 1), _rowset(S, 0, 0, 1, S), None, scale, nsplit=ns, ws=ws,

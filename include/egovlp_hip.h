@@ -125,6 +125,12 @@ typedef struct egv_attn_desc {
  * other side has <= 224 rows run on the MFMA kernels (csrc/egv_attn_mfma.hip). */
 long long egv_attn_split_workspace_bytes(int which, int B, int G, int H, int n_own, int nsplit);
 int egv_attn_fwd(int dtype, const egv_attn_desc* d, void* stream);
+/* An unsplit egv_attn_fwd launch with an extra row, query row set == key row set and a workspace of
+ * egv_attn_fwd_extra_workspace_bytes also computes the extra row AS A QUERY over the union of the groups' keys -- the CLS query
+ * of the divided attention (video_transformer.py:129) -- from per-group partial softmax states, when egv_attn_fwd_covers_extra
+ * returns 1 for the descriptor (bf16, 65..224 keys per group, no mask / dropout); the one-query launch is then not needed. */
+long long egv_attn_fwd_extra_workspace_bytes(int B, int G, int H);
+int egv_attn_fwd_covers_extra(int dtype, const egv_attn_desc* d);
 int egv_attn_bwd_dq(int dtype, const egv_attn_desc* d, void* stream);
 long long egv_attn_bwd_dkv_workspace_bytes(int B, int G, int H, int k_n, int nsplit);
 int egv_attn_bwd_dkv(int dtype, const egv_attn_desc* d, void* stream);

@@ -532,8 +532,9 @@ def test_fused_attention_backward_matches_kernel_pair(ops):
         grads = {}
         try:
             for fused, cls in ((False, False), (True, True), (True, True), (True, False)):
-                ops.FUSED_ATTN_BWD, ops.FUSED_ATTN_CLS = fused, cls
+                ops.FUSED_ATTN_BWD = ops.FUSED_ATTN_CLS = True            # one forward for all (its CLS row may come from the group launch)
                 o = ops.divided_attention(qkv, B, Fr, N, H, 'space')
+                ops.FUSED_ATTN_BWD, ops.FUSED_ATTN_CLS = fused, cls
                 g, = torch.autograd.grad(o, qkv, do)
                 grads.setdefault((fused, cls), []).append(g)
         finally:
