@@ -88,3 +88,5 @@ bool egv_attn_fwd_cls_ok(const egv::AttnArgs& a);
 int egv_attn_dq_mfma(const egv::AttnArgs& a, int B, hipStream_t st);
 int egv_attn_dkv_mfma(const egv::AttnArgs& a, int B, hipStream_t st);
 int egv_attn_bwd_fused_mfma(const egv::AttnArgs& a, int B, hipStream_t st);
+bool egv_attn_bwd_pair_cls_ok(const egv::AttnArgs& a);
+void egv_attn_bwd_cls_reduce_launch(const egv::AttnArgs& a, int B, int self_term, hipStream_t st);

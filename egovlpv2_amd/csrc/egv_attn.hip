@@ -821,3 +821,23 @@ extern "C" int egv_attn_bwd_fused(int dtype, const egv_attn_desc* d, void* strea
     EGV_LAUNCH_CHECK();
     return 0;
 }
+
+// The dQ + dK/dV kernel pair of a grouped launch whose groups are a single 16-row tile (the 17-row time attention) can leave the
+// extra row's three gradients as per-group partials in d->ws (egv_attn_bwd_fused_workspace_bytes) when this returns 1: call
+// egv_attn_bwd_dq and egv_attn_bwd_dkv with the workspace set, then egv_attn_bwd_extra_reduce(..., self_term = 1) -- the
+// one-query and one-key launches of the extra row are then not needed (and egv_attn_bwd_dkv does not read the extra row's delta).
+extern "C" int egv_attn_bwd_pair_covers_extra(int dtype, const egv_attn_desc* d) {
+    if (dtype != EGV_BF16 || !d || !d->ws || d->ws_bytes < egv_attn_bwd_fused_workspace_bytes(d->B, d->G, d->H)) return 0;
+    AttnArgs a = to_args(d);
+    return egv_attn_bwd_pair_cls_ok(a) ? 1 : 0;
+}
+extern "C" int egv_attn_bwd_extra_reduce(int dtype, const egv_attn_desc* d, int self_term, void* stream) {
+    if (check_desc(d, "egv_attn_bwd_extra_reduce")) return -1;
+    EGV_CHECK(dtype == EGV_BF16 && d->ws && d->extra && d->dQ && d->dK && d->dV && d->lse && d->dO && d->O,
+              "egv_attn_bwd_extra_reduce: bf16 launch with workspace, extra row, O, dO, lse and the three gradient tensors");
+    EGV_CHECK(d->ws_bytes >= egv_attn_bwd_fused_workspace_bytes(d->B, d->G, d->H), "egv_attn_bwd_extra_reduce: workspace too small");
+    AttnArgs a = to_args(d);
+    egv_attn_bwd_cls_reduce_launch(a, d->B, self_term, reinterpret_cast<hipStream_t>(stream));
+    EGV_LAUNCH_CHECK();
+    return 0;
+}

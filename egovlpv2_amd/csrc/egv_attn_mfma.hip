@@ -346,6 +346,12 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a,
     stage_rows_t<NT, 64 * NW>(sVt, V, a.ldv, hv, a, a.k, b, g, ntot, tid, r0);
     __syncthreads();
 
+    // cls_out (one-wave, one-tile groups: the 17-row time attention; unsplit launch with an extra key and a workspace): the extra
+    // KEY's gradient under this group's queries -- dK = sum_q dS[q, cls] Q[q], dV = sum_q P[q, cls] dO[q] -- is left as an fp32
+    // partial per group (slots 1, 2 of ws[problem][head][3][64]) for attn_cls_reduce_kernel; the column is computed here anyway
+    const bool cls_out = NT == 2 && NW == 1 && !MASK && !DROP && a.nsplit == 1 && a.ws != nullptr && a.extra;
+    float p_cls = 0.f, ds_cls = 0.f;
+
     const int nqt = (a.q.n + 15) >> 4;
     const int t0 = (blockIdx.x / a.nsplit) * tiles_per_wg;
     const int t1 = min(nqt, t0 + tiles_per_wg);
@@ -394,6 +400,7 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a,
                             if (a.drop_p > 0.f) dpv *= drop_mult(a, (long long)p * a.q.n + q, r0 + key, h);
                         }
                         acc[r] = pj * (dpv - dl);
+                        if (t == 0 && r == 0) { p_cls = pj; ds_cls = acc[0]; }     // key 0 = the extra key (lanes fg == 0)
                     }
                     if (tile_partial<NL>(t, ntot)) {                         // uniform: the partial tile zeroes its padding keys
                         asm volatile("" ::: "memory");
@@ -410,6 +417,30 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a,
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_t<NT>(sKt, dt * 16 + fr, kk, fg), dsf, o[dt], 0, 0, 0);
             }
             EGV_KK_BARRIER
+        }
+        if (cls_out) {
+            // lane (fr, fg) holds Q / dO [query fr][fg*8 .. +7 | 32 + fg*8 ..]: weight by the query's dS / P of the extra key
+            // (lane fr of the first row) and sum over the 16 queries of the row with DPP exchanges
+            float dc = __shfl(ds_cls, fr, 64), pc = __shfl(p_cls, fr, 64);
+            if (!qv) dc = pc = 0.f;
+            float* pw = a.ws + ((long long)p * a.H + h) * 3 * HD;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v4[4] = {dc * (float)q0[e], dc * (float)q1[e], pc * (float)g0[e], pc * (float)g1[e]};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v4[k] += dpp_mov_f<0xB1>(v4[k]);
+                    v4[k] += dpp_mov_f<0x4E>(v4[k]);
+                    v4[k] += dpp_mov_f<0x141>(v4[k]);
+                    v4[k] += dpp_mov_f<0x140>(v4[k]);
+                }
+                if (fr == 0) {
+                    pw[HD + fg * 8 + e] = v4[0] * a.scale;
+                    pw[HD + 32 + fg * 8 + e] = v4[1] * a.scale;
+                    pw[2 * HD + fg * 8 + e] = v4[2];
+                    pw[2 * HD + 32 + fg * 8 + e] = v4[3];
+                }
+            }
         }
         if (qv && a.nsplit > 1) {
             const long long nrows = (long long)gridDim.y * a.q.n;
@@ -460,17 +491,32 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_mfma_kernel(const AttnArgs a
 
     stage_rows_t<NT, 64 * NW>(sQt, Q, a.ldq, hq, a, a.q, b, g, ntot, tid, r0);
     stage_rows_t<NT, 64 * NW>(sGt, dO, a.ldo, ho, a, a.q, b, g, ntot, tid, r0);
+    // cls_out (as in attn_dq_mfma_kernel): the extra QUERY's gradient over this group's keys, dQ = sum_k dS[cls, k] K[k], is left
+    // as an fp32 partial (slot 0 of ws[problem][head][3][64]); its delta is computed here (nobody else has to provide it)
+    const bool cls_out = NT == 2 && NW == 1 && !MASK && !DROP && a.nsplit == 1 && a.ws != nullptr && a.extra;
     for (int i = tid; i < NT * 16; i += 64 * NW) {
         float l = INFINITY, d = 0.f;                 // padded query rows: exp(s - inf) = 0
         if (i < ntot) {
             const long long row = other_row(a, a.q, b, g, r0 + i);
             l = a.lse[row * a.H + h] * LOG2E;          // log2 domain, like the scores
-            d = a.delta[row * a.H + h];
+            if (cls_out && i == 0) {
+                const bf16_t* Oc = reinterpret_cast<const bf16_t*>(a.O);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const bf16x8_t x = *reinterpret_cast<const bf16x8_t*>(dO + row * a.ldo + ho + c * 8);
+                    const bf16x8_t y = *reinterpret_cast<const bf16x8_t*>(Oc + row * a.ldo + ho + c * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) d += (float)x[e] * (float)y[e];
+                }
+            } else {
+                d = a.delta[row * a.H + h];
+            }
         }
         sL[i] = l;
         sD[i] = d;
     }
     __syncthreads();
+    float ds_cls = 0.f;
 
     const int nkt = (a.k.n + 15) >> 4;
     const int t0 = (blockIdx.x / a.nsplit) * tiles_per_wg;
@@ -516,6 +562,7 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_mfma_kernel(const AttnArgs a
                         acc[r] = DROP ? pj * mu : pj;
                         dp[r] = pj * ((DROP ? dp[r] * mu : dp[r]) - dl[r]);
                     }
+                    if (t == 0) ds_cls = dp[0];                                // query 0 = the extra query (lanes fg == 0)
                 }
                 pr[u] = acc;
                 dr[u] = dp;
@@ -530,6 +577,26 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_mfma_kernel(const AttnArgs a
                 }
             }
             EGV_KK_BARRIER
+        }
+        if (cls_out) {
+            float dc = __shfl(ds_cls, fr, 64);
+            if (!kv) dc = 0.f;
+            float* pw = a.ws + ((long long)p * a.H + h) * 3 * HD;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v2[2] = {dc * (float)k0[e], dc * (float)k1[e]};
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    v2[k] += dpp_mov_f<0xB1>(v2[k]);
+                    v2[k] += dpp_mov_f<0x4E>(v2[k]);
+                    v2[k] += dpp_mov_f<0x141>(v2[k]);
+                    v2[k] += dpp_mov_f<0x140>(v2[k]);
+                }
+                if (fr == 0) {
+                    pw[fg * 8 + e] = v2[0] * a.scale;
+                    pw[32 + fg * 8 + e] = v2[1] * a.scale;
+                }
+            }
         }
         if (kv && a.nsplit > 1) {
             // fp32 partials: ws[split][P * k.n own rows][H][2][64]  (summed by attn_dkv_reduce_kernel)
@@ -803,15 +870,51 @@ __global__ __launch_bounds__(64 * FNW) void attn_bwd_fused_kernel(const AttnArgs
 }
 
 // dQ / dK / dV of the extra (CLS) row = sum over the G groups of attn_bwd_fused_kernel's partials, in group order
-__global__ __launch_bounds__(64) void attn_cls_reduce_kernel(const AttnArgs a) {
-    const int b = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
+// self_term: the partials hold neither side of the (extra query, extra key) pair (dQ + dK/dV kernel pair: the extra row is
+// never an OWN row there) -- its three contributions are added here from the row itself
+__global__ __launch_bounds__(256) void attn_cls_reduce_kernel(const AttnArgs a, int self_term) {
+    __shared__ float red[4][3][HD];
+    const int b = blockIdx.x, h = blockIdx.y, d = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // four waves take the groups round-robin (196 groups for the time attention: a single wave's loop was 100 us of load
+    // latency), eight loads in flight each; combined in wave order -- the sum does not depend on scheduling
     float s[3] = {0.f, 0.f, 0.f};
-    for (int g = 0; g < a.G; ++g) {
-        const float* pw = a.ws + (((long long)b * a.G + g) * a.H + h) * 3 * HD;
+    const float* base = a.ws + ((long long)b * a.G * a.H + h) * 3 * HD + d;
+    const long long gstride = (long long)a.H * 3 * HD;
+    int g = w;
+    for (; g + 28 < a.G; g += 32) {
+        float v[8][3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) s[k] += pw[k * HD + d];
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[u][k] = base[(g + 4 * u) * gstride + k * HD];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s[k] += v[u][k];
     }
+    for (; g < a.G; g += 4)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s[k] += base[g * gstride + k * HD];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) red[w][k][d] = s[k];
+    __syncthreads();
+    if (w != 0) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s[k] = (red[0][k][d] + red[1][k][d]) + (red[2][k][d] + red[3][k][d]);
     const long long row = (long long)b * a.extra_bs + a.extra_row;
+    if (self_term) {
+        const float qc = bf2f(reinterpret_cast<const bf16_t*>(a.Q)[row * a.ldq + a.qoff + h * HD + d].v);
+        const float kc = bf2f(reinterpret_cast<const bf16_t*>(a.K)[row * a.ldk + a.koff + h * HD + d].v);
+        const float vc = bf2f(reinterpret_cast<const bf16_t*>(a.V)[row * a.ldv + a.voff + h * HD + d].v);
+        const float gc = bf2f(reinterpret_cast<const bf16_t*>(a.dO)[row * a.ldo + a.ooff + h * HD + d].v);
+        const float oc = bf2f(reinterpret_cast<const bf16_t*>(a.O)[row * a.ldo + a.ooff + h * HD + d].v);
+        const float sc = wave_sum_dpp(qc * kc) * a.scale, dp = wave_sum_dpp(gc * vc), dl = wave_sum_dpp(gc * oc);
+        const float pj = __expf(sc - a.lse[row * a.H + h]);
+        const float ds = pj * (dp - dl);
+        s[0] += ds * kc * a.scale;
+        s[1] += ds * qc * a.scale;
+        s[2] += pj * gc;
+    }
     reinterpret_cast<bf16_t*>(a.dQ)[row * a.lddq + a.dqoff + h * HD + d].v = f2bf(s[0]);
     reinterpret_cast<bf16_t*>(a.dK)[row * a.lddk + a.dkoff + h * HD + d].v = f2bf(s[1]);
     reinterpret_cast<bf16_t*>(a.dV)[row * a.lddv + a.dvoff + h * HD + d].v = f2bf(s[2]);
@@ -888,7 +991,19 @@ int egv_attn_fwd_mfma(const AttnArgs& ain, int B, hipStream_t st) {
     return cls ? 2 : 1;
 }
 
-int egv_attn_dq_mfma(const AttnArgs& a, int B, hipStream_t st) {
+// the dQ + dK/dV kernel pair leaves the extra row's gradients as per-group partials in a.ws (one-wave, one-tile groups: the
+// 17-row time attention) when the launch is unsplit, bf16, without mask / dropout, and the extra row is row 0 of the sample
+bool egv_attn_bwd_pair_cls_ok(const AttnArgs& a) {
+    return aligned_ok(a) && a.nsplit == 1 && a.ws && a.extra && a.extra_row == 0 && !a.mask && a.drop_p <= 0.f && a.k.n + a.extra <= 32 &&
+           a.q.n <= 16 && a.k.n <= 16 && a.O && a.dO;
+}
+void egv_attn_bwd_cls_reduce_launch(const AttnArgs& a, int B, int self_term, hipStream_t st) {
+    hipLaunchKernelGGL(attn_cls_reduce_kernel, dim3(B, a.H), dim3(256), 0, st, a, self_term);
+}
+
+int egv_attn_dq_mfma(const AttnArgs& ain, int B, hipStream_t st) {
+    AttnArgs a = ain;
+    if (a.nsplit == 1 && !egv_attn_bwd_pair_cls_ok(a)) a.ws = nullptr;
     const int nall = a.k.n + a.extra;
     const int ntot = a.nsplit > 1 ? ((((nall + a.nsplit - 1) / a.nsplit) + 15) & ~15) : nall;
     if (!aligned_ok(a) || (a.lddq % 4) || (a.dqoff % 4) || ntot > 224) return 0;
@@ -902,7 +1017,9 @@ int egv_attn_dq_mfma(const AttnArgs& a, int B, hipStream_t st) {
     return 1;
 }
 
-int egv_attn_dkv_mfma(const AttnArgs& a, int B, hipStream_t st) {
+int egv_attn_dkv_mfma(const AttnArgs& ain, int B, hipStream_t st) {
+    AttnArgs a = ain;
+    if (a.nsplit == 1 && !egv_attn_bwd_pair_cls_ok(a)) a.ws = nullptr;
     const int nall = a.q.n + a.extra;
     const int ntot = a.nsplit > 1 ? ((((nall + a.nsplit - 1) / a.nsplit) + 15) & ~15) : nall;
     if (!aligned_ok(a) || (a.lddk % 4) || (a.lddv % 4) || (a.dkoff % 4) || (a.dvoff % 4) || ntot > 224) return 0;
@@ -928,6 +1045,6 @@ int egv_attn_bwd_fused_mfma(const AttnArgs& a, int B, hipStream_t st) {
     constexpr size_t lds = fused_lds<14>();
     set_lds(attn_bwd_fused_kernel<14>, lds);
     hipLaunchKernelGGL((attn_bwd_fused_kernel<14>), dim3(1, B * a.G, a.H), dim3(64 * FNW), lds, st, a);
-    if (a.ws && a.extra) hipLaunchKernelGGL(attn_cls_reduce_kernel, dim3(B, a.H), dim3(64), 0, st, a);
+    if (a.ws && a.extra) hipLaunchKernelGGL(attn_cls_reduce_kernel, dim3(B, a.H), dim3(256), 0, st, a, 0);
     return 1;
 }

@@ -179,6 +179,11 @@ struct Divided {
         int fr = fused ? egv_attn_bwd_fused(dt, &d, st) : 1;
         if (fr < 0) return fr;
         if (fr == 0 && d.ws) return 0;
+        if (fr == 1 && d.ws && egv_attn_bwd_pair_covers_extra(dt, &d)) {   // time attention: the kernel pair + the CLS partial sum
+            BCHK(egv_attn_bwd_dq(dt, &d, st));
+            BCHK(egv_attn_bwd_dkv(dt, &d, st));
+            return egv_attn_bwd_extra_reduce(dt, &d, 1, st);
+        }
         const bool groups_done = fr == 0;
         fill(d, qkv, const_cast<void*>(O), lse); grads(d);  // CLS query over all S keys (also its delta, which the key-owned group launch reads)
         d.G = 1;

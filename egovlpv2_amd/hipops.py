@@ -656,6 +656,12 @@ class DividedAttnFn(Function):
                 check(rc, 'egv_attn_bwd_fused(groups)')
             if rc == 0 and wsf is not None:
                 return dqkv, None, None, None, None, None
+            if rc == 1 and wsf is not None and lib.egv_attn_bwd_pair_covers_extra(dt, C.byref(d1)) == 1:
+                # one-tile groups (time attention): the kernel pair leaves the CLS row's gradients as partials, one small sum
+                check(lib.egv_attn_bwd_dq(dt, C.byref(d1), _st()), 'egv_attn_bwd_dq(groups)')
+                check(lib.egv_attn_bwd_dkv(dt, C.byref(d1), _st()), 'egv_attn_bwd_dkv(groups)')
+                check(lib.egv_attn_bwd_extra_reduce(dt, C.byref(d1), 1, _st()), 'egv_attn_bwd_extra_reduce')
+                return dqkv, None, None, None, None, None
         ns = _nsplit_for(S)
         ws, nb = _split_ws(1, B, 1, H, 1, ns, qkv.device)
         d2 = _mk_desc(Q, K, V, O, lse, B, 1, H, cls1, allS, None, scale, nsplit=ns, ws=ws, ws_bytes=nb, **kw)

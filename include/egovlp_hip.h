@@ -141,6 +141,12 @@ int egv_attn_bwd_dkv(int dtype, const egv_attn_desc* d, void* stream);
  * the one-query egv_attn_bwd_dq and the one-key egv_attn_bwd_dkv launches of the CLS row. */
 long long egv_attn_bwd_fused_workspace_bytes(int B, int G, int H);
 int egv_attn_bwd_fused(int dtype, const egv_attn_desc* d, void* stream);
+/* The same for launches whose groups are one 16-row tile (the 17-row time attention), on the dQ + dK/dV kernel pair: when
+ * egv_attn_bwd_pair_covers_extra returns 1 for a descriptor with d->ws set, egv_attn_bwd_dq and egv_attn_bwd_dkv leave the extra
+ * row's gradients as per-group partials and egv_attn_bwd_extra_reduce(self_term = 1) sums them (adding the extra-query x
+ * extra-key term, which no group owns) -- the one-query / one-key launches of the CLS row are not needed. */
+int egv_attn_bwd_pair_covers_extra(int dtype, const egv_attn_desc* d);
+int egv_attn_bwd_extra_reduce(int dtype, const egv_attn_desc* d, int self_term, void* stream);
 
 /* ---- patch embedding pre/post (video_transformer.py:78-83,356-371; model.py:212-231,296-317) ---- */
 int egv_im2col(int dtype, const float* video, void* out, int BF, int C, int H, int W, int P, void* stream);
