@@ -37,6 +37,21 @@ if 'stream_id' in cols:
           f"< 20 us: {sum(g0 for g0, _, _ in gaps if g0 <= 20e3) / 1e6 / steps:.1f}")
     for g0, a, b in big[:12]:
         print(f"   gap {g0 / 1e3:8.1f} us after `{re.sub(r'[(<].*$', '', a)[:50]}` before `{re.sub(r'[(<].*$', '', b)[:50]}`")
+    # steady-state view: a step = the interval between consecutive cast_weights_kernel launches (one per step); the last full
+    # ones are the timed steps.  Busy / idle of the calling stream inside them, and the largest gaps with their neighbours.
+    marks = [k0 for k0, _, n in ks if 'cast_weights_kernel' in n]
+    if len(marks) >= 4:
+        lo, hi = marks[-4], marks[-1]
+        inside = [(a0, b0, n) for a0, b0, n in ks if lo <= a0 < hi]
+        nst = 3
+        busy_in = sum(b0 - a0 for a0, b0, _ in inside)
+        g_in = [(inside[i + 1][0] - inside[i][1], inside[i][2], inside[i + 1][2]) for i in range(len(inside) - 1) if inside[i + 1][0] > inside[i][1]]
+        print(f"Last {nst} steps (between cast_weights launches): {(hi - lo) / 1e6 / nst:.1f} ms/step wall under the profiler, stream {main} busy "
+              f"{busy_in / 1e6 / nst:.1f} ms/step, idle {sum(x for x, _, _ in g_in) / 1e6 / nst:.1f} ms/step "
+              f"(gaps > 100 us: {sum(x for x, _, _ in g_in if x > 100e3) / 1e6 / nst:.1f}, 10-100 us: {sum(x for x, _, _ in g_in if 10e3 < x <= 100e3) / 1e6 / nst:.1f}, "
+              f"< 10 us: {sum(x for x, _, _ in g_in if x <= 10e3) / 1e6 / nst:.1f} over {len(g_in) / nst:.0f} gaps)")
+        for x, a_, b_ in sorted(g_in, reverse=True)[:14]:
+            print(f"   gap {x / 1e3:8.1f} us after `{re.sub(r'[(<].*$', '', a_)[:48]}` before `{re.sub(r'[(<].*$', '', b_)[:48]}`")
     print()
     print(f"Kernel-interval union (GPU busy) {busy / 1e6 / steps:.1f} ms/step of a {span / steps:.1f} ms/step trace span; per stream (ms/step): "
           + ", ".join(f"stream {k}: {v / steps:.1f}" for k, v in sorted(per_stream.items(), key=lambda kv: -kv[1])[:4]) + "\n")
