@@ -208,7 +208,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
     };
     const __amdgpu_buffer_rsrc_t rs_c = mk(g.C, (long long)g.M * g.ldc * 2);
     const __amdgpu_buffer_rsrc_t rs_pre = mk(e.pre, (long long)g.M * e.ldr * 2);
-    const __amdgpu_buffer_rsrc_t rs_x = mk(X1K == 1 ? e.res1 : e.aux, (long long)g.M * e.ldr * 2);
+    const __amdgpu_buffer_rsrc_t rs_x = mk((X1K == 1 || X1K == 3) ? e.res1 : e.aux, (long long)g.M * e.ldr * 2);
+    const __amdgpu_buffer_rsrc_t rs_x2 = mk(X1K == 3 ? e.res2 : nullptr, (long long)g.M * e.ldr * 2);
     const __amdgpu_buffer_rsrc_t rs_bias = mk(e.bias, (long long)g.N * 4);
     const float gate = e.gate ? *e.gate : 1.0f;
 
@@ -267,6 +268,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
     bf16x8_t af[IM][2], bf0[2][2], bf1[2][2];
 
     // convert + store the two quadrants (s, 0), (s, 1) of the finished tile `tl`: 8 full-line stores (16 with the pre-activation)
+    u32x4_t xop2[X1K == 3 ? 2 : 1][X1K == 3 ? IM : 1][2];      // second residual (gated i2t projection: x + gate * y + skip)
     u32x4_t xop[2][IM][2];                                         // bulk epilogue: residual / GELU' operand vectors (s, i, t) of the tile
     auto pair_epilogue = [&](int s, const PPTile& tl) {           // s compile-time
         float bias8[2][8];                                        // the finished tile's bias from this wave's LDS slab
@@ -315,8 +317,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] *= gate;
-                if (X1K == 1) {
+                if (X1K == 1 || X1K == 3) {
                     const u32x4_t r = xop[s][i][t];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { v[2 * k] += __uint_as_float(r[k] << 16); v[2 * k + 1] += __uint_as_float(r[k] & 0xffff0000u); }
+                }
+                if constexpr (X1K == 3) {
+                    const u32x4_t r = xop2[s][i][t];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { v[2 * k] += __uint_as_float(r[k] << 16); v[2 * k + 1] += __uint_as_float(r[k] & 0xffff0000u); }
                 }
@@ -468,7 +475,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
                         xop[s][i][t] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, q_off(cur, true, s, i, t, false), 0, 0);
-            pp_wait_vmcnt<6 + 4 * IM>();                               // the bias DMA of LAST phase 1 (16 operand loads are younger)
+            if constexpr (X1K == 3) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int i = 0; i < IM; ++i)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+                            xop2[s][i][t] = __builtin_amdgcn_raw_buffer_load_b128(rs_x2, q_off(cur, true, s, i, t, false), 0, 0);
+            }
+            pp_wait_vmcnt<6 + (X1K == 3 ? 8 : 4) * IM>();                               // the bias DMA of LAST phase 1 (16 operand loads are younger)
             pair_epilogue(0, cur);
             pair_epilogue(1, cur);
         }
@@ -502,8 +518,8 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
     if ((long long)g.M * g.lda >= (1LL << 30) || (long long)g.N * g.ldb >= (1LL << 30)) return 0;   // 32-bit byte offsets
     if ((long long)g.M * g.ldc >= (1LL << 30) || (long long)g.M * e.ldr >= (1LL << 30)) return 0;
     if (e.scale != 1.0f) return 0;                                // the bias rides in as the accumulators' initial value
-    if (e.res2) return 0;                                         // gated two-residual form (i2t projection): ring kernel
-    if (e.res1 && (e.gate || e.dact || e.act || e.pre)) return 0;
+    if (e.res2 && (!e.res1 || e.dact || e.act || e.pre)) return 0;
+    if (e.res1 && !e.res2 && (e.gate || e.dact || e.act || e.pre)) return 0;
     if (e.dact && (e.act || e.pre)) return 0;
     if (e.pre && !e.act) return 0;
     g.tiles_n = (g.N + 255) / 256;
@@ -560,6 +576,8 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
         hipLaunchKernelGGL((gemm_pp_kernel<X, false, false, false, 3>), dim3(grid), dim3(512), PP_LDS, st, g, ntiles);   \
         return 1;                                                                                                        \
     } while (0)
+    if (e.res2 && !use192) return 0;                              // gated two-residual form (i2t projection): built for the 192-row tiles only
+    if (use192 && e.res2) PP_LAUNCH192(3);
     if (use192 && e.res1) PP_LAUNCH192(1);
     if (use192) PP_LAUNCH192(0);
 #undef PP_LAUNCH192

@@ -593,7 +593,7 @@ def test_patch_tokens_from_uint8_clips(ops, dtype):
 
 
 # ---- round 2: persistent ping-pong GEMM / block-level entry points -------------------------------------------------------------
-@pytest.mark.parametrize('N,K,kind', [(2304, 768, 'bias'), (3072, 768, 'gelu'), (768, 3072, 'res'), (768, 2304, 'plain'), (768, 768, 'plain')])
+@pytest.mark.parametrize('N,K,kind', [(2304, 768, 'bias'), (3072, 768, 'gelu'), (768, 3072, 'res'), (768, 2304, 'plain'), (768, 768, 'plain'), (768, 768, 'gate_res2')])
 def test_persistent_gemm_bitwise_equals_ring_gemm(ops, N, K, kind):
     """The kernel choice depends on the grid size (persistent ping-pong kernel from 64 tiles of 256x256 up -- with 192-row tiles
     for the N = 768 shapes at full M -- DMA-ring kernels below): all accumulate in the same K order and add the bias after the sum, so the first rows of a full-size call must be
@@ -602,10 +602,13 @@ def test_persistent_gemm_bitwise_equals_ring_gemm(ops, N, K, kind):
     x = _rnd((M, K), torch.bfloat16, 1.0, 11).cuda()
     w = _rnd((N, K), torch.float32, 0.05, 12).cuda()
     b = _rnd((N,), torch.float32, 0.5, 13).cuda() if kind != 'plain' else None
-    res = _rnd((M, N), torch.bfloat16, 1.0, 14).cuda() if kind == 'res' else None
+    res = _rnd((M, N), torch.bfloat16, 1.0, 14).cuda() if kind in ('res', 'gate_res2') else None
+    res2 = _rnd((M, N), torch.bfloat16, 1.0, 15).cuda() if kind == 'gate_res2' else None
+    gate = torch.tensor([0.37], device='cuda') if kind == 'gate_res2' else None
     act = 'gelu' if kind == 'gelu' else 'none'
-    big = ops.linear(x, w, b, act=act, res1=res)
-    small = ops.linear(x[:m].contiguous(), w, b, act=act, res1=None if res is None else res[:m].contiguous())
+    big = ops.linear(x, w, b, act=act, res1=res, res2=res2, gate=gate)
+    small = ops.linear(x[:m].contiguous(), w, b, act=act, res1=None if res is None else res[:m].contiguous(),
+                       res2=None if res2 is None else res2[:m].contiguous(), gate=gate)
     assert torch.equal(big[:m], small)
     # and against fp64 on sampled rows of the last (ragged, 8-row) tile
     rows = torch.arange(M - 8, M)
@@ -613,8 +616,12 @@ def test_persistent_gemm_bitwise_equals_ring_gemm(ops, N, K, kind):
     if b is not None:
         z = z + b.double().cpu()
     ref = gelu64(z) if kind == 'gelu' else z
+    if gate is not None:
+        ref = ref * float(gate)
     if res is not None:
         ref = ref + res[rows.cuda()].double().cpu()
+    if res2 is not None:
+        ref = ref + res2[rows.cuda()].double().cpu()
     assert _rel(big[rows.cuda()], ref) < 6e-3
 
 
