@@ -541,7 +541,8 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
     static const bool allow192 = !getenv("EGV_PP_BM192") || atoi(getenv("EGV_PP_BM192")) != 0;
     const bool kind192 = !e.dact && !e.pre && !e.act && !getenv("EGV_PP_STAMPS");
     const int t256 = ((g.M + 255) / 256) * g.tiles_n, t192 = ((g.M + 191) / 192) * g.tiles_n;
-    const double c256 = (double)((t256 + ncu - 1) / ncu), c192 = (double)((t192 + ncu - 1) / ncu) * 0.75 * 1.06;
+    static const double pen192 = getenv("EGV_PP_192_PENALTY") ? atof(getenv("EGV_PP_192_PENALTY")) : 1.06;
+    const double c256 = (double)((t256 + ncu - 1) / ncu), c192 = (double)((t192 + ncu - 1) / ncu) * 0.75 * pen192;
     const bool use192 = allow192 && kind192 && t256 >= ncu && c192 < c256;
     g.tiles_m = use192 ? (g.M + 191) / 192 : (g.M + 255) / 256;
     const int ntiles = g.tiles_m * g.tiles_n;
