@@ -111,8 +111,8 @@ def cpu_baseline(cfg, L, workload, timeout_s=300):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='full', choices=['full', 'dual'])
     ap.add_argument('--optimizer', action='store_true', help='also time the fused AdamW step + LR schedule (SURVEY.md §8f item 1)')
     ap.add_argument('--batch', type=int, default=8)
