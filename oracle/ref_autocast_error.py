@@ -1,0 +1,45 @@
+"""How far is the REFERENCE ITSELF from its fp32 values when it runs the way its trainer runs it -- under autocast
+(trainer_egoclip.py:143; bf16 here, CPU autocast: matmuls / convolutions in bf16, LayerNorm, softmax, residual sums and losses
+in fp32)?  Puts the bf16 mode of this build (activations stored in bf16) in context.  Build container only
+(imports /root/reference through oracle/gen_golden.py).  usage: python oracle/ref_autocast_error.py [base_f4|tiny]"""
+import os, sys, types
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import gen_golden as G                                               # noqa: E402
+from egovlpv2_amd.synthetic import make_state_dict, make_batch      # noqa: E402
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return ((a - b).norm() / b.norm()).item()
+
+
+def main(name):
+    c = G.CASES[name]
+    cfg, B, L = c['cfg'], c['B'], c['L']
+    R = G.import_reference()
+    torch.manual_seed(0)
+    m = G.build_reference(R, cfg).eval()
+    m.load_state_dict(make_state_dict(cfg, c['wseed']), strict=True)
+    data, noun, verb = make_batch(cfg, B, L, c['bseed'])
+    g = np.load(os.path.join(G.REPO, 'tests', 'golden', name + '.npz'))
+    G.enable_cpu_forward()
+    args = types.SimpleNamespace(world_size=1, rank=0)
+    with torch.no_grad(), torch.autocast('cpu', dtype=torch.bfloat16):
+        r = m.infer(data, task_names='EgoNCE', ret={})
+    print(f"{name}: reference under bf16 autocast vs its fp32 values: text_embeds {rel(r['text_embeds'].float(), g['text_embeds']):.2e}, "
+          f"video_embeds {rel(r['video_embeds'].float(), g['video_embeds']):.2e}")
+    np.random.seed(17)
+    torch.manual_seed(17)
+    with torch.autocast('cpu', dtype=torch.bfloat16):
+        loss, ld, ret = m(data, noun, verb, R.AllGather_multi.apply, 1, args, {'loss': {'type': 'EgoNCE'}}, R.ml.EgoNCE(), 0,
+                          task_names='EgoNCE_MLM_ITM')
+    for k in ('EgoNCE', 'loss_mlm', 'loss_itm', 'loss_total'):
+        ref = float(g['loss_' + k])
+        print(f"   {k}: {float(ld[k]):.6f} vs fp32 {ref:.6f}  (rel {abs(float(ld[k]) - ref) / abs(ref):.2e})")
+
+
+if __name__ == '__main__':
+    main(sys.argv[1] if len(sys.argv) > 1 else 'base_f4')
