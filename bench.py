@@ -114,6 +114,9 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='full', choices=['full', 'dual'])
+    ap.add_argument('--arch', default='base16', choices=['base16', 'large14'],
+                    help='base16: ViT-B/16 + RoBERTa-base (the measured configs); large14: the configs[4] geometry -- ViT-L/14 TimeSformer '
+                         '(24 blocks, d = 1024, 16 heads, 256 patches per frame) + RoBERTa-large width, 12 fused layers -- in bf16 (no fp8 weights)')
     ap.add_argument('--optimizer', action='store_true', help='also time the fused AdamW step + LR schedule (SURVEY.md §8f item 1)')
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--frames', type=int, default=16)
@@ -155,6 +158,8 @@ def main():
     from egovlpv2_amd.trainer.trainer_egoclip import AllGather_multi
 
     cfg = PathConfig(frames=a.frames, drop_rate=a.drop_rate)     # roberta-base hidden / attention dropout (train mode)
+    if a.arch == 'large14':
+        cfg = PathConfig(depth=24, n_fuse=12, patch=14, dim=1024, heads=16, frames=a.frames, drop_rate=a.drop_rate)
     tasks = 'EgoNCE' if a.workload == 'dual' else 'EgoNCE_MLM_ITM'
     dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
     model = FrozenInTime({'model': 'SpaceTimeTransformer', 'num_frames': cfg.frames, 'pretrained': True},
@@ -291,8 +296,9 @@ def main():
                "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": ("configs[2] full fusion EgoNCE+MLM+ITM" if a.workload == 'full' else "configs[1] dual encoder EgoNCE")
-                          + f", ViT-B/16 TimeSformer + RoBERTa-base, B={a.batch}/GPU, {a.frames}x224^2, {a.text_len} tok",
+               "config": {"workload": (("configs[2] full fusion EgoNCE+MLM+ITM" if a.arch == 'base16' else "full fusion EgoNCE+MLM+ITM") if a.workload == 'full' else "configs[1] dual encoder EgoNCE")
+                          + (f", ViT-B/16 TimeSformer + RoBERTa-base" if a.arch == 'base16' else ", configs[4] geometry: ViT-L/14 TimeSformer + RoBERTa-large width, bf16 weights")
+                          + f", B={a.batch}/GPU, {a.frames}x224^2, {a.text_len} tok",
                           "global_batch": world * a.batch, "parallelism": f"dp{world}", "drop_rate": a.drop_rate, "timed": "zero_grad + fwd + bwd (+DDP all-reduce), weight cast included" + (" + fused AdamW step" if a.optimizer else "")},
                # model_tflops: the reference algorithm's matmul FLOPs per pair x pairs/s; executed_tflops leaves
                # out the dead MLM video block and the ITM video prefix shared with the MLM pass (same values, computed once)

@@ -979,12 +979,13 @@ int egv_attn_fwd_mfma(const AttnArgs& ain, int B, hipStream_t st) {
     if (!cls && a.nsplit == 1) a.ws = nullptr;                     // the kernel keys the extra-query path on ws
     const int nall = a.k.n + a.extra;
     const int ntot = a.nsplit > 1 ? ((((nall + a.nsplit - 1) / a.nsplit) + 15) & ~15) : nall;
-    if (!aligned_ok(a) || ntot > 224) return 0;
+    if (!aligned_ok(a) || ntot > 288) return 0;
     if (a.nsplit > 1 && (a.q.n > 64 || !a.ws)) return 0;          // split form: short query side only (text -> image)
     int nw, tpw, chunks;
     own_split(a.q.n, nw, tpw, chunks);
     chunks *= a.nsplit;
-    if (ntot <= 32) EGV_MFMA_LAUNCH(attn_fwd_mfma_kernel, fwd_lds, 2, 0);
+    if (ntot > 224) EGV_MFMA_LAUNCH(attn_fwd_mfma_kernel, fwd_lds, 18, 0);      // 256 patches + CLS (14 x 14 patches of a 224^2 frame)
+    else if (ntot <= 32) EGV_MFMA_LAUNCH(attn_fwd_mfma_kernel, fwd_lds, 2, 0);
     else if (ntot <= 64) EGV_MFMA_LAUNCH(attn_fwd_mfma_kernel, fwd_lds, 4, 0);
     else if (ntot > 192 && ntot <= 208 && a.nsplit == 1) { if (cls) ++tpw; EGV_MFMA_LAUNCH(attn_fwd_mfma_kernel, fwd_lds, 14, 13); }     // 196 patches + CLS: 13 live tiles known at compile time (-20 % on the forward; measured slower on the two backward kernels)
     else { if (cls) ++tpw; EGV_MFMA_LAUNCH(attn_fwd_mfma_kernel, fwd_lds, 14, 0); }
@@ -1006,12 +1007,13 @@ int egv_attn_dq_mfma(const AttnArgs& ain, int B, hipStream_t st) {
     if (a.nsplit == 1 && !egv_attn_bwd_pair_cls_ok(a)) a.ws = nullptr;
     const int nall = a.k.n + a.extra;
     const int ntot = a.nsplit > 1 ? ((((nall + a.nsplit - 1) / a.nsplit) + 15) & ~15) : nall;
-    if (!aligned_ok(a) || (a.lddq % 4) || (a.dqoff % 4) || ntot > 224) return 0;
+    if (!aligned_ok(a) || (a.lddq % 4) || (a.dqoff % 4) || ntot > 288) return 0;
     if (a.nsplit > 1 && (a.q.n > 64 || !a.ws)) return 0;
     int nw, tpw, chunks;
     own_split(a.q.n, nw, tpw, chunks);
     chunks *= a.nsplit;
-    if (ntot <= 32) EGV_MFMA_LAUNCH(attn_dq_mfma_kernel, dq_lds, 2, 0);
+    if (ntot > 224) EGV_MFMA_LAUNCH(attn_dq_mfma_kernel, dq_lds, 18, 0);
+    else if (ntot <= 32) EGV_MFMA_LAUNCH(attn_dq_mfma_kernel, dq_lds, 2, 0);
     else if (ntot <= 64) EGV_MFMA_LAUNCH(attn_dq_mfma_kernel, dq_lds, 4, 0);
     else EGV_MFMA_LAUNCH(attn_dq_mfma_kernel, dq_lds, 14, 0);
     return 1;
@@ -1022,12 +1024,13 @@ int egv_attn_dkv_mfma(const AttnArgs& ain, int B, hipStream_t st) {
     if (a.nsplit == 1 && !egv_attn_bwd_pair_cls_ok(a)) a.ws = nullptr;
     const int nall = a.q.n + a.extra;
     const int ntot = a.nsplit > 1 ? ((((nall + a.nsplit - 1) / a.nsplit) + 15) & ~15) : nall;
-    if (!aligned_ok(a) || (a.lddk % 4) || (a.lddv % 4) || (a.dkoff % 4) || (a.dvoff % 4) || ntot > 224) return 0;
+    if (!aligned_ok(a) || (a.lddk % 4) || (a.lddv % 4) || (a.dkoff % 4) || (a.dvoff % 4) || ntot > 288) return 0;
     if (a.nsplit > 1 && (a.k.n > 64 || !a.ws)) return 0;          // split form: short key side only
     int nw, tpw, chunks;
     own_split(a.k.n, nw, tpw, chunks);
     chunks *= a.nsplit;
-    if (ntot <= 32) EGV_MFMA_LAUNCH(attn_dkv_mfma_kernel, dkv_lds, 2, 0);
+    if (ntot > 224) EGV_MFMA_LAUNCH(attn_dkv_mfma_kernel, dkv_lds, 18, 0);
+    else if (ntot <= 32) EGV_MFMA_LAUNCH(attn_dkv_mfma_kernel, dkv_lds, 2, 0);
     else if (ntot <= 64) EGV_MFMA_LAUNCH(attn_dkv_mfma_kernel, dkv_lds, 4, 0);
     else EGV_MFMA_LAUNCH(attn_dkv_mfma_kernel, dkv_lds, 14, 0);
     return 1;

@@ -23,9 +23,19 @@ __global__ void im2col_kernel(const float* __restrict__ video, T* __restrict__ o
         const int x = x4 * 4;
         float v[4];
         ld4(video + (((long long)bf * C + c) * H + y) * W + x, v);
-        const int py = y / P, ph = y % P, px = x / P, pw = x % P;
-        const long long orow = ((long long)bf * gh + py) * gw + px;
-        st4(out + orow * rowlen + (c * P + ph) * P + pw, v);
+        const int py = y / P, ph = y % P;
+        if ((P & 3) == 0) {
+            const int px = x / P, pw = x % P;
+            const long long orow = ((long long)bf * gh + py) * gw + px;
+            st4(out + orow * rowlen + (c * P + ph) * P + pw, v);
+        } else {                                               // patch width not a multiple of 4 (14 x 14 patches): the four pixels
+#pragma unroll                                                 // may belong to two patches and the row is not 16-byte aligned
+            for (int e = 0; e < 4; ++e) {
+                const int px = (x + e) / P, pw = (x + e) % P;
+                const long long orow = ((long long)bf * gh + py) * gw + px;
+                Elem<T>::st(out + orow * rowlen + (c * P + ph) * P + pw, v[e]);
+            }
+        }
     }
 }
 
@@ -50,9 +60,19 @@ __global__ void im2col_u8_kernel(const unsigned char* __restrict__ video, T* __r
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = ((float)((px4 >> (8 * e)) & 0xffu) * (1.0f / 255.0f) - mean) * inv;
-        const int py = y / P, ph = y % P, px = x / P, pw = x % P;
-        const long long orow = ((long long)bf * gh + py) * gw + px;
-        st4(out + orow * rowlen + (c * P + ph) * P + pw, v);
+        const int py = y / P, ph = y % P;
+        if ((P & 3) == 0) {
+            const int px = x / P, pw = x % P;
+            const long long orow = ((long long)bf * gh + py) * gw + px;
+            st4(out + orow * rowlen + (c * P + ph) * P + pw, v);
+        } else {                                               // patch width not a multiple of 4 (14 x 14 patches): the four pixels
+#pragma unroll                                                 // may belong to two patches and the row is not 16-byte aligned
+            for (int e = 0; e < 4; ++e) {
+                const int px = (x + e) / P, pw = (x + e) % P;
+                const long long orow = ((long long)bf * gh + py) * gw + px;
+                Elem<T>::st(out + orow * rowlen + (c * P + ph) * P + pw, v[e]);
+            }
+        }
     }
 }
 
@@ -403,7 +423,7 @@ using namespace egv;
 #define EGV_ST reinterpret_cast<hipStream_t>(stream)
 
 extern "C" int egv_im2col(int dtype, const float* video, void* out, int BF, int C, int H, int W, int P, void* stream) {
-    EGV_CHECK(W % 4 == 0 && P % 4 == 0 && H % P == 0 && W % P == 0, "egv_im2col: unsupported geometry H=%d W=%d P=%d", H, W, P);
+    EGV_CHECK(W % 4 == 0 && H % P == 0 && W % P == 0, "egv_im2col: unsupported geometry H=%d W=%d P=%d", H, W, P);
     const long long total = (long long)BF * C * H * (W / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
@@ -415,7 +435,7 @@ extern "C" int egv_im2col(int dtype, const float* video, void* out, int BF, int 
 
 extern "C" int egv_im2col_u8(int dtype, const unsigned char* video, void* out, int BF, int C, int H, int W, int P, const float* mean3,
                              const float* std3, void* stream) {
-    EGV_CHECK(C == 3 && W % 4 == 0 && P % 4 == 0 && H % P == 0 && W % P == 0, "egv_im2col_u8: unsupported geometry C=%d H=%d W=%d P=%d", C, H, W, P);
+    EGV_CHECK(C == 3 && W % 4 == 0 && H % P == 0 && W % P == 0, "egv_im2col_u8: unsupported geometry C=%d H=%d W=%d P=%d", C, H, W, P);
     EGV_CHECK(mean3 && std3 && std3[0] > 0.f && std3[1] > 0.f && std3[2] > 0.f, "egv_im2col_u8: mean/std (host float[3]) required");
     const long long total = (long long)BF * C * H * (W / 4);
     int blocks = (int)((total + 255) / 256);

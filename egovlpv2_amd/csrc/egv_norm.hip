@@ -509,7 +509,14 @@ extern "C" int egv_layernorm_bwd2(int dtype, const void* dy, const void* x, cons
     const int nb2 = (M + rpb - 1) / rpb;
     float* partial = (float*)workspace;
     static const int packed = getenv("EGV_LN_PACKED") ? atoi(getenv("EGV_LN_PACKED")) : 1;
-    if (dtype == EGV_BF16 && packed && D == 768) {
+    if (dtype == EGV_BF16 && packed && D == 1024) {                  // ViT-L / RoBERTa-large width: two packed rows per wave
+        const bf16_t *pdy = (const bf16_t*)dy, *pxx = (const bf16_t*)x, *pa = (const bf16_t*)add, *pb = (const bf16_t*)add2;
+        if (pb && !pa) { pa = pb; pb = nullptr; }
+        if (pb) hipLaunchKernelGGL((layernorm_bwd_bf16_kernel<4, 2, 2>), dim3(nb2), dim3(256), 0, st, pdy, pxx, stats, gamma, pa, pb, (bf16_t*)dx, partial, M, rpb);
+        else if (pa) hipLaunchKernelGGL((layernorm_bwd_bf16_kernel<4, 2, 1>), dim3(nb2), dim3(256), 0, st, pdy, pxx, stats, gamma, pa, pb, (bf16_t*)dx, partial, M, rpb);
+        else hipLaunchKernelGGL((layernorm_bwd_bf16_kernel<4, 2, 0>), dim3(nb2), dim3(256), 0, st, pdy, pxx, stats, gamma, pa, pb, (bf16_t*)dx, partial, M, rpb);
+    }
+    else if (dtype == EGV_BF16 && packed && D == 768) {
         const bf16_t *pdy = (const bf16_t*)dy, *pxx = (const bf16_t*)x, *pa = (const bf16_t*)add, *pb = (const bf16_t*)add2;
         if (pb && !pa) { pa = pb; pb = nullptr; }
         if (pb) hipLaunchKernelGGL((layernorm_bwd_bf16_kernel<3, 4, 2>), dim3(nb2), dim3(256), 0, st, pdy, pxx, stats, gamma, pa, pb, (bf16_t*)dx, partial, M, rpb);

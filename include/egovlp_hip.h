@@ -122,7 +122,7 @@ typedef struct egv_attn_desc {
 /* nsplit > 1 splits the OTHER side of a launch across workgroups (fp32 partials in ws, combined in a fixed order):
  * needed when one own row meets thousands of other rows (CLS query/key over all S tokens, text<->video cross attention).
  * which = 0 fwd, 1 dq, 2 dkv; n_own = q_n (fwd, dq) or k_n (dkv).  With nsplit == 1 and dtype == EGV_BF16, problems whose
- * other side has <= 224 rows run on the MFMA kernels (csrc/egv_attn_mfma.hip). */
+ * other side has <= 288 rows (256 patches of a 14 x 14-patch frame + CLS) run on the MFMA kernels (csrc/egv_attn_mfma.hip). */
 long long egv_attn_split_workspace_bytes(int which, int B, int G, int H, int n_own, int nsplit);
 int egv_attn_fwd(int dtype, const egv_attn_desc* d, void* stream);
 /* An unsplit egv_attn_fwd launch with an extra row, query row set == key row set and a workspace of

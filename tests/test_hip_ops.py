@@ -178,7 +178,7 @@ def _divided_ref(qkv, B, Fr, N, H, mode):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('mode,Fr,N', [('space', 3, 70), ('time', 5, 9), ('space', 2, 196), ('time', 16, 4)])
+@pytest.mark.parametrize('mode,Fr,N', [('space', 3, 70), ('time', 5, 9), ('space', 2, 196), ('time', 16, 4), ('space', 2, 256)])
 def test_divided_attention(ops, dtype, mode, Fr, N):
     B, H = 2, 3
     S = 1 + Fr * N

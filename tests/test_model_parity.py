@@ -421,3 +421,38 @@ def test_dual_finetune_variant_vs_golden(name, dtype, tol_e, tol_l, tol_g):
             num += float((a - b).pow(2).sum()); den += float(b.pow(2).sum()); dot += float((a * b).sum()); gg += float(a.pow(2).sum())
         assert math.sqrt(num / den) < tol_g, (ds, math.sqrt(num / den))
         assert dot / math.sqrt(gg * den) > (0.999 if dtype == torch.float32 else 0.99), ds
+
+
+@pytest.mark.parametrize('dtype,tol_l,tol_g', [(torch.float32, 1e-3, 5e-3), (torch.bfloat16, 2e-2, 0.15)])
+def test_vit_large_patch14_geometry_vs_oracle(dtype, tol_l, tol_g):
+    """BASELINE.json configs[4] geometry without the fp8 weights: d = 1024, 16 heads, 14 x 14 patches (256 patches + CLS = 257 keys
+    per space-attention group: the 18-tile MFMA attention kernels, the scalar patchify path, 1024-wide LayerNorms and GEMMs), two
+    layers per tower with one fused, three losses, the whole gradient against the oracle."""
+    from oracle import ref_model as O
+    from egovlpv2_amd.config import PathConfig
+    from egovlpv2_amd.synthetic import make_state_dict, make_batch
+    cfg = PathConfig(depth=2, n_fuse=1, img=224, patch=14, frames=2, dim=1024, heads=16, proj_dim=512)
+    B, L = 2, 16
+    sd = make_state_dict(cfg, 7)
+    data, noun, verb = make_batch(cfg, B, L, 77)
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    np.random.seed(5)
+    torch.manual_seed(5)
+    oloss, old, _ = O.forward_losses(sd, data, noun, verb, O.make_cfg(**cfg.as_dict()), 'EgoNCE_MLM_ITM')
+    oloss.backward()
+    m = _build(cfg, sd, dtype).eval()
+    np.random.seed(5)
+    torch.manual_seed(5)
+    loss, ld, _ = _forward(m, data, noun, verb, 'EgoNCE_MLM_ITM')
+    for k in ('EgoNCE', 'loss_mlm', 'loss_itm'):
+        ref = float(old[k])
+        assert abs(float(ld[k].detach()) - ref) <= tol_l * abs(ref), (k, float(ld[k].detach()), ref)
+    loss.backward()
+    num = den = dot = gg = 0.0
+    for k, p in m.named_parameters():
+        a, b = p.grad.detach().double().cpu(), sd[k].grad.double()
+        num += float((a - b).pow(2).sum()); den += float(b.pow(2).sum()); dot += float((a * b).sum()); gg += float(a.pow(2).sum())
+    assert math.sqrt(num / den) < tol_g, math.sqrt(num / den)
+    assert dot / math.sqrt(gg * den) > (0.9999 if dtype == torch.float32 else 0.99)
