@@ -156,6 +156,17 @@ class FrozenInTime(nn.Module):
                 _register(self, name, _init_tensor(name, shape, gen, self.cfg))
         self._P = None
 
+        # Pretrained towers (model.py:69 RobertaModel.from_pretrained("roberta-base"); :80-94 the timm ViT-B/16 state dict loaded
+        # with strict=False when no full checkpoint is given).  The reference hard-codes its file locations; here they come from
+        # text_params['pretrained_path'] / video_params['pretrained_path'] (or EGV_ROBERTA_CHECKPOINT / EGV_VIT_CHECKPOINT).
+        # Without a path the towers keep their seeded random init (there is no network for the hub downloads).
+        tpath = text_params.get('pretrained_path') or os.environ.get('EGV_ROBERTA_CHECKPOINT')
+        if tpath:
+            self.load_pretrained_text(tpath)
+        vpath = video_params.get('pretrained_path') or os.environ.get('EGV_VIT_CHECKPOINT')
+        if vpath and video_params.get('pretrained', True) and load_checkpoint in ["", None]:
+            self.load_pretrained_vit(vpath)
+
         if load_checkpoint not in ["", None]:
             # reference checkpoints pickle a ConfigParser under 'config' (base_trainer.py:412-436): weights_only must be off
             checkpoint = torch.load(load_checkpoint, map_location='cpu', weights_only=False)
@@ -163,6 +174,56 @@ class FrozenInTime(nn.Module):
             new_state_dict = state_dict_data_parallel_fix(state_dict, self.state_dict())
             new_state_dict = self._inflate_positional_embeds(new_state_dict)
             self.load_state_dict(new_state_dict, strict=False)
+
+    # ------------------------------------------------------------------ pretrained towers
+    @staticmethod
+    def _read_state_dict(path):
+        if str(path).endswith('.safetensors'):
+            from safetensors.torch import load_file
+            return load_file(str(path))
+        sd = torch.load(path, map_location='cpu', weights_only=True)
+        return sd.get('state_dict', sd) if isinstance(sd, dict) and 'state_dict' in sd else sd
+
+    def _load_matching(self, loaded, what):
+        """load_state_dict(strict=False) semantics on a name-mapped dict: unknown names are ignored, missing ones keep their init,
+        a shape mismatch is an error (as in torch).  Returns the names that were loaded."""
+        own = self.state_dict()
+        done = []
+        with torch.no_grad():
+            for k, v in loaded.items():
+                if k not in own:
+                    continue
+                if tuple(own[k].shape) != tuple(v.shape):
+                    raise RuntimeError(f"{what}: size mismatch for {k}: checkpoint {tuple(v.shape)} vs model {tuple(own[k].shape)}")
+                own[k].copy_(v.to(own[k].dtype))
+                done.append(k)
+        self._P = None
+        return done
+
+    def load_pretrained_text(self, path):
+        """model.py:69: HF roberta-base weights into text_model.* (checkpoint names with or without the 'roberta.' prefix; lm_head /
+        pooler are not part of the path; the cross-attention layers of the fused blocks stay newly initialised, as they do under
+        from_pretrained)"""
+        sd = self._read_state_dict(path)
+        mapped = {}
+        for k, v in sd.items():
+            k = k[len('roberta.'):] if k.startswith('roberta.') else k
+            if k.startswith(('embeddings.', 'encoder.')) and not k.endswith('position_ids'):
+                mapped['text_model.' + k] = v
+        done = self._load_matching(mapped, 'load_pretrained_text')
+        if not done:
+            raise RuntimeError(f"load_pretrained_text: no RoBERTa tensors found in {path}")
+        return done
+
+    def load_pretrained_vit(self, path):
+        """model.py:80-94: the timm ViT-B/16 state dict (cls_token, pos_embed, patch_embed.proj.*, blocks.i.{norm1,norm2,attn.qkv,
+        attn.proj,mlp.fc1,mlp.fc2}.*, norm.*) into video_model.* with strict=False: the classifier head is dropped, temporal
+        embedding / temporal attention / norm3 / fusion parameters keep their init"""
+        sd = state_dict_data_parallel_fix(self._read_state_dict(path), {k[len('video_model.'):]: 0 for k in self.state_dict() if k.startswith('video_model.')})
+        done = self._load_matching({'video_model.' + k: v for k, v in sd.items()}, 'load_pretrained_vit')
+        if not done:
+            raise RuntimeError(f"load_pretrained_vit: no ViT tensors found in {path}")
+        return done
 
     # ------------------------------------------------------------------ plumbing
     def set_device(self, device):

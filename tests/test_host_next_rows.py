@@ -223,3 +223,43 @@ def test_load_checkpoint_roundtrip_with_pickled_config_module_prefix_and_frame_i
     torch.save({'config': _OpaqueConfig(), 'state_dict': make_state_dict(cfg4, 6)}, path)
     m1 = FrozenInTime({**vp, 'num_frames': 2}, tp, path_config=cfg2, load_checkpoint=path, compute_dtype=torch.float32)
     assert torch.equal(m1.state_dict()['video_model.temporal_embed'], make_state_dict(cfg4, 6)['video_model.temporal_embed'][:, :2])
+
+
+def test_pretrained_tower_ingestion(tmp_path):
+    """model.py:69 / :80-94: a RoBERTa checkpoint (HF names, 'roberta.' prefix, lm_head and pooler present) goes into
+    text_model.*, a timm ViT checkpoint ('module.'-prefixed here, with a classifier head) into video_model.* with strict=False
+    semantics: matching names are loaded, the rest keeps its init, unknown names are ignored, a wrong shape is an error."""
+    import pytest
+    import torch
+    from egovlpv2_amd.config import tiny_config
+    from egovlpv2_amd.model.model import FrozenInTime
+    from egovlpv2_amd.synthetic import make_state_dict
+    cfg = tiny_config()
+    src = make_state_dict(cfg, 11)
+    rob = {'roberta.' + k[len('text_model.'):]: v for k, v in src.items() if k.startswith('text_model.') and 'crossattention' not in k and 'alpha' not in k}
+    rob['lm_head.dense.weight'] = torch.zeros(4, 4)
+    rob['roberta.pooler.dense.weight'] = torch.zeros(cfg.dim, cfg.dim)
+    vit_names = [k for k in src if k.startswith('video_model.') and not any(t in k for t in ('timeattn', 'temporal_embed', 'norm3', 'i2t'))]
+    vit = {'module.' + k[len('video_model.'):]: src[k] for k in vit_names}
+    vit['module.head.weight'] = torch.zeros(10, cfg.dim)
+    torch.save(rob, tmp_path / 'roberta.bin')
+    torch.save(vit, tmp_path / 'vit.pth')
+    vp = {'model': 'SpaceTimeTransformer', 'num_frames': cfg.frames, 'pretrained': True, 'pretrained_path': str(tmp_path / 'vit.pth')}
+    tp = {'model': 'roberta-base', 'pretrained': True, 'input': 'text', 'pretrained_path': str(tmp_path / 'roberta.bin')}
+    base = FrozenInTime({k: v for k, v in vp.items() if k != 'pretrained_path'}, {k: v for k, v in tp.items() if k != 'pretrained_path'},
+                        path_config=cfg, compute_dtype=torch.float32, init_seed=3).state_dict()
+    got = FrozenInTime(vp, tp, path_config=cfg, compute_dtype=torch.float32, init_seed=3).state_dict()
+    loaded = 0
+    for k, v in got.items():
+        from_ckpt = (k.startswith('text_model.') and 'roberta.' + k[len('text_model.'):] in rob and not k.endswith('position_ids')) or k in vit_names
+        if from_ckpt:
+            assert torch.equal(v, src[k]), k
+            loaded += 1
+        else:
+            assert torch.equal(v, base[k]), k                # same seed -> same init as without checkpoints
+    assert loaded > 40
+    bad = dict(vit)
+    bad['module.pos_embed'] = torch.zeros(1, 3, cfg.dim)
+    torch.save(bad, tmp_path / 'bad.pth')
+    with pytest.raises(RuntimeError, match='size mismatch'):
+        FrozenInTime(dict(vp, pretrained_path=str(tmp_path / 'bad.pth')), tp, path_config=cfg, compute_dtype=torch.float32)
