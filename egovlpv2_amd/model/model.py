@@ -256,6 +256,13 @@ class FrozenInTime(nn.Module):
         main = torch.cuda.current_stream()
         if getattr(self, '_side', None) is None or self._side.device != main.device:
             self._side = ops.companion_stream(main.device)
+            # Text-side parameters get their gradients from nodes that ran on the companion stream, while their AccumulateGrad
+            # nodes (kept alive by DDP's reducer) belong to the stream DDP was built on.  The engine orders the two streams before
+            # every accumulation -- that is the documented behaviour this design relies on (see _overlap) -- so the per-step
+            # warning about the mismatch is noise here.
+            warn_off = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
+            if warn_off is not None:
+                warn_off(False)
         side = self._side
         if after is None:
             side.wait_stream(main)
