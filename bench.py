@@ -6,7 +6,7 @@
 
 One "step" = zero_grad + forward (EgoNCE + MLM + ITM, three backbone passes) + backward over one synthetic batch of B
 pairs per GPU at 16 x 224^2 frames / 32 tokens (BASELINE.json configs[2]; `--workload dual` = configs[1], EgoNCE only),
-bf16 storage / fp32 accumulation, weights cast from the fp32 masters inside every timed step, DDP gradient all-reduce
+bf16 storage / fp32 accumulation, weights cast from the fp32 masters inside every timed step, data-parallel gradient all-reduce (flat per-block buffers, or DDP)
 over RCCL for N > 1.  Prints ONE JSON line (rank 0) with the contract fields + `roofline` (dominant kernel: the MFMA GEMM,
 timed with HIP events on its own stream inside the timed region) + `cpu_baseline` (the CPU oracle timed on the host cores).
 """
@@ -125,7 +125,10 @@ def main():
     ap.add_argument('--drop-rate', type=float, default=0.1, help='RoBERTa dropout in the train step (pretrained roberta-base config: 0.1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gemm-events', action='store_true')
-    ap.add_argument('--force-ddp', action='store_true', help='wrap in DDP + RCCL even at world size 1 (test aid)')
+    ap.add_argument('--force-ddp', action='store_true', help='run the data-parallel path (process group, gradient sync) even at world size 1 (test aid)')
+    ap.add_argument('--grad-sync', default='flat', choices=['flat', 'ddp'],
+                    help='world > 1: flat = all-reduce of the per-block flat gradient buffers as they complete (trainer/grad_sync.py); '
+                         'ddp = torch DistributedDataParallel as in the reference')
     a = ap.parse_args()
 
     import torch.distributed as dist
@@ -168,10 +171,14 @@ def main():
     model.load_state_dict(make_state_dict(cfg, 0), strict=True)          # same random-init weights on every rank
     model = model.to(dev)
     net = model
-    if use_dist:
+    gsync = None
+    if use_dist and a.grad_sync == 'ddp':
         from torch.nn.parallel import DistributedDataParallel as DDP
         net = DDP(model, device_ids=[local], static_graph=True, gradient_as_bucket_view=True,
                   find_unused_parameters=False, bucket_cap_mb=64)
+    elif use_dist:
+        from egovlpv2_amd.trainer.grad_sync import FlatGradSync
+        gsync = FlatGradSync(model)               # all-reduce of the flat per-block gradient buffers as they complete
     data, noun, verb = make_batch(cfg, a.batch, a.text_len, 1234 + rank)
     data = {'video': data['video'].to(dev), 'text': {k: v.to(dev) for k, v in data['text'].items()},
             'text_mlm_ids': data['text_mlm_ids'].to(dev), 'text_mlm_labels': data['text_mlm_labels'].to(dev)}
@@ -193,7 +200,10 @@ def main():
         for p in model.parameters():
             p.grad = None
         loss, ld, _ = net(data, noun, verb, AllGather_multi.apply, world, args, conf, loss_fn, local, task_names=tasks)
-        loss.backward()
+        if gsync is not None:
+            gsync.backward(loss)
+        else:
+            loss.backward()
         if optimizer is not None:
             optimizer.step()
             scheduler.step()
@@ -299,7 +309,7 @@ def main():
                "config": {"workload": (("configs[2] full fusion EgoNCE+MLM+ITM" if a.arch == 'base16' else "full fusion EgoNCE+MLM+ITM") if a.workload == 'full' else "configs[1] dual encoder EgoNCE")
                           + (f", ViT-B/16 TimeSformer + RoBERTa-base" if a.arch == 'base16' else ", configs[4] geometry: ViT-L/14 TimeSformer + RoBERTa-large width, bf16 weights")
                           + f", B={a.batch}/GPU, {a.frames}x224^2, {a.text_len} tok",
-                          "global_batch": world * a.batch, "parallelism": f"dp{world}", "drop_rate": a.drop_rate, "timed": "zero_grad + fwd + bwd (+DDP all-reduce), weight cast included" + (" + fused AdamW step" if a.optimizer else "")},
+                          "global_batch": world * a.batch, "parallelism": f"dp{world}", "drop_rate": a.drop_rate, "timed": "zero_grad + fwd + bwd (+ gradient all-reduce: " + (a.grad_sync if use_dist else "none") + "), weight cast included" + (" + fused AdamW step" if a.optimizer else "")},
                # model_tflops: the reference algorithm's matmul FLOPs per pair x pairs/s; executed_tflops leaves
                # out the dead MLM video block and the ITM video prefix shared with the MLM pass (same values, computed once)
                "model_tflops": round(value * fpp / 1e12, 1), "executed_tflops": round(value * fpx / 1e12, 1),

@@ -804,6 +804,14 @@ class _GradPack:
 # parameter and step.  If a backward pass ends with uses outstanding (partial graphs), the pending sums are flushed into .grad.
 _acc = {}
 _acc_cb = [False]
+_pack_hook = [None]
+
+
+def set_pack_hook(fn):
+    """fn(flat, params) is called -- inside backward, on the stream the block ran on -- when the flat fp32 gradient buffer of a
+    block holds the sum over all of the step's uses of that block, just before its views go to autograd (trainer/grad_sync.py
+    starts the data-parallel all-reduce of the buffer there).  None removes the hook."""
+    _pack_hook[0] = fn
 
 
 def _acc_forward(key, needs_grad, fused):
@@ -841,6 +849,8 @@ def _acc_part(k, flat, views, params):
     e['done'] += 1
     if e['done'] >= e['uses']:
         del _acc[k]
+        if _pack_hook[0] is not None:
+            _pack_hook[0](e['flat'], e['params'])
         return e['views']
     if not _acc_cb[0]:
         _acc_cb[0] = True

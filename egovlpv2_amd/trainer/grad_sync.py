@@ -1,0 +1,63 @@
+"""Data-parallel gradient averaging on the flat per-block gradient buffers (the reference wraps the model in
+DistributedDataParallel, base/base_trainer.py:267-269).
+
+DDP sees 557 parameters: its reducer copies / scales every gradient into a bucket with one small kernel per tensor (560 launches
+and 7 ms per step on one MI355X before any byte moves) and all-reduces 64 MB buckets.  The block executor already delivers the
+gradients of a SpaceTimeBlock / RobertaLayer as ONE flat fp32 buffer, complete (summed over the EgoNCE / MLM / ITM uses of the
+block) at a known point of backward.  FlatGradSync all-reduces that buffer in place, asynchronously, the moment it is complete --
+about 50 RCCL calls of 20-57 MB per step, overlapped with the rest of backward, in the same order on every rank (every rank runs
+the same graph) -- and the three dozen tensors outside the blocks (embeddings, heads, projections) after backward.  The average
+comes from scaling the loss by 1 / world before backward (exact in floating point for power-of-two worlds), so no kernel touches
+the gradients besides the collective itself.
+
+    sync = FlatGradSync(model)                 # instead of DistributedDataParallel(model, ...)
+    loss, loss_dict, ret = model(...)
+    sync.backward(loss)                        # = (loss / world).backward() + the collectives
+    optimizer.step()
+
+Parameters must enter backward with p.grad None (optimizer.zero_grad(set_to_none=True), the torch default): the gradient views
+of a flat buffer become p.grad by reference while the collective may still be running on them.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+from .. import hipops as ops
+
+
+class FlatGradSync:
+    def __init__(self, model, group=None):
+        self.model = model
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # EGV_SYNC_FORCE=1 (test aid): issue the collectives even in a one-rank group, to run the RCCL code path on a 1-GPU box
+        self.comm = self.world > 1 or (bool(os.environ.get('EGV_SYNC_FORCE')) and dist.is_available() and dist.is_initialized())
+        self._works = []
+        self._packed = set()
+
+    def _on_pack(self, flat, params):
+        self._packed.update(id(p) for p in params)
+        if self.comm:
+            self._works.append(dist.all_reduce(flat, group=self.group, async_op=True))
+
+    def backward(self, loss):
+        """backward of loss / world with the gradient all-reduces issued as the block buffers complete; returns after every
+        collective has been ordered before the calling stream (RCCL) or finished (gloo)"""
+        for p in self.model.parameters():
+            if p.grad is not None:
+                raise RuntimeError("FlatGradSync.backward: gradients must be None on entry (zero_grad(set_to_none=True))")
+        ops.set_pack_hook(self._on_pack)
+        try:
+            (loss * (1.0 / self.world)).backward()
+        finally:
+            ops.set_pack_hook(None)
+        if self.comm:
+            rest = [p.grad for p in self.model.parameters() if p.grad is not None and id(p) not in self._packed]
+            self._works += [dist.all_reduce(g, group=self.group, async_op=True) for g in rest]
+            for w in self._works:
+                w.wait()
+        self._works.clear()
+        self._packed.clear()

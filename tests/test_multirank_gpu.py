@@ -32,7 +32,7 @@ class _HostGather(torch.autograd.Function):
         return g[ctx.b * ctx.rank: ctx.b * (ctx.rank + 1)], None, None
 
 
-def _worker(rank, world, port, q, steps, overlap):
+def _worker(rank, world, port, q, steps, overlap, gsync='ddp'):
     try:
         if not overlap:
             os.environ['EGV_NO_OVERLAP'] = '1'
@@ -56,8 +56,13 @@ def _worker(rank, world, port, q, steps, overlap):
                          path_config=cfg, task_names='EgoNCE_MLM_ITM', compute_dtype=torch.float32)
         m.load_state_dict({k: v.detach() for k, v in sd.items()}, strict=True)
         m = m.cuda()
-        from torch.nn.parallel import DistributedDataParallel as DDP
-        net = DDP(m, device_ids=[0], static_graph=True, gradient_as_bucket_view=True, find_unused_parameters=False)
+        flat = None
+        if gsync == 'ddp':
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            net = DDP(m, device_ids=[0], static_graph=True, gradient_as_bucket_view=True, find_unused_parameters=False)
+        else:                                              # trainer/grad_sync.py: all-reduce of the flat per-block gradient buffers
+            from egovlpv2_amd.trainer.grad_sync import FlatGradSync
+            net, flat = m, FlatGradSync(m)
         args = types.SimpleNamespace(world_size=world, rank=rank)
         names = [n for n, _ in m.named_parameters()]
         worst = {'loss': 0.0, 'grad': 0.0, 'remote': 0, 'no_remote': 0}
@@ -70,7 +75,10 @@ def _worker(rank, world, port, q, steps, overlap):
             net.zero_grad(set_to_none=True)
             loss, ld, ret = net(dev, noun.cuda(), verb.cuda(), _HostGather.apply, world, args, {'loss': {'type': 'EgoNCE'}},
                                 EgoNCE(), 0, task_names='EgoNCE_MLM_ITM')
-            loss.backward()
+            if flat is not None:
+                flat.backward(loss)
+            else:
+                loss.backward()
             torch.cuda.synchronize()
             # oracle, same rank, same RNG stream, gathers over the same group
             np.random.seed(40 + step + rank)
@@ -106,12 +114,12 @@ def _worker(rank, world, port, q, steps, overlap):
         q.put((rank, 'error', traceback.format_exc()[-3000:]))
 
 
-@pytest.mark.parametrize('overlap', [True, False])
-def test_world2_full_step_vs_oracle(overlap):
+@pytest.mark.parametrize('overlap,gsync', [(True, 'ddp'), (False, 'ddp'), (True, 'flat')])
+def test_world2_full_step_vs_oracle(overlap, gsync):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29900 + (os.getpid() % 90) + (100 if overlap else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, 3, overlap)) for r in range(2)]
+    port = 29900 + (os.getpid() % 90) + (100 if overlap else 0) + (200 if gsync == 'flat' else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, 3, overlap, gsync)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=900) for _ in procs]
