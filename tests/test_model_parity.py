@@ -456,3 +456,31 @@ def test_vit_large_patch14_geometry_vs_oracle(dtype, tol_l, tol_g):
         num += float((a - b).pow(2).sum()); den += float(b.pow(2).sum()); dot += float((a * b).sum()); gg += float(a.pow(2).sum())
     assert math.sqrt(num / den) < tol_g, math.sqrt(num / den)
     assert dot / math.sqrt(gg * den) > (0.9999 if dtype == torch.float32 else 0.99)
+
+
+def test_text_fp32_option_inside_the_bf16_model():
+    """FrozenInTime(compute_dtype=bf16, text_fp32=True): the text-only tower pass runs with fp32 storage (exact-fp32 MFMA) while
+    everything else stays bf16 -- text embeddings at the fp32 mode's accuracy against the reference, the three-loss step still
+    inside the bf16 bounds, gradients finite for every parameter."""
+    from egovlpv2_amd.model.model import FrozenInTime
+    g, cfg, B, L, wseed, bseed = load_golden('tiny')
+    sd, data, noun, verb, oc = oracle_setup(cfg, B, L, wseed, bseed)
+    m = FrozenInTime({'model': 'SpaceTimeTransformer', 'num_frames': cfg.frames, 'pretrained': True},
+                     {'model': 'roberta-base', 'pretrained': True, 'input': 'text'},
+                     path_config=cfg, compute_dtype=torch.bfloat16, text_fp32=True)
+    m.load_state_dict({k: v.detach() for k, v in sd.items()}, strict=True)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        r = m.infer(_to_cuda(data), task_names='EgoNCE')
+    assert r['text_embeds'].dtype == torch.float32
+    assert rel_err(r['text_embeds'], g['text_embeds']) < 1e-4
+    assert rel_err(r['video_embeds'].float(), g['video_embeds']) < 3e-2
+    np.random.seed(17)
+    torch.manual_seed(17)
+    loss, ld, ret = _forward(m, data, noun, verb, 'EgoNCE_MLM_ITM')
+    for k in ('EgoNCE', 'loss_mlm', 'loss_itm', 'loss_total'):
+        ref = float(g['loss_' + k])
+        assert abs(float(ld[k].detach()) - ref) <= 2e-2 * abs(ref), (k, float(ld[k].detach()), ref)
+    loss.backward()
+    for n, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
