@@ -214,8 +214,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        ld = step()
+    for i in range(a.warmup):
+        try:
+            ld = step()
+        except Exception as e:                      # the flat all-reduce path failed on this software stack: fall back to DDP once
+            if gsync is None or i > 0:
+                raise
+            print(f"[bench] flat gradient sync failed ({type(e).__name__}: {e}); falling back to DistributedDataParallel", file=sys.stderr)
+            ops.set_pack_hook(None)
+            ops.begin_step()
+            for p in model.parameters():
+                p.grad = None
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            gsync, a.grad_sync = None, 'ddp'
+            net = DDP(model, device_ids=[local], static_graph=True, gradient_as_bucket_view=True, find_unused_parameters=False, bucket_cap_mb=64)
+            ld = step()
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
