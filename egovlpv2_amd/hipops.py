@@ -245,11 +245,13 @@ def dot(a, b):
 _wg_streams = {}
 
 
-def companion_stream(device):
-    """A stream for work that runs beside the calling stream (weight gradients, the text tower).  HIP priority
-    EGV_SIDE_PRIORITY (default 1 = low: the companions' workgroups only take CUs the calling stream's kernels leave free;
-    0 = a plain torch stream)."""
+def companion_stream(device, kind='wgrad'):
+    """A stream for work that runs beside the calling stream (kind 'wgrad': weight gradients, 'text': the text tower).  HIP
+    priority EGV_SIDE_PRIORITY (default 1 = low: the companions' workgroups only take CUs the calling stream's kernels leave free;
+    0 = a plain torch stream); EGV_TEXT_PRIORITY overrides it for the text stream."""
     prio = int(os.environ.get('EGV_SIDE_PRIORITY', '1'))
+    if kind == 'text' and os.environ.get('EGV_TEXT_PRIORITY') is not None:
+        prio = int(os.environ['EGV_TEXT_PRIORITY'])
     if prio == 0:
         return torch.cuda.Stream(device=device)
     h = C.c_void_p()

@@ -256,7 +256,7 @@ class FrozenInTime(nn.Module):
             return fn(), (lambda: None)
         main = torch.cuda.current_stream()
         if getattr(self, '_side', None) is None or self._side.device != main.device:
-            self._side = ops.companion_stream(main.device)
+            self._side = ops.companion_stream(main.device, 'text')
             # Text-side parameters get their gradients from nodes that ran on the companion stream, while their AccumulateGrad
             # nodes (kept alive by DDP's reducer) belong to the stream DDP was built on.  The engine orders the two streams before
             # every accumulation -- that is the documented behaviour this design relies on (see _overlap) -- so the per-step
