@@ -75,7 +75,7 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, OutT* C, int m
     }
     if (e.gate) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= gate;
+        for (int r = 0; r < 4; ++r) { v[r] *= gate; asm volatile("" : "+v"(v[r])); }   // product rounded on its own in every GEMM kernel: never contracted with the residual add
     }
     if (R1) {
         float x[4] = {0.f, 0.f, 0.f, 0.f};

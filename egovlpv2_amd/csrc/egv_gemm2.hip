@@ -168,7 +168,7 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmArgs g) {
                 }
                 if (e.gate) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] *= gate;
+                    for (int k = 0; k < 8; ++k) { v[k] *= gate; asm volatile("" : "+v"(v[k])); }   // not contracted with the residual add (bit-equal across the GEMM kernels)
                 }
                 if (R1) {
                     const u32x4_t r = *reinterpret_cast<const u32x4_t*>(R1 + ro);

@@ -316,7 +316,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] *= gate;
+                for (int k = 0; k < 8; ++k) { v[k] *= gate; asm volatile("" : "+v"(v[k])); }   // not contracted with the residual add (bit-equal across the GEMM kernels)
                 if (X1K == 1 || X1K == 3) {
                     const u32x4_t r = xop[s][i][t];
 #pragma unroll
@@ -518,10 +518,10 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
     if ((long long)g.M * g.lda >= (1LL << 30) || (long long)g.N * g.ldb >= (1LL << 30)) return 0;   // 32-bit byte offsets
     if ((long long)g.M * g.ldc >= (1LL << 30) || (long long)g.M * e.ldr >= (1LL << 30)) return 0;
     if (e.scale != 1.0f) return 0;                                // the bias rides in as the accumulators' initial value
-    if (e.res2 && (!e.res1 || e.dact || e.act || e.pre)) return 0;
+    if (e.res2 && (!e.res1 || e.dact || e.act)) return 0;             // gated two-residual form; e.pre = the saved pre-gate value
     if (e.res1 && !e.res2 && (e.gate || e.dact || e.act || e.pre)) return 0;
     if (e.dact && (e.act || e.pre)) return 0;
-    if (e.pre && !e.act) return 0;
+    if (e.pre && !e.act && !e.res2) return 0;
     g.tiles_n = (g.N + 255) / 256;
     static int ncu = 0;
     if (!ncu) {
@@ -539,7 +539,7 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
     // tile height: 192-row tiles where they shorten the walk (rounds x tile work, + 6 % for the smaller tile's lower operand
     // reuse); only the plain and the residual epilogue kinds are built for them
     static const bool allow192 = !getenv("EGV_PP_BM192") || atoi(getenv("EGV_PP_BM192")) != 0;
-    const bool kind192 = !e.dact && !e.pre && !e.act && !getenv("EGV_PP_STAMPS");
+    const bool kind192 = !e.dact && (!e.pre || e.res2) && !e.act && !getenv("EGV_PP_STAMPS");
     const int t256 = ((g.M + 255) / 256) * g.tiles_n, t192 = ((g.M + 191) / 192) * g.tiles_n;
     static const double pen192 = getenv("EGV_PP_192_PENALTY") ? atof(getenv("EGV_PP_192_PENALTY")) : 1.06;
     const double c256 = (double)((t256 + ncu - 1) / ncu), c192 = (double)((t192 + ncu - 1) / ncu) * 0.75 * pen192;
@@ -566,22 +566,25 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
     } while (0)
     static const int res_min_k = getenv("EGV_PP_RES_MINK") ? atoi(getenv("EGV_PP_RES_MINK")) : 1536;
     if (e.res1 && g.K < res_min_k && !(use192 && g.K >= res_min_k / 2)) return 0;   // short-K residual GEMMs on 256-row tiles: the 2-workgroup ring kernel hides their epilogue better
-#define PP_LAUNCH192(X)                                                                                                  \
+#define PP_LAUNCH192P(X, P)                                                                                              \
     do {                                                                                                                 \
         static bool attr = false;                                                                                        \
         if (!attr) {                                                                                                     \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<X, false, false, false, 3>),          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<X, P, false, false, 3>),              \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);                               \
             attr = true;                                                                                                 \
         }                                                                                                                \
-        hipLaunchKernelGGL((gemm_pp_kernel<X, false, false, false, 3>), dim3(grid), dim3(512), PP_LDS, st, g, ntiles);   \
+        hipLaunchKernelGGL((gemm_pp_kernel<X, P, false, false, 3>), dim3(grid), dim3(512), PP_LDS, st, g, ntiles);       \
         return 1;                                                                                                        \
     } while (0)
+#define PP_LAUNCH192(X) PP_LAUNCH192P(X, false)
     if (e.res2 && !use192) return 0;                              // gated two-residual form (i2t projection): built for the 192-row tiles only
+    if (use192 && e.res2 && e.pre) PP_LAUNCH192P(3, true);
     if (use192 && e.res2) PP_LAUNCH192(3);
     if (use192 && e.res1) PP_LAUNCH192(1);
     if (use192) PP_LAUNCH192(0);
 #undef PP_LAUNCH192
+#undef PP_LAUNCH192P
     if (e.res1) PP_LAUNCH(1, false, false);
     if (e.dact) PP_LAUNCH(2, false, false);
     if (e.pre) PP_LAUNCH(0, true, true);
