@@ -14,6 +14,7 @@ import torch  # noqa: F401  -- must be imported first: the HIP runtime torch bun
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libegovlp_hip.so')
 
+ABI_VERSION = 2
 EGV_F32, EGV_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 
@@ -51,6 +52,7 @@ class VBlockDesc(C.Structure):
         ('dout', vp), ('dx', vp), ('dy', vp),
         ('dw', vp * 9), ('db', vp * 9), ('dln_g', vp * 4), ('dln_b', vp * 4), ('dalpha', vp),
         ('stream', vp), ('stream2', vp),
+        ('flags', i32),
     ]
 
 
@@ -68,7 +70,17 @@ class TLayerDesc(C.Structure):
         ('dout', vp), ('dhid', vp), ('denc', vp),
         ('dw', vp * 10), ('db', vp * 10), ('dln_g', vp * 2), ('dln_b', vp * 2), ('dalpha', vp),
         ('stream', vp), ('stream2', vp),
+        ('flags', i32),
     ]
+
+
+class WgradProblem(C.Structure):
+    """struct egv_wgrad_problem (include/egovlp_hip.h)"""
+    _fields_ = [('dy', vp), ('ldy', i32), ('x', vp), ('ldx', i32), ('dw', vp), ('db', vp), ('gate', vp), ('N', i32), ('K', i32)]
+
+
+BLOCK_NO_JOIN = 1
+BLOCK_RES_F32 = 2
 
 
 # name -> (restype, argtypes); every symbol declared in include/egovlp_hip.h
@@ -78,6 +90,8 @@ PROTOTYPES = {
     'egv_gemm': (i32, [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     'egv_gemm_wgrad_workspace_bytes': (i64, [i32, i32, i32]),
     'egv_gemm_wgrad': (i32, [i32, i32, i32, i32, vp, i32, vp, i32, vp, vp, f32, vp, vp, i64, vp]),
+    'egv_gemm_wgrad_grouped_workspace_bytes': (i64, [i32, i32, C.POINTER(WgradProblem), i32]),
+    'egv_gemm_wgrad_grouped': (i32, [i32, i32, i32, C.POINTER(WgradProblem), i32, vp, i64, vp]),
     'egv_layernorm_fwd': (i32, [i32, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     'egv_layernorm_bwd_workspace_bytes': (i64, [i32, i32]),
     'egv_layernorm_bwd': (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
@@ -86,6 +100,9 @@ PROTOTYPES = {
     'egv_dot': (i32, [i32, vp, vp, i64, vp, f32, vp, vp]),
     'egv_act_bwd': (i32, [i32, vp, vp, vp, i64, i32, vp]),
     'egv_dropout_add': (i32, [i32, vp, vp, vp, vp, i64, f32, C.c_uint, vp]),
+    'egv_dropout_add_mixed': (i32, [i32, vp, vp, vp, i32, vp, i64, f32, C.c_uint, vp]),
+    'egv_layernorm_fwd_res32': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
+    'egv_layernorm_bwd_res32': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     'egv_cast': (i32, [i32, i32, vp, vp, i64, vp]),
     'egv_cast_transpose': (i32, [vp, vp, i32, i32, vp]),
     'egv_transpose': (i32, [i32, i32, vp, vp, i32, i32, i32, vp]),
@@ -145,7 +162,7 @@ def _load():
         fn = getattr(lib, name)          # AttributeError -> loud failure on a stale library
         fn.restype = res
         fn.argtypes = args
-    if lib.egv_abi_version() != 1:
+    if lib.egv_abi_version() != ABI_VERSION:
         raise ImportError("libegovlp_hip.so ABI version mismatch")
     return lib
 

@@ -17,6 +17,7 @@
 #include "../../include/egovlp_hip.h"
 
 void egv_set_error(const char* fmt, ...);
+void egv_gemm_set_cu_limit(int n);                  // egv_gemm3.hip: CUs the persistent forward / dgrad grids of this thread plan for
 extern "C" int egv_layernorm_bwd2(int dtype, const void* dy, const void* x, const float* stats, const float* gamma,
                                   const void* add, const void* add2, void* dx, float* dgamma, float* dbeta, int M, int D,
                                   void* workspace, void* stream);
@@ -280,6 +281,56 @@ VLayout vlayout(const egv_vblock_desc* d) {
     return L;
 }
 
+// the weight gradients of a block go out as ONE grouped launch (egv_gemm5.hip) at the end of the backward call when the shapes
+// allow it: bf16, D and Hd multiples of 256, enough tokens
+bool vgroup_ok(const egv_vblock_desc* d) {
+    static const bool on = !getenv("EGV_WGRAD_GROUP") || atoi(getenv("EGV_WGRAD_GROUP")) != 0;
+    const long long M = (long long)d->B * (1 + (long long)d->F * d->N);
+    return on && d->dtype == EGV_BF16 && (d->D % 256) == 0 && (d->Hd % 256) == 0 && M >= 4096;
+}
+int device_cus() {
+    static int n = 0;
+    if (!n) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipGetDeviceProperties(&prop, dev);
+        n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return n;
+}
+// CUs granted to the persistent grouped weight-gradient launch of a block when it runs beside the data-gradient chain of the
+// next block: two thirds of a CU per output tile -- the launch is then two phases, one whole tile per workgroup and one half tile
+// per workgroup (one reduction split for a third of the tiles), and takes about as long as that chain on the remaining CUs
+// (measured on configs[2]: 96 of 256 CUs for the 144 tiles of an unfused block; 88 / 104 are 2 / 5 ms per step worse).
+// EGV_WGRAD_CUS overrides.
+int vgroup_cus(const egv_vblock_desc* d) {
+    static const int forced = getenv("EGV_WGRAD_CUS") ? atoi(getenv("EGV_WGRAD_CUS")) : 0;
+    if (forced > 0) return forced;
+    const int tD = d->D / 256, tH = d->Hd / 256;
+    const int ntile = 2 * tD * tH + 2 * tD * tD + 2 * 3 * tD * tD + (d->L > 0 ? 2 * tD * tD : 0);
+    int g = (2 * ntile + 2) / 3;
+    const int cap = device_cus() / 2;
+    return g > cap ? cap : g;
+}
+struct CuLimit {                                    // scoped egv_gemm_set_cu_limit
+    bool on;
+    explicit CuLimit(int n) : on(n > 0) { if (on) egv_gemm_set_cu_limit(n); }
+    ~CuLimit() { if (on) egv_gemm_set_cu_limit(0); }
+};
+long long vgroup_ws_bytes(const egv_vblock_desc* d) {
+    if (!vgroup_ok(d)) return 0;
+    const int M = d->B * (1 + d->F * d->N), D = d->D, Hd = d->Hd;
+    egv_wgrad_problem pr[8];
+    int n = 0;
+    auto add = [&](int N, int K) { pr[n] = egv_wgrad_problem{}; pr[n].N = N; pr[n].K = K; ++n; };
+    add(D, Hd); add(Hd, D); add(D, D); add(3 * D, D); add(D, D); add(3 * D, D);
+    if (d->L > 0) { add(D, D); add(D, D); }
+    const long long b = egv_gemm_wgrad_grouped_workspace_bytes(M, n, pr, vgroup_cus(d));
+    const long long b0 = egv_gemm_wgrad_grouped_workspace_bytes(M, n, pr, (device_cus() * 7) / 8);     // single-stream mode
+    return b > b0 ? b : (b0 > 0 ? b0 : 0);
+}
+
 }  // namespace
 
 extern "C" long long egv_vblock_save_bytes(const egv_vblock_desc* d) { return (long long)vlayout(d).total; }
@@ -300,6 +351,7 @@ extern "C" long long egv_vblock_ws_bytes(const egv_vblock_desc* d, int backward)
         mx(egv_gemm_wgrad_workspace_bytes(3 * (int)D, (int)D, (int)M)); mx(egv_gemm_wgrad_workspace_bytes((int)D, (int)D, (int)M));
         mx(egv_gemm_wgrad_workspace_bytes((int)Hd, (int)D, (int)M)); mx(egv_gemm_wgrad_workspace_bytes((int)D, (int)Hd, (int)M));
         if (d->L > 0) mx(egv_gemm_wgrad_workspace_bytes(2 * (int)D, (int)D, d->B * d->L));
+        mx(vgroup_ws_bytes(d));
         tot += al((size_t)wg) + al((size_t)egv_layernorm_bwd_workspace_bytes((int)M, (int)D));
         tot += al(M * Hd * es) + 8 * al(M * D * es) + 2 * al(M * 3 * D * es) + 3 * al(M * H * 4) + 4096;
         if (d->L > 0) tot += 4 * al(M * D * es) + al((size_t)d->B * d->L * 2 * D * es) + 4096;
@@ -374,6 +426,7 @@ extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
         mx(egv_gemm_wgrad_workspace_bytes(3 * D, D, M)); mx(egv_gemm_wgrad_workspace_bytes(D, D, M));
         mx(egv_gemm_wgrad_workspace_bytes(Hd, D, M)); mx(egv_gemm_wgrad_workspace_bytes(D, Hd, M));
         if (fused) mx(egv_gemm_wgrad_workspace_bytes(2 * D, D, d->B * d->L));
+        mx(vgroup_ws_bytes(d));
     }
     void* wgw = ws.take((size_t)wgb);                       // weight-gradient slabs: the side stream runs them one after another
     void* lnw = ws.take((size_t)egv_layernorm_bwd_workspace_bytes(M, D));
@@ -398,7 +451,27 @@ extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
     }
     void* dotw = ws.take(4096);
     if (!ws.ok()) { egv_set_error("egv_vblock_bwd: workspace too small (%zu > %zu)", ws.off, ws.cap); return -1; }
+    // weight gradients over the M video tokens: collected and launched together at the end of the call (every operand -- saved
+    // activations, scratch, dout -- stays untouched until then), or one launch each on the side stream as soon as ready
+    // Where the weight gradients run:
+    //  * companion stream + EGV_BLOCK_NO_JOIN (the caller joins once per backward pass): ONE persistent grouped launch on a granted
+    //    share of the CUs, started at the end of this call, running beside the NEXT call's data-gradient chain -- whose persistent
+    //    GEMM grids plan for the remaining CUs (a grid planned for CUs it cannot get runs its surplus as a second, nearly empty round);
+    //  * no companion stream: one grouped launch on the calling stream (7/8 of the CUs: the chip-wide rate of this kernel peaks there);
+    //  * companion stream, joined inside the call (DistributedDataParallel, gradient accumulation, hooks): one launch per gradient
+    //    as soon as its operands exist, fp32 slabs + reduction launch (egv_gemm4.hip).
+    const bool side_group = vgroup_ok(d) && fk.forked() && (d->flags & EGV_BLOCK_NO_JOIN);
+    const bool group = vgroup_ok(d) && (side_group || !fk.forked());
+    static const int main_limit = getenv("EGV_WGRAD_MAIN_LIMIT") ? atoi(getenv("EGV_WGRAD_MAIN_LIMIT")) : 0;
+    CuLimit cu_limit(side_group ? (main_limit > 0 ? main_limit : device_cus() - vgroup_cus(d)) : 0);
+    egv_wgrad_problem grp[8];
+    int ngrp = 0;
     auto wgrad = [&](int N, int K, const void* dz, const void* x, int w, const float* gate, int rows) -> int {
+        if (group && rows == M) {
+            egv_wgrad_problem& q = grp[ngrp++];
+            q.dy = dz; q.ldy = N; q.x = x; q.ldx = K; q.dw = d->dw[w]; q.db = d->db[w]; q.gate = gate; q.N = N; q.K = K;
+            return 0;
+        }
         return lin_wgrad(dt, rows, N, K, dz, N, x, d->dw[w], d->db[w], gate, wgw, wgb, fk.begin());
     };
 
@@ -444,7 +517,8 @@ extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
     // dx = LN3'(dh3) + d_sr + d_tr: x feeds norm3, the time residual and the space residual
     BCHK(egv_layernorm_bwd2(dt, dh3, d->x, (const float*)(sv + L.stats3), d->ln_g[VL_NORM3], d_sr, d_tr, d->dx, d->dln_g[VL_NORM3],
                             d->dln_b[VL_NORM3], M, D, lnw, st));
-    fk.join();
+    if (ngrp) BCHK(egv_gemm_wgrad_grouped(dt, M, ngrp, grp, side_group ? vgroup_cus(d) : (device_cus() * 7) / 8, wgw, wgb, fk.begin()));
+    if (!side_group) fk.join();
     return 0;
 }
 
@@ -456,27 +530,33 @@ enum { TW_Q = 0, TW_K, TW_V, TW_AO, TW_FC1, TW_FC2, TW_CQ, TW_CK, TW_CV, TW_CO }
 enum { TL_ATT = 0, TL_OUT };
 
 struct TLayout {
-    size_t q, k, v, ctx, lse, a0, a0d, cq, ck, cv, cctx, lse_c, pg, a_pre, stats0, a, pre, act, f0, f_pre, stats1;
+    size_t q, k, v, ctx, lse, a0, a0d, cq, ck, cv, cctx, lse_c, pg, a_pre, stats0, a, pre, act, f0, f_pre, stats1, hid16, a16;
     size_t total;
 };
+
+// EGV_BLOCK_RES_F32 (bf16 mode only): the residual stream -- layer input / output, the two pre-LayerNorm sums and the output of the
+// attention LayerNorm -- is fp32, GEMM operands and outputs stay bf16 (what torch.autocast does, trainer/trainer_egoclip.py:143)
+inline bool tres32(const egv_tlayer_desc* d) { return (d->flags & EGV_BLOCK_RES_F32) && d->dtype == EGV_BF16; }
 
 TLayout tlayout(const egv_tlayer_desc* d) {
     TLayout L{};
     Bump b(nullptr, 0);
     const size_t es = esz(d->dtype);
+    const size_t rs = tres32(d) ? 4 : es;                       // element size of the residual-stream tensors
     const size_t BL = (size_t)d->B * d->L, BS = (size_t)d->B * d->S, D = d->D, Hd = d->Hd, H = d->H;
     const bool fused = d->S > 0, drop = d->drop_p > 0.f;
     auto T = [&](size_t n) { return b.take_off(n); };
     L.q = T(BL * D * es); L.k = T(BL * D * es); L.v = T(BL * D * es); L.ctx = T(BL * D * es); L.lse = T(BL * H * 4);
-    if (fused || drop) L.a0 = T(BL * D * es);
+    if (fused || drop || tres32(d)) L.a0 = T(BL * D * es);
     if (fused && drop) L.a0d = T(BL * D * es);
     if (fused) {
         L.cq = T(BL * D * es); L.ck = T(BS * D * es); L.cv = T(BS * D * es); L.cctx = T(BL * D * es); L.lse_c = T(BL * H * 4);
         L.pg = T(BL * D * es);
     }
-    L.a_pre = T(BL * D * es); L.stats0 = T(BL * 8); L.a = T(BL * D * es); L.pre = T(BL * Hd * es); L.act = T(BL * Hd * es);
-    if (drop) L.f0 = T(BL * D * es);
-    L.f_pre = T(BL * D * es); L.stats1 = T(BL * 8);
+    L.a_pre = T(BL * D * rs); L.stats0 = T(BL * 8); L.a = T(BL * D * rs); L.pre = T(BL * Hd * es); L.act = T(BL * Hd * es);
+    if (drop || tres32(d)) L.f0 = T(BL * D * es);
+    L.f_pre = T(BL * D * rs); L.stats1 = T(BL * 8);
+    if (tres32(d)) { L.hid16 = T(BL * D * es); L.a16 = T(BL * D * es); }
     L.total = al(b.off);
     return L;
 }
@@ -509,7 +589,7 @@ extern "C" long long egv_tlayer_ws_bytes(const egv_tlayer_desc* d, int backward)
         mx(egv_gemm_wgrad_workspace_bytes((int)D, (int)Hd, (int)BL));
         if (d->S > 0) mx(egv_gemm_wgrad_workspace_bytes((int)D, (int)D, (int)BS));
         tot += al((size_t)wg) + al((size_t)egv_layernorm_bwd_workspace_bytes((int)BL, (int)D));
-        tot += 17 * al(BL * D * es) + al(BL * Hd * es) + 2 * al(BL * H * 4) + 4096;
+        tot += 17 * al(BL * D * es) + 3 * al(BL * D * 4) + al(BL * Hd * es) + 2 * al(BL * H * 4) + 4096;
         if (d->S > 0) tot += 3 * al(BS * D * es) + 4096;
     }
     return (long long)tot + 65536;
@@ -531,12 +611,23 @@ extern "C" int egv_tlayer_fwd(const egv_tlayer_desc* d) {
     if (!ws.ok()) { egv_set_error("egv_tlayer_fwd: workspace too small"); return -1; }
     const long long n = (long long)BL * D;
 
-    BCHK(lin_fwd(dt, BL, D, D, d->hid, d->w[TW_Q], d->b[TW_Q], sv + L.q, 0, nullptr, nullptr, nullptr, nullptr, st));
-    BCHK(lin_fwd(dt, BL, D, D, d->hid, d->w[TW_K], d->b[TW_K], sv + L.k, 0, nullptr, nullptr, nullptr, nullptr, st));
-    BCHK(lin_fwd(dt, BL, D, D, d->hid, d->w[TW_V], d->b[TW_V], sv + L.v, 0, nullptr, nullptr, nullptr, nullptr, st));
+    const bool r32 = tres32(d);
+    // fp32 residual stream: the Linears read a bf16 copy of the (fp32) layer input; every residual sum is formed in fp32 by the
+    // mixed-type dropout/add kernel (p = 0: a plain add) instead of a GEMM epilogue
+    const void* hid_op = d->hid;
+    if (r32) {
+        BCHK(egv_cast(EGV_F32, EGV_BF16, d->hid, sv + L.hid16, n, st));
+        hid_op = sv + L.hid16;
+    }
+    BCHK(lin_fwd(dt, BL, D, D, hid_op, d->w[TW_Q], d->b[TW_Q], sv + L.q, 0, nullptr, nullptr, nullptr, nullptr, st));
+    BCHK(lin_fwd(dt, BL, D, D, hid_op, d->w[TW_K], d->b[TW_K], sv + L.k, 0, nullptr, nullptr, nullptr, nullptr, st));
+    BCHK(lin_fwd(dt, BL, D, D, hid_op, d->w[TW_V], d->b[TW_V], sv + L.v, 0, nullptr, nullptr, nullptr, nullptr, st));
     BCHK(tp.self.fwd(sv + L.q, D, sv + L.k, sv + L.v, D, sv + L.ctx, (float*)(sv + L.lse), aws, tp.awb, st));
     if (!fused) {
-        if (!drop) {
+        if (r32) {
+            BCHK(lin_fwd(dt, BL, D, D, sv + L.ctx, d->w[TW_AO], d->b[TW_AO], sv + L.a0, 0, nullptr, nullptr, nullptr, nullptr, st));
+            BCHK(egv_dropout_add_mixed(EGV_BF16, sv + L.a0, nullptr, (const float*)d->hid, EGV_F32, sv + L.a_pre, n, drop ? p : 0.f, d->seeds[1], st));
+        } else if (!drop) {
             BCHK(lin_fwd(dt, BL, D, D, sv + L.ctx, d->w[TW_AO], d->b[TW_AO], sv + L.a_pre, 0, nullptr, d->hid, nullptr, nullptr, st));   // dense(ctx) + hidden
         } else {
             BCHK(lin_fwd(dt, BL, D, D, sv + L.ctx, d->w[TW_AO], d->b[TW_AO], sv + L.a0, 0, nullptr, nullptr, nullptr, nullptr, st));
@@ -553,7 +644,7 @@ extern "C" int egv_tlayer_fwd(const egv_tlayer_desc* d) {
         BCHK(lin_fwd(dt, BS, D, D, d->enc, d->w[TW_CK], d->b[TW_CK], sv + L.ck, 0, nullptr, nullptr, nullptr, nullptr, st));
         BCHK(lin_fwd(dt, BS, D, D, d->enc, d->w[TW_CV], d->b[TW_CV], sv + L.cv, 0, nullptr, nullptr, nullptr, nullptr, st));
         BCHK(tp.cross.fwd(sv + L.cq, D, sv + L.ck, sv + L.cv, D, sv + L.cctx, (float*)(sv + L.lse_c), aws, tp.awb, st));
-        if (!drop) {
+        if (!drop && !r32) {
             // alpha_t2i * dense(cctx) + a0 + hidden (roberta.py:486-488)
             BCHK(lin_fwd(dt, BL, D, D, sv + L.cctx, d->w[TW_CO], d->b[TW_CO], sv + L.a_pre, 0, d->alpha, a0x, d->hid, sv + L.pg, st));
         } else {
@@ -561,11 +652,23 @@ extern "C" int egv_tlayer_fwd(const egv_tlayer_desc* d) {
             void* y = ws.take((size_t)n * esz(dt));
             if (!ws.ok()) { egv_set_error("egv_tlayer_fwd: workspace too small"); return -1; }
             BCHK(lin_fwd(dt, BL, D, D, sv + L.cctx, d->w[TW_CO], d->b[TW_CO], y, 0, d->alpha, nullptr, nullptr, sv + L.pg, st));
-            BCHK(egv_dropout_add(dt, y, a0x, d->hid, sv + L.a_pre, n, p, d->seeds[3], st));
+            if (r32) BCHK(egv_dropout_add_mixed(EGV_BF16, y, a0x, (const float*)d->hid, EGV_F32, sv + L.a_pre, n, drop ? p : 0.f, d->seeds[3], st));
+            else BCHK(egv_dropout_add(dt, y, a0x, d->hid, sv + L.a_pre, n, p, d->seeds[3], st));
         }
     }
-    BCHK(egv_layernorm_fwd(dt, sv + L.a_pre, sv + L.a, d->ln_g[TL_ATT], d->ln_b[TL_ATT], (float*)(sv + L.stats0), BL, D, d->eps, st));
-    BCHK(lin_fwd(dt, BL, Hd, D, sv + L.a, d->w[TW_FC1], d->b[TW_FC1], sv + L.act, EGV_ACT_GELU, nullptr, nullptr, nullptr, sv + L.pre, st));
+    const void* a_op = sv + L.a;
+    if (r32) {
+        BCHK(egv_layernorm_fwd_res32((const float*)(sv + L.a_pre), (float*)(sv + L.a), sv + L.a16, d->ln_g[TL_ATT], d->ln_b[TL_ATT], (float*)(sv + L.stats0), BL, D, d->eps, st));
+        a_op = sv + L.a16;
+    } else {
+        BCHK(egv_layernorm_fwd(dt, sv + L.a_pre, sv + L.a, d->ln_g[TL_ATT], d->ln_b[TL_ATT], (float*)(sv + L.stats0), BL, D, d->eps, st));
+    }
+    BCHK(lin_fwd(dt, BL, Hd, D, a_op, d->w[TW_FC1], d->b[TW_FC1], sv + L.act, EGV_ACT_GELU, nullptr, nullptr, nullptr, sv + L.pre, st));
+    if (r32) {
+        BCHK(lin_fwd(dt, BL, D, Hd, sv + L.act, d->w[TW_FC2], d->b[TW_FC2], sv + L.f0, 0, nullptr, nullptr, nullptr, nullptr, st));
+        BCHK(egv_dropout_add_mixed(EGV_BF16, sv + L.f0, nullptr, (const float*)(sv + L.a), EGV_F32, sv + L.f_pre, n, drop ? p : 0.f, d->seeds[4], st));
+        return egv_layernorm_fwd_res32((const float*)(sv + L.f_pre), (float*)d->out, nullptr, d->ln_g[TL_OUT], d->ln_b[TL_OUT], (float*)(sv + L.stats1), BL, D, d->eps, st);
+    }
     if (!drop) {
         BCHK(lin_fwd(dt, BL, D, Hd, sv + L.act, d->w[TW_FC2], d->b[TW_FC2], sv + L.f_pre, 0, nullptr, sv + L.a, nullptr, nullptr, st));
     } else {
@@ -622,6 +725,67 @@ extern "C" int egv_tlayer_bwd(const egv_tlayer_desc* d) {
         return egv_gemm(dt, 0, 1, rows, K, N, dz, N, d->w[w], K, dx, K, 0, nullptr, 0, gate, res, nullptr, nullptr, nullptr, 0, K, 1.0f, st);
     };
 
+    const bool r32 = tres32(d);
+    if (r32) {
+        // ---- fp32 residual stream: the gradients of the fp32 tensors (layer output, the two pre-LayerNorm sums, the attention
+        // LayerNorm output, the layer input) are fp32; every GEMM operand is bf16.  The residual-path gradient joins a GEMM's
+        // bf16 data gradient inside the LayerNorm backward (dy16 + dy32) or in a mixed-type add, never in a GEMM epilogue.
+        const size_t nb4 = (size_t)BL * D * 4;
+        float* df_pre32 = (float*)ws.take(nb4);
+        float* da_pre32 = (float*)ws.take(nb4);
+        float* s32 = (float*)ws.take(nb4);
+        if (!ws.ok()) { egv_set_error("egv_tlayer_bwd: workspace too small (%zu > %zu)", ws.off, ws.cap); return -1; }
+        const float pd = drop ? p : 0.f;
+        // out = LN(f_pre): dout is fp32
+        BCHK(egv_layernorm_bwd_res32(nullptr, (const float*)d->dout, (const float*)(sv + L.f_pre), (const float*)(sv + L.stats1), d->ln_g[TL_OUT], nullptr,
+                                     df_pre32, d->dln_g[TL_OUT], d->dln_b[TL_OUT], BL, D, lnw, st));
+        // f_pre = dropout(fc2(act)) + a
+        BCHK(egv_dropout_add_mixed(EGV_F32, df_pre32, nullptr, nullptr, EGV_BF16, df0, n, pd, d->seeds[4], st));
+        BCHK(wgrad(BL, D, Hd, df0, sv + L.act, TW_FC2, nullptr));
+        BCHK(lin_dgrad(dt, BL, D, Hd, df0, d->w[TW_FC2], d->wt[TW_FC2], dpre, nullptr, sv + L.pre, EGV_ACT_GELU, st));
+        BCHK(wgrad(BL, Hd, D, dpre, sv + L.a16, TW_FC1, nullptr));
+        BCHK(lin_dgrad(dt, BL, Hd, D, dpre, d->w[TW_FC1], d->wt[TW_FC1], da, nullptr, nullptr, 0, st));
+        // a = LN(a_pre); its gradient = fc1's data gradient (bf16) + the residual path df_pre (fp32)
+        BCHK(egv_layernorm_bwd_res32(da, df_pre32, (const float*)(sv + L.a_pre), (const float*)(sv + L.stats0), d->ln_g[TL_ATT], nullptr, da_pre32,
+                                     d->dln_g[TL_ATT], d->dln_b[TL_ATT], BL, D, lnw, st));
+        const void* d_ao = da0;
+        if (!fused) {
+            BCHK(egv_dropout_add_mixed(EGV_F32, da_pre32, nullptr, nullptr, EGV_BF16, da0, n, pd, d->seeds[1], st));
+        } else {
+            BCHK(egv_dropout_add_mixed(EGV_F32, da_pre32, nullptr, nullptr, EGV_BF16, dyg, n, pd, d->seeds[3], st));
+            const char* a0x = drop ? sv + L.a0d : sv + L.a0;
+            BCHK(egv_dot(dt, dyg, sv + L.pg, n, d->dalpha, 1.0f, dotw, st));
+            BCHK(wgrad(BL, D, D, dyg, sv + L.cctx, TW_CO, d->alpha));
+            BCHK(lin_dgrad(dt, BL, D, D, dyg, d->w[TW_CO], d->wt[TW_CO], dcctx, d->alpha, nullptr, 0, st));
+            BCHK(tp.cross.bwd(sv + L.cq, D, sv + L.ck, sv + L.cv, D, sv + L.cctx, (float*)const_cast<char*>(sv + L.lse_c), dcctx, dcq, D, dck, dcv, D, delta_c,
+                              aws, tp.awb, st));
+            BCHK(wgrad(BL, D, D, dcq, a0x, TW_CQ, nullptr));
+            BCHK(lin_dgrad(dt, BL, D, D, dcq, d->w[TW_CQ], d->wt[TW_CQ], da0d, nullptr, nullptr, 0, st));
+            BCHK(wgrad(BS, D, D, dck, d->enc, TW_CK, nullptr));
+            BCHK(wgrad(BS, D, D, dcv, d->enc, TW_CV, nullptr));
+            if (d->denc) {
+                BCHK(lin_dgrad(dt, BS, D, D, dck, d->w[TW_CK], d->wt[TW_CK], te, nullptr, nullptr, 0, st));
+                BCHK(dgrad_res(BS, D, D, dcv, TW_CV, d->denc, te, nullptr));
+            }
+            // a0 (after its dropout) feeds the cross-attention query AND the residual: (bf16 data gradient + fp32 da_pre), then the
+            // dropout of attention.output
+            BCHK(egv_dropout_add_mixed(EGV_BF16, da0d, nullptr, da_pre32, EGV_F32, s32, n, 0.f, 0u, st));
+            BCHK(egv_dropout_add_mixed(EGV_F32, s32, nullptr, nullptr, EGV_BF16, da0, n, pd, d->seeds[1], st));
+        }
+        BCHK(wgrad(BL, D, D, d_ao, sv + L.ctx, TW_AO, nullptr));
+        BCHK(lin_dgrad(dt, BL, D, D, d_ao, d->w[TW_AO], d->wt[TW_AO], dctx, nullptr, nullptr, 0, st));
+        BCHK(tp.self.bwd(sv + L.q, D, sv + L.k, sv + L.v, D, sv + L.ctx, (float*)const_cast<char*>(sv + L.lse), dctx, dq, D, dk, dv, D, delta, aws, tp.awb, st));
+        BCHK(wgrad(BL, D, D, dq, sv + L.hid16, TW_Q, nullptr));
+        BCHK(wgrad(BL, D, D, dk, sv + L.hid16, TW_K, nullptr));
+        BCHK(wgrad(BL, D, D, dv, sv + L.hid16, TW_V, nullptr));
+        BCHK(lin_dgrad(dt, BL, D, D, dq, d->w[TW_Q], d->wt[TW_Q], t1, nullptr, nullptr, 0, st));
+        BCHK(dgrad_res(BL, D, D, dk, TW_K, t2, t1, nullptr));
+        BCHK(dgrad_res(BL, D, D, dv, TW_V, t1, t2, nullptr));
+        // dhid (fp32) = data gradients of q / k / v (bf16 sum) + the residual path
+        BCHK(egv_dropout_add_mixed(EGV_BF16, t1, nullptr, da_pre32, EGV_F32, d->dhid, n, 0.f, 0u, st));
+        fk.join();
+        return 0;
+    }
     // out = LN(f_pre)
     BCHK(egv_layernorm_bwd2(dt, d->dout, sv + L.f_pre, (const float*)(sv + L.stats1), d->ln_g[TL_OUT], nullptr, nullptr, df_pre, d->dln_g[TL_OUT],
                             d->dln_b[TL_OUT], BL, D, lnw, st));

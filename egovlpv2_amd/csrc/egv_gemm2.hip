@@ -202,9 +202,12 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmArgs g) {
     }
 }
 
-// tools/gemm_pp_stamps.py: buffer for the per-K-tile timestamps of the EGV_PP_STAMPS instrumentation build of gemm_pp_kernel
+#ifdef EGV_INSTRUMENT
+// instrumentation build only (build.sh EGV_INSTRUMENT=1; tools/gemm_pp_stamps.py): buffer for the per-K-tile timestamps of the
+// STAMPS variant of gemm_pp_kernel.  Neither the symbol nor the variant exists in the release library.
 float* g_timing_buf = nullptr;
 extern "C" int egv_debug_timing(void* buf) { g_timing_buf = (float*)buf; return 0; }
+#endif
 
 template <typename CFG, int NS>
 static void launch_ring(GemmArgs g, hipStream_t st) {

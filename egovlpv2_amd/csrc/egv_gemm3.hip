@@ -447,8 +447,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
         // the second wave row runs one barrier behind the first inside a tile (ping-pong); the skew is applied per tile (and
         // undone by the first row at the tile's end) so that both rows cross the tile boundary together
         if (wr == 1) __builtin_amdgcn_s_barrier();
+#ifdef EGV_INSTRUMENT
 #define PP_STAMP(KT_) do { if (STAMPS && g.colsum && lane == 0 && (wave & 3) == 0 && ts < 4 && (KT_) < 16)                      \
             reinterpret_cast<long long*>(g.colsum)[((blockIdx.x * 2 + wr) * 4 + ts) * 16 + (KT_)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PP_STAMP(KT_) do { } while (0)
+#endif
         PP_STAMP(0);
         const int kb = ts * KT;
         if (ts == 0) {
@@ -506,11 +510,24 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
 }  // namespace egv
 using namespace egv;
 
+// CUs the persistent grids of THIS host thread may plan for (0: all).  The block executor lowers it for the duration of a
+// backward call whose weight gradients run as a persistent launch on a granted share of the chip (egv_gemm5.hip): a grid
+// planned for CUs it cannot get would run its surplus workgroups as a second, nearly empty round.
+static thread_local int g_cu_limit = 0;
+void egv_gemm_set_cu_limit(int n) { g_cu_limit = n; }
+
 // returns 1 if the persistent ping-pong kernel took the call
+#ifdef EGV_INSTRUMENT
 namespace egv { extern float* g_timing_buf; }   // tools/gemm_pp_stamps.py (egv_debug_timing)
+#endif
 int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
     GemmArgs g = gin;
+#ifdef EGV_INSTRUMENT
     g.colsum = egv::g_timing_buf;
+    static const bool stamps = getenv("EGV_PP_STAMPS") != nullptr;     // the STAMPS variant of the plain kind
+#else
+    constexpr bool stamps = false;
+#endif
     const GemmEpi& e = g.e;
     if ((g.K % 64) || g.K < 192 || (g.N % 64) || !g.a_vec_ok || !g.b_vec_ok) return 0;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
@@ -523,7 +540,8 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
     if (e.dact && (e.act || e.pre)) return 0;
     if (e.pre && !e.act && !e.res2) return 0;
     g.tiles_n = (g.N + 255) / 256;
-    static int ncu = 0;
+    static int ncu_dev = 0;
+    int ncu = ncu_dev;
     if (!ncu) {
         hipDeviceProp_t prop;
         int dev = 0;
@@ -533,13 +551,16 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
         // The persistent workgroups own their CU (144 KB LDS, 512 threads x 252 VGPRs): kernels of the text / weight-gradient
         // streams can only run beside them on CUs the grid leaves free.  The grid is trimmed per call (below) to the smallest
         // size that keeps the number of rounds; EGV_PP_CUS caps it (with untrimmed grids 7/8 of the CUs measured best).
-        if (getenv("EGV_PP_CUS")) ncu = (atoi(getenv("EGV_PP_CUS")) / 8) * 8;
+        if (const char* cap = getenv("EGV_PP_CUS")) ncu = (atoi(cap) / 8) * 8;
         if (ncu < 8) ncu = 8;
+        ncu_dev = ncu;
     }
+    const int ncu_all = ncu;
+    if (g_cu_limit > 0 && g_cu_limit < ncu_all) ncu = g_cu_limit >= 8 ? (g_cu_limit / 8) * 8 : 8;
     // tile height: 192-row tiles where they shorten the walk (rounds x tile work, + 6 % for the smaller tile's lower operand
     // reuse); only the plain and the residual epilogue kinds are built for them
     static const bool allow192 = !getenv("EGV_PP_BM192") || atoi(getenv("EGV_PP_BM192")) != 0;
-    const bool kind192 = !e.dact && (!e.pre || e.res2) && !e.act && !getenv("EGV_PP_STAMPS");
+    const bool kind192 = !e.dact && (!e.pre || e.res2) && !e.act && !stamps;
     const int t256 = ((g.M + 255) / 256) * g.tiles_n, t192 = ((g.M + 191) / 192) * g.tiles_n;
     static const double pen192 = getenv("EGV_PP_192_PENALTY") ? atof(getenv("EGV_PP_192_PENALTY")) : 1.06;
     const double c256 = (double)((t256 + ncu - 1) / ncu), c192 = (double)((t192 + ncu - 1) / ncu) * 0.75 * pen192;
@@ -589,7 +610,7 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
     if (e.dact) PP_LAUNCH(2, false, false);
     if (e.pre) PP_LAUNCH(0, true, true);
     if (e.act) PP_LAUNCH(0, false, true);
-    static const bool stamps = getenv("EGV_PP_STAMPS") != nullptr;                       // instrumentation build of the plain kind
+#ifdef EGV_INSTRUMENT
     if (stamps) {
         static bool attr = false;
         if (!attr) {
@@ -599,6 +620,7 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
         hipLaunchKernelGGL((gemm_pp_kernel<0, false, false, true>), dim3(grid), dim3(512), PP_LDS, st, g, ntiles);
         return 1;
     }
+#endif
     PP_LAUNCH(0, false, false);
 #undef PP_LAUNCH
 }

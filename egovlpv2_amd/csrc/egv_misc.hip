@@ -182,25 +182,56 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const long long* __rest
     }
 }
 
-// scatter-add of the embedding gradient (fp32 atomics; rows of the padding index get no gradient, as with
-// nn.Embedding(padding_idx=1) in roberta.py:154,168-171).  dword / dpos must be zero-filled by the caller.
+// Gradient of the embedding tables (rows of the padding index get no gradient, as with nn.Embedding(padding_idx=1) in
+// roberta.py:154,168-171).  No atomics: one wave per token t; the wave whose token is the FIRST occurrence of its word id (or of
+// its position id) owns that table row -- it adds the gradient rows of every token with the same id in token order and writes
+// the sum once, so the result does not depend on scheduling.  dword / dpos must be zero-filled by the caller (untouched rows).
+// B*L is a few hundred tokens: every wave scans the id list (L2-resident) itself; position ids are computed once per
+// workgroup into LDS.
 template <typename T>
 __global__ __launch_bounds__(256) void text_embed_bwd_kernel(const long long* __restrict__ ids, const T* __restrict__ de,
                                                              float* __restrict__ dword, float* __restrict__ dpos, int BL, int L,
                                                              int D, int pad) {
+    extern __shared__ int pids[];                                  // [BL] position id of every token
+    for (int t = threadIdx.x; t < BL; t += blockDim.x) pids[t] = position_id(ids + (long long)(t / L) * L, t % L, pad);
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int tok = blockIdx.x * 4 + wave_id();
     if (tok >= BL) return;
-    const int b = tok / L, l = tok % L;
     const long long id = ids[tok];
-    const int pid = position_id(ids + (long long)b * L, l, pad);
-    for (int c = lane * 4; c < D; c += 256) {
-        float g[4];
-        ld4(de + (long long)tok * D + c, g);
+    const int pid = pids[tok];
+    // table 0: word embeddings keyed by id; table 1: position embeddings keyed by pid
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (id != pad) atomicAdd(dword + id * D + c + e, g[e]);
-            if (pid != pad) atomicAdd(dpos + (long long)pid * D + c + e, g[e]);
+    for (int table = 0; table < 2; ++table) {
+        const long long key = table == 0 ? id : (long long)pid;
+        if (key == pad) continue;                                  // wave-uniform
+        bool first = true;
+        for (int t0 = 0; t0 < tok && first; t0 += 64) {
+            const int t = t0 + lane;
+            const bool same = t < tok && (table == 0 ? ids[t] : (long long)pids[t]) == key;
+            if (__ballot(same)) first = false;
+        }
+        if (!first) continue;
+        float* out = (table == 0 ? dword : dpos) + key * D;
+        for (int cb = 0; cb < D; cb += 256) {                      // wave-uniform loops: every lane takes part in the ballots
+            const int c = cb + lane * 4;
+            const bool live = c < D;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int t0 = tok; t0 < BL; t0 += 64) {
+                const int t = t0 + lane;
+                unsigned long long m = __ballot(t < BL && (table == 0 ? ids[t] : (long long)pids[t]) == key);
+                while (m) {                                        // matching tokens in increasing order
+                    const int j = __builtin_ctzll(m);
+                    m &= m - 1;
+                    if (live) {
+                        float g[4];
+                        ld4(de + (long long)(t0 + j) * D + c, g);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[e] += g[e];
+                    }
+                }
+            }
+            if (live) st4(out + c, acc);
         }
     }
 }
@@ -417,6 +448,33 @@ __global__ void dropout_add_kernel(const T* __restrict__ x, const T* __restrict_
     }
 }
 
+// mixed-type form for the fp32 residual stream of the text tower: y (TY) = keep(i)/(1-p) * x (TX) + r1 (bf16) + r2 (fp32); the keep
+// decision is the one of dropout_add_kernel (same function of seed and element index), so forward (bf16 dense output -> fp32 sum)
+// and backward (fp32 gradient -> bf16 operand of the dense layer's gradients) agree
+template <typename TX, typename TY>
+__global__ void dropout_add_mixed_kernel(const TX* __restrict__ x, const bf16_t* __restrict__ r1, const float* __restrict__ r2, TY* __restrict__ y,
+                                         long long n, float p, unsigned int seed) {
+    const float inv = 1.0f / (1.0f - p);
+    const long long nv = n / 4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+        float v[4], a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
+        ld4(x + i * 4, v);
+        if (r1) ld4(r1 + i * 4, a);
+        if (r2) ld4(r2 + i * 4, b);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float kept = v[e];
+            if (p > 0.f) {
+                const unsigned int h = fmix32_e(seed ^ fmix32_e((unsigned int)(i * 4 + e) * 0x9E3779B1u + 0x7F4A7C15u));
+                const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+                kept = u >= p ? v[e] * inv : 0.f;
+            }
+            o[e] = kept + a[e] + b[e];
+        }
+        st4(y + i * 4, o);
+    }
+}
+
 }  // namespace egv
 using namespace egv;
 
@@ -497,10 +555,12 @@ extern "C" int egv_text_embed_fwd(int dtype, const long long* ids, const float* 
 extern "C" int egv_text_embed_bwd(int dtype, const long long* ids, const void* de, float* dword, float* dpos, int B, int L, int D,
                                   int pad_id, void* stream) {
     dim3 grid((B * L + 3) / 4);
+    EGV_CHECK((D % 4) == 0 && (long long)B * L * 4 <= 64 * 1024, "egv_text_embed_bwd: D must be a multiple of 4 and B*L <= 16384 tokens");
+    const size_t lds = (size_t)B * L * sizeof(int);
     if (dtype == EGV_BF16)
-        hipLaunchKernelGGL(text_embed_bwd_kernel<bf16_t>, grid, dim3(256), 0, EGV_ST, ids, (const bf16_t*)de, dword, dpos, B * L, L, D, pad_id);
+        hipLaunchKernelGGL(text_embed_bwd_kernel<bf16_t>, grid, dim3(256), lds, EGV_ST, ids, (const bf16_t*)de, dword, dpos, B * L, L, D, pad_id);
     else
-        hipLaunchKernelGGL(text_embed_bwd_kernel<float>, grid, dim3(256), 0, EGV_ST, ids, (const float*)de, dword, dpos, B * L, L, D, pad_id);
+        hipLaunchKernelGGL(text_embed_bwd_kernel<float>, grid, dim3(256), lds, EGV_ST, ids, (const float*)de, dword, dpos, B * L, L, D, pad_id);
     EGV_LAUNCH_CHECK();
     return 0;
 }
@@ -565,6 +625,25 @@ extern "C" int egv_act_bwd(int dtype, const void* dy, const void* aux, void* out
         hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3((int)nb), dim3(256), 0, EGV_ST, (const bf16_t*)dy, (const bf16_t*)aux, (bf16_t*)out, n, kind);
     else
         hipLaunchKernelGGL(act_bwd_kernel<float>, dim3((int)nb), dim3(256), 0, EGV_ST, (const float*)dy, (const float*)aux, (float*)out, n, kind);
+    EGV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int egv_dropout_add_mixed(int xtype, const void* x, const void* r1_bf16, const float* r2_f32, int ytype, void* y, long long n, float p,
+                                     unsigned int seed, void* stream) {
+    EGV_CHECK(n % 4 == 0 && p >= 0.f && p < 1.f, "egv_dropout_add_mixed: n %% 4 == 0 and 0 <= p < 1 required");
+    long long nb = (n / 4 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    const bf16_t* r1 = (const bf16_t*)r1_bf16;
+    if (xtype == EGV_BF16 && ytype == EGV_F32)
+        hipLaunchKernelGGL((dropout_add_mixed_kernel<bf16_t, float>), dim3((int)nb), dim3(256), 0, EGV_ST, (const bf16_t*)x, r1, r2_f32, (float*)y, n, p, seed);
+    else if (xtype == EGV_F32 && ytype == EGV_BF16)
+        hipLaunchKernelGGL((dropout_add_mixed_kernel<float, bf16_t>), dim3((int)nb), dim3(256), 0, EGV_ST, (const float*)x, r1, r2_f32, (bf16_t*)y, n, p, seed);
+    else if (xtype == EGV_F32 && ytype == EGV_F32)
+        hipLaunchKernelGGL((dropout_add_mixed_kernel<float, float>), dim3((int)nb), dim3(256), 0, EGV_ST, (const float*)x, r1, r2_f32, (float*)y, n, p, seed);
+    else
+        hipLaunchKernelGGL((dropout_add_mixed_kernel<bf16_t, bf16_t>), dim3((int)nb), dim3(256), 0, EGV_ST, (const bf16_t*)x, r1, r2_f32, (bf16_t*)y, n, p, seed);
     EGV_LAUNCH_CHECK();
     return 0;
 }

@@ -8,10 +8,12 @@ namespace egv {
 
 constexpr int LN_MAXV = 4;   // up to 4 vectors of 4 elements per lane -> D <= 1024
 
+// y2 (optional): a bf16 copy of the output -- the fp32 residual stream of the text tower keeps y in fp32 and feeds the next Linear
+// (a bf16 MFMA GEMM) from the copy
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            float* __restrict__ stats, int M, int D, float eps) {
+                                                            float* __restrict__ stats, int M, int D, float eps, bf16_t* __restrict__ y2 = nullptr) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + wave_id();
     if (row >= M) return;
@@ -56,16 +58,21 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * gamma[c + e] + beta[c + e];
             st4(yr + c, o);
+            if (y2) st4(y2 + (size_t)row * D + c, o);
         }
     }
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  partial dgamma/dbeta per workgroup.
-template <typename T>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+// TD / TX / TA / TO: types of dy, x, the skip gradients and dx (all T in the uniform modes; the fp32 residual stream of the text
+// tower has a bf16 dy -- a data gradient leaving a GEMM -- beside fp32 x / skips / dx).  dy_b (optional, fp32): a second part of
+// the incoming gradient, dy = dy + dy_b.
+template <typename TD, typename TX = TD, typename TA = TD, typename TO = TD>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TD* __restrict__ dy, const TX* __restrict__ x,
                                                             const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                            const T* __restrict__ add, const T* __restrict__ add2, T* __restrict__ dx,
-                                                            float* __restrict__ partial, int M, int D, int rows_per_block) {
+                                                            const TA* __restrict__ add, const TA* __restrict__ add2, TO* __restrict__ dx,
+                                                            float* __restrict__ partial, int M, int D, int rows_per_block,
+                                                            const float* __restrict__ dy_b = nullptr) {
     __shared__ float red[4][2][LN_MAXV * 256];
     const int lane = threadIdx.x & 63;
     const int w = wave_id();
@@ -99,9 +106,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             for (int j = 0; j < LN_MAXV; ++j) {
                 const int c = (j * 64 + lane) * 4;
                 if (c < D) {
-                    float xv[4], dv[4];
+                    float xv[4], dv[4] = {0.f, 0.f, 0.f, 0.f};
                     ld4(x + (size_t)rr * D + c, xv);
-                    ld4(dy + (size_t)rr * D + c, dv);
+                    if (dy) ld4(dy + (size_t)rr * D + c, dv);
+                    if (dy_b) {
+                        float d2[4];
+                        ld4(dy_b + (size_t)rr * D + c, d2);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dv[e] += d2[e];
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) av[u][j][e] = 0.f;
                     if (add) {
@@ -481,6 +494,18 @@ extern "C" int egv_layernorm_fwd(int dtype, const void* x, void* y, const float*
     return 0;
 }
 
+// fp32 residual stream of the text tower in the bf16 mode (bf16 GEMM operands, LayerNorm input / output and residual sums in fp32:
+// what torch.autocast does with nn.LayerNorm, trainer/trainer_egoclip.py:143; roberta.py:336-345, :417-426): y fp32 and, when
+// y16 != NULL, a bf16 copy for the next Linear
+extern "C" int egv_layernorm_fwd_res32(const float* x, float* y, void* y16, const float* gamma, const float* beta, float* stats, int M, int D,
+                                       float eps, void* stream) {
+    EGV_CHECK(D % 4 == 0 && D <= LN_MAXV * 256 && M > 0, "egv_layernorm_fwd_res32: M=%d D=%d unsupported", M, D);
+    hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3((M + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y, gamma, beta, stats,
+                       M, D, eps, (bf16_t*)y16);
+    EGV_LAUNCH_CHECK();
+    return 0;
+}
+
 static inline int ln_bwd_blocks(int M) {
     int nb = (M + 3) / 4;
     static const int cap = getenv("EGV_LN_BLOCKS") ? atoi(getenv("EGV_LN_BLOCKS")) : 512;
@@ -539,6 +564,34 @@ extern "C" int egv_layernorm_bwd2(int dtype, const void* dy, const void* x, cons
                            2 * D, 1.0f, (const float*)nullptr);
         hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 63) / 64), dim3(1024), 0, st, (const float*)partial + D, dbeta, nb2, D,
                            2 * D, 1.0f, (const float*)nullptr);
+    }
+    EGV_LAUNCH_CHECK();
+    return 0;
+}
+
+// dx (fp32) = LN'(dy16 + dy32) + add32 over fp32 x: dy16 (bf16, a data gradient leaving a GEMM) and dy32 (fp32, the residual path)
+// may each be NULL, not both
+extern "C" int egv_layernorm_bwd_res32(const void* dy16, const float* dy32, const float* x, const float* stats, const float* gamma,
+                                       const float* add32, float* dx, float* dgamma, float* dbeta, int M, int D, void* workspace, void* stream) {
+    EGV_CHECK(D % 4 == 0 && D <= LN_MAXV * 256 && (dy16 || dy32), "egv_layernorm_bwd_res32: D=%d unsupported or no gradient", D);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int nb = ln_bwd_blocks(M);
+    const int rpb = (M + nb - 1) / nb;
+    const int nb2 = (M + rpb - 1) / rpb;
+    float* partial = (float*)workspace;
+    if (dy16)
+        hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, float, float, float>), dim3(nb2), dim3(256), 0, st, (const bf16_t*)dy16, x, stats, gamma, add32,
+                           (const float*)nullptr, dx, partial, M, D, rpb, dy32);
+    else
+        hipLaunchKernelGGL((layernorm_bwd_kernel<float, float, float, float>), dim3(nb2), dim3(256), 0, st, dy32, x, stats, gamma, add32,
+                           (const float*)nullptr, dx, partial, M, D, rpb, (const float*)nullptr);
+    EGV_LAUNCH_CHECK();
+    if (dbeta == dgamma + D) {
+        hipLaunchKernelGGL(colsum_partials_kernel, dim3((2 * D + 63) / 64), dim3(1024), 0, st, (const float*)partial, dgamma, nb2, 2 * D, 2 * D, 1.0f,
+                           (const float*)nullptr);
+    } else {
+        hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 63) / 64), dim3(1024), 0, st, (const float*)partial, dgamma, nb2, D, 2 * D, 1.0f, (const float*)nullptr);
+        hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 63) / 64), dim3(1024), 0, st, (const float*)partial + D, dbeta, nb2, D, 2 * D, 1.0f, (const float*)nullptr);
     }
     EGV_LAUNCH_CHECK();
     return 0;

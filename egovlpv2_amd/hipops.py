@@ -17,7 +17,6 @@ import torch
 from torch.autograd import Function
 
 from . import _lib as L
-from . import _lib as L_
 from ._lib import lib, check, AttnDesc
 
 ACT = {'none': L.ACT_NONE, 'gelu': L.ACT_GELU, 'relu': L.ACT_RELU, 'tanh': L.ACT_TANH}
@@ -224,6 +223,28 @@ def wgrad(dy, x, M, N, K, gate=None, scale=1.0, ldy=None, bias=False):
     check(lib.egv_gemm_wgrad(_dt(dy), M, N, K, _p(dy), N if ldy is None else ldy, _p(x), K, _p(dw), _p(db), float(scale),
                              _p(gate), _p(ws), nb, _st()), 'egv_gemm_wgrad')
     return (dw, db) if bias else dw
+
+
+def wgrad_grouped(problems, M, cus=0):
+    """Weight (and bias) gradients of several Linear layers over the same M tokens in ONE launch (egv_gemm_wgrad_grouped):
+    problems = [(dy [M,N] bf16, x [M,K] bf16, want_bias, gate or None), ...]; cus = CUs granted to the persistent launch
+    (0: all); returns [(dW [N,K] fp32, db [N] fp32 or None), ...]"""
+    n = len(problems)
+    arr = (L.WgradProblem * n)()
+    outs = []
+    for i, (dy, x, bias, gate) in enumerate(problems):
+        N, K = dy.shape[1], x.shape[1]
+        dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+        db = torch.empty(N, dtype=torch.float32, device=dy.device) if bias else None
+        arr[i].dy, arr[i].ldy, arr[i].x, arr[i].ldx = _p(dy), dy.stride(0), _p(x), x.stride(0)
+        arr[i].dw, arr[i].db, arr[i].gate, arr[i].N, arr[i].K = _p(dw), _p(db), _p(gate), N, K
+        outs.append((dw, db))
+    nb = lib.egv_gemm_wgrad_grouped_workspace_bytes(M, n, arr, cus)
+    if nb < 0:
+        raise L.EgvError("egv_gemm_wgrad_grouped: unsupported group")
+    ws = workspace(nb, problems[0][0].device, slot=3)
+    check(lib.egv_gemm_wgrad_grouped(L.EGV_BF16, M, n, arr, cus, _p(ws), nb, _st()), 'egv_gemm_wgrad_grouped')
+    return outs
 
 
 def colsum(dy, M, N, gate=None, scale=1.0, ld=None):
@@ -807,70 +828,146 @@ class _GradPack:
 _acc = {}
 _acc_cb = [False]
 _pack_hook = [None]
+_defer_allowed = [True]
+_deferred = {'sides': {}, 'handed': []}
 
 
 def set_pack_hook(fn):
-    """fn(flat, params) is called -- inside backward, on the stream the block ran on -- when the flat fp32 gradient buffer of a
-    block holds the sum over all of the step's uses of that block, just before its views go to autograd (trainer/grad_sync.py
-    starts the data-parallel all-reduce of the buffer there).  None removes the hook."""
+    """fn(flat, params) is called -- inside backward, with the stream current on which the buffer is complete (the calling
+    stream of the block, or its weight-gradient companion when the block's join is deferred) -- when the flat fp32 gradient
+    buffer of a block holds the sum over all of the step's uses of that block, just before its views go to autograd
+    (trainer/grad_sync.py starts the data-parallel all-reduce of the buffer there).  None removes the hook."""
     _pack_hook[0] = fn
 
 
-def _acc_forward(key, needs_grad, fused):
+def set_defer_wgrad_join(on: bool):
+    """Deferred join (default on): a video block's backward call returns while its grouped weight-gradient launch is still
+    running on the companion stream; the calling stream is joined ONCE, at the end of the backward pass.  Only taken when
+    nothing can read the gradients before that: parameters enter backward with .grad None and without tensor hooks, and the
+    model is not running under DistributedDataParallel (whose reducer copies each gradient when it is produced) --
+    FrozenInTime.forward switches it off there."""
+    _defer_allowed[0] = bool(on)
+
+
+def _acc_forward(key, track, fused):
     """key identifies the block; its parameters split into the SHARED set (used by the fused and the unfused form of the block)
-    and the EXTRA set (cross-attention parameters, fused form only): each has its own use count"""
-    if needs_grad:
+    and the EXTRA set (cross-attention parameters, fused form only): each has its own use count.  track: the call was made with
+    grad mode on and a parameter requires grad (decided by the caller of .apply: inside Function.forward grad mode is off and
+    needs_input_grad is True for parameters even under torch.no_grad())."""
+    if track:
         for k in ((key, 0), (key, 1)) if fused else ((key, 0),):
-            e = _acc.setdefault(k, {'uses': 0, 'done': 0, 'flat': None, 'views': None, 'params': None})
+            e = _acc.setdefault(k, {'uses': 0, 'done': 0, 'flat': None, 'views': None, 'params': None, 'side': None})
             e['uses'] += 1
 
 
-def _acc_flush():
+def _backward_done():
+    """end of a backward pass (autograd engine callback): join the deferred weight-gradient streams, flush block gradients whose
+    remaining uses did not take part in this pass, check that autograd kept the views it was handed."""
     _acc_cb[0] = False
-    for key in list(_acc.keys()):
+    cur = torch.cuda.current_stream() if torch.cuda.is_available() else None
+    for side, main in _deferred['sides'].values():
+        main.wait_stream(side)
+        if cur is not None and cur.cuda_stream != main.cuda_stream:
+            cur.wait_stream(side)
+    _deferred['sides'].clear()
+    handed, _deferred['handed'] = _deferred['handed'], []
+    pending = [k for k, e in _acc.items() if e['done'] and e['flat'] is not None]
+    if pending and _pack_hook[0] is not None:
+        _acc.clear()
+        raise RuntimeError("egovlpv2_amd: a backward pass ended with block uses outstanding while a gradient-sync hook is active "
+                           "(the flat per-block buffers would bypass the data-parallel reduction); run backward on the full loss")
+    for key in pending:
         e = _acc[key]
-        if e['done'] and e['flat'] is not None:              # a backward pass ended before every use of the block came back
-            with torch.no_grad():
-                for p, g in zip(e['params'], e['views']):
-                    if p.requires_grad:
-                        p.grad = g.clone() if p.grad is None else p.grad.add_(g)
-            e['uses'] -= e['done']
-            e['done'], e['flat'] = 0, None
-        if e['uses'] <= 0:
-            del _acc[key]
+        with torch.no_grad():
+            for p, g in zip(e['params'], e['views']):
+                if p.requires_grad:
+                    p.grad = g.clone() if p.grad is None else p.grad.add_(g)
+    # uses that did not come back in this pass belong to graph parts that may run in a later backward call: those calls find no
+    # entry and hand their gradients to autograd tensor by tensor (the plain path)
+    _acc.clear()
+    for params, ptrs in handed:
+        for p, ptr in zip(params, ptrs):
+            g = p.grad
+            if g is not None and g.data_ptr() != ptr:
+                raise RuntimeError("egovlpv2_amd: autograd copied a block gradient before the deferred weight-gradient launch had "
+                                   "finished (a hook or an existing .grad on a parameter?); call hipops.set_defer_wgrad_join(False)")
 
 
-def _acc_part(k, flat, views, params):
+def _queue_done():
+    if not _acc_cb[0]:
+        _acc_cb[0] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_backward_done)
+
+
+def _acc_part(k, flat, views, params, side=None):
+    """side: (companion stream, calling stream) when this call's weight gradients are still running on the companion"""
     e = _acc.get(k)
-    if e is None:                                             # forward ran without bookkeeping (should not happen): plain path
+    if e is None:                                             # no bookkeeping for this use (earlier pass flushed it): plain path
+        if side is not None:                                  # nothing may touch the views before the join: join now
+            side[1].wait_stream(side[0])
         return views
     if e['flat'] is None:
-        e['flat'], e['views'], e['params'] = flat, views, params
+        e['flat'], e['views'], e['params'], e['side'] = flat, views, params, side
     else:
-        e['flat'].add_(flat)
+        sd = side or e['side']
+        if sd is not None:                                    # one of the two buffers is still being written on the companion
+            sd[0].wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(sd[0]):
+                e['flat'].add_(flat)
+            flat.record_stream(sd[0])
+            e['flat'].record_stream(sd[0])
+            e['side'] = sd
+        else:
+            e['flat'].add_(flat)
     e['done'] += 1
     if e['done'] >= e['uses']:
         del _acc[k]
+        sd = e['side']
         if _pack_hook[0] is not None:
-            _pack_hook[0](e['flat'], e['params'])
+            if sd is not None:
+                with torch.cuda.stream(sd[0]):
+                    _pack_hook[0](e['flat'], e['params'])
+            else:
+                _pack_hook[0](e['flat'], e['params'])
+        if sd is not None:
+            _deferred['handed'].append((e['params'], [v.data_ptr() for v in e['views']]))   # addresses only: a live reference to a view would make AccumulateGrad copy it
         return e['views']
-    if not _acc_cb[0]:
-        _acc_cb[0] = True
-        torch.autograd.Variable._execution_engine.queue_callback(_acc_flush)
+    _queue_done()
     return [None] * len(params)
 
 
-def _acc_backward(key, pack, params, nshared):
+def _acc_backward(key, pack, params, nshared, side=None):
     ns = sum(p.numel() for p in params[:nshared])
-    out = list(_acc_part((key, 0), pack.flat[:ns], pack.views[:nshared], params[:nshared]))
+    out = list(_acc_part((key, 0), pack.flat[:ns], pack.views[:nshared], params[:nshared], side))
     if len(params) > nshared:
-        out += list(_acc_part((key, 1), pack.flat[ns:], pack.views[nshared:], params[nshared:]))
+        out += list(_acc_part((key, 1), pack.flat[ns:], pack.views[nshared:], params[nshared:], side))
     return out
 
 
-def begin_step():
-    """forget gradient bookkeeping of an aborted step (called at the top of FrozenInTime.forward)"""
-    _acc.clear()
+def begin_step(param_ids=None):
+    """forget gradient bookkeeping of an aborted step (called at the top of FrozenInTime.forward).  param_ids: ids of the
+    calling model's parameters -- only its blocks are forgotten; None: everything."""
+    if param_ids is None:
+        _acc.clear()
+        return
+    for k in [k for k in _acc if k[0][1] in param_ids]:
+        del _acc[k]
+
+
+def _tracks_grad(params):
+    return torch.is_grad_enabled() and any(p.requires_grad for p in params)
+
+
+def _defer_side(params):
+    """(companion stream, calling stream) if this backward call may return before its weight gradients are done, else None"""
+    if not _defer_allowed[0] or os.environ.get('EGV_NO_OVERLAP') or os.environ.get('EGV_WGRAD_DEFER', '1') == '0':
+        return None
+    for p in params:
+        if p.grad is not None or p._backward_hooks or getattr(p, '_post_accumulate_grad_hooks', None):
+            return None
+    cur = torch.cuda.current_stream()
+    st = _wg_streams.get((cur.device.index, cur.cuda_stream))
+    return None if st is None else (st, cur)
 
 
 class VideoBlockFn(Function):
@@ -880,10 +977,10 @@ class VideoBlockFn(Function):
 
     @staticmethod
     def _desc(cfg, x, y, y_mask, params):
-        B, Fr, N, H, Hd, eps, L = cfg
-        fused = L > 0
-        d = L_.VBlockDesc()
-        d.dtype, d.B, d.F, d.N, d.H, d.D, d.Hd, d.L, d.eps = _dt(x), B, Fr, N, H, x.shape[1], Hd, L, eps
+        B, Fr, N, H, Hd, eps, L_, _track = cfg
+        fused = L_ > 0
+        d = L.VBlockDesc()
+        d.dtype, d.B, d.F, d.N, d.H, d.D, d.Hd, d.L, d.eps = _dt(x), B, Fr, N, H, x.shape[1], Hd, L_, eps
         d.x = _p(x)
         nw = 9 if fused else 6
         ws = [params[2 * i] for i in range(6)] + ([params[18 + 2 * i] for i in range(3)] if fused else [])
@@ -913,7 +1010,7 @@ class VideoBlockFn(Function):
         check(lib.egv_vblock_fwd(C.byref(d)), 'egv_vblock_fwd')
         ctx.cfg = cfg
         ctx.key = ('v', id(params[0]))
-        _acc_forward(ctx.key, any(ctx.needs_input_grad[4:]), cfg[6] > 0)
+        _acc_forward(ctx.key, cfg[7], cfg[6] > 0)
         ctx.save_for_backward(x, y, y_mask, save, *params)
         return out
 
@@ -943,12 +1040,23 @@ class VideoBlockFn(Function):
             d.dln_g[3], d.dln_b[3] = _p(g[24]), _p(g[25])
             d.dalpha = _p(g[26])
         d.stream2 = _side_stream_ptr()
+        side = _defer_side(params) if d.stream2 else None
+        if side is not None:
+            # the grouped weight-gradient launch of this call keeps running on the companion stream after the call returns:
+            # everything it reads or writes must outlive it in the caching allocator, and the calling stream is joined at the
+            # end of the backward pass (_backward_done)
+            d.flags = L.BLOCK_NO_JOIN
+            for t in (ws, save, dout, gp.flat, y):
+                if t is not None:
+                    t.record_stream(side[0])
+            _deferred['sides'][side[0].cuda_stream] = side
+            _queue_done()
         check(lib.egv_vblock_bwd(C.byref(d)), 'egv_vblock_bwd')
-        return (None, dx, dy, None, *_acc_backward(ctx.key, gp, params, 18))
+        return (None, dx, dy, None, *_acc_backward(ctx.key, gp, params, 18, side))
 
 
 def video_block(x, params, B, Fr, N, H, Hd, eps, y=None, y_mask=None, L=0):
-    return VideoBlockFn.apply((B, Fr, N, H, Hd, float(eps), L if y is not None else 0), x, y, y_mask, *params)
+    return VideoBlockFn.apply((B, Fr, N, H, Hd, float(eps), L if y is not None else 0, _tracks_grad(params)), x, y, y_mask, *params)
 
 
 class TextLayerFn(Function):
@@ -958,17 +1066,19 @@ class TextLayerFn(Function):
 
     @staticmethod
     def _desc(cfg, hid, mask, enc, params):
-        B, Lt, H, Hd, eps, S, p, seeds = cfg
+        B, Lt, H, Hd, eps, S, p, seeds, _track, res32 = cfg
         fused = S > 0
-        d = L_.TLayerDesc()
-        d.dtype, d.B, d.L, d.H, d.D, d.Hd, d.S, d.eps, d.drop_p = _dt(hid), B, Lt, H, hid.shape[1], Hd, S, eps, p
+        d = L.TLayerDesc()
+        d.dtype, d.B, d.L, d.H, d.D, d.Hd, d.S, d.eps, d.drop_p = (L.EGV_BF16 if res32 else _dt(hid)), B, Lt, H, hid.shape[1], Hd, S, eps, p
+        if res32:
+            d.flags = L.BLOCK_RES_F32
         for i, sd in enumerate(seeds):
             d.seeds[i] = sd & 0xFFFFFFFF
         d.hid, d.mask = _p(hid), _p(mask)
         nw = 10 if fused else 6
         ws = [params[2 * i] for i in range(6)] + ([params[16 + 2 * i] for i in range(4)] if fused else [])
         bs = [params[2 * i + 1] for i in range(6)] + ([params[17 + 2 * i] for i in range(4)] if fused else [])
-        _fill_weights(d, ws, hid.dtype)
+        _fill_weights(d, ws, torch.bfloat16 if res32 else hid.dtype)
         for i in range(nw):
             d.b[i] = _p(bs[i])
         for i in range(2):
@@ -992,7 +1102,7 @@ class TextLayerFn(Function):
         check(lib.egv_tlayer_fwd(C.byref(d)), 'egv_tlayer_fwd')
         ctx.cfg = cfg
         ctx.key = ('t', id(params[0]))
-        _acc_forward(ctx.key, any(ctx.needs_input_grad[4:]), cfg[5] > 0)
+        _acc_forward(ctx.key, cfg[8], cfg[5] > 0)
         ctx.save_for_backward(hid, mask, enc, save, *params)
         return out
 
@@ -1005,6 +1115,8 @@ class TextLayerFn(Function):
         d = TextLayerFn._desc(cfg, hid, mask, enc, params)
         dhid = torch.empty_like(hid)
         denc = torch.empty_like(enc) if (fused and ctx.needs_input_grad[3]) else None
+        if cfg[9] and dout.dtype != torch.float32:
+            dout = dout.float()
         gp = _GradPack(params, hid.device)
         nwsb = lib.egv_tlayer_ws_bytes(C.byref(d), 1)
         ws = torch.empty(nwsb, dtype=torch.uint8, device=hid.device)
@@ -1024,8 +1136,13 @@ class TextLayerFn(Function):
         return (None, dhid, None, denc, *_acc_backward(ctx.key, gp, params, 16))
 
 
-def text_layer(hid, mask, params, B, Lt, H, Hd, eps, enc=None, S=0, drop_p=0.0, seeds=(0, 0, 0, 0, 0, 0)):
-    return TextLayerFn.apply((B, Lt, H, Hd, float(eps), S if enc is not None else 0, float(drop_p), tuple(seeds)), hid, mask, enc, *params)
+def text_layer(hid, mask, params, B, Lt, H, Hd, eps, enc=None, S=0, drop_p=0.0, seeds=(0, 0, 0, 0, 0, 0), res32=False):
+    """res32: hid (and the result) are the fp32 residual stream of a bf16 model -- bf16 GEMM operands, fp32 LayerNorm in / out and
+    residual sums (EGV_BLOCK_RES_F32); enc stays bf16"""
+    if res32:
+        assert hid.dtype == torch.float32 and (enc is None or enc.dtype == torch.bfloat16)
+    return TextLayerFn.apply((B, Lt, H, Hd, float(eps), S if enc is not None else 0, float(drop_p), tuple(seeds), _tracks_grad(params), bool(res32)),
+                             hid, mask, enc, *params)
 
 
 # ---- patch embedding + CLS + positional / temporal embedding ------------------------------------------------

@@ -147,6 +147,9 @@ class FrozenInTime(nn.Module):
         self.num_text_layer = self.cfg.depth
         self.compute_dtype = compute_dtype
         self.text_fp32 = bool(text_fp32) or os.environ.get('EGV_TEXT_FP32', '0') == '1'
+        # bf16 mode: the text tower's residual stream (LayerNorm inputs / outputs, residual sums) stays fp32 between bf16 GEMMs, as under
+        # torch.autocast (trainer/trainer_egoclip.py:143); EGV_TEXT_RES32=0 stores it in bf16 like the video tower's
+        self.text_res32 = compute_dtype == torch.bfloat16 and os.environ.get('EGV_TEXT_RES32', '1') != '0'
         self.patches_per_frame = self.cfg.n_patches
 
         gen = torch.Generator().manual_seed(init_seed)
@@ -169,8 +172,8 @@ class FrozenInTime(nn.Module):
             self.load_pretrained_vit(vpath)
 
         if load_checkpoint not in ["", None]:
-            # reference checkpoints pickle a ConfigParser under 'config' (base_trainer.py:412-436): weights_only must be off
-            checkpoint = torch.load(load_checkpoint, map_location='cpu', weights_only=False)
+            from ..utils.checkpoint import load_checkpoint_file
+            checkpoint = load_checkpoint_file(load_checkpoint)
             state_dict = checkpoint['state_dict']
             new_state_dict = state_dict_data_parallel_fix(state_dict, self.state_dict())
             new_state_dict = self._inflate_positional_embeds(new_state_dict)
@@ -402,7 +405,7 @@ class FrozenInTime(nn.Module):
         """additive (B, L) fp32 key mask: (1 - m) * finfo(fp32).min (get_extended_attention_mask, roberta.py:826)."""
         return ((1.0 - attention_mask.to(torch.float32)) * F32_MIN).contiguous()
 
-    def _text_layer(self, hid, mask, i, B, L, enc=None):
+    def _text_layer(self, hid, mask, i, B, L, enc=None, exact=False):
         """RobertaLayer.forward (roberta.py:444-505); enc = video tokens (B*S, d) for the fused layers.  One C-ABI call forward,
         one backward.  Train mode: dropout on the attention probabilities (roberta.py:313) inside the attention kernels and on
         every dense output before its residual add (:342, :422); one seed per site, drawn here in the sites' order."""
@@ -415,8 +418,16 @@ class FrozenInTime(nn.Module):
             if fused:
                 seeds[2], seeds[3] = self._drop_seed(), self._drop_seed()
             seeds[4] = self._drop_seed()
+        res32 = self.text_res32 and hid.dtype == torch.float32 and not (self.text_fp32 and exact)
         return ops.text_layer(hid, mask, self._block_params('text', i, fused), B, L, c.heads, c.dim * c.mlp_ratio, c.eps_text,
-                              enc=enc, S=c.seq if fused else 0, drop_p=p, seeds=seeds)
+                              enc=enc, S=c.seq if fused else 0, drop_p=p, seeds=seeds, res32=res32)
+
+    def _text_operand(self, t, exact_ok=False):
+        """text states as a GEMM / attention operand outside the text layers (projection heads, the video blocks' image-to-text
+        keys): the fp32 residual stream is rounded to the compute dtype there, as autocast rounds a Linear's input"""
+        if t.dtype == self.compute_dtype or (exact_ok and self.text_fp32):
+            return t
+        return ops.CastFn.apply(t, self.compute_dtype)
 
     def _text_dtype(self):
         """Storage type of the TEXT-ONLY tower pass (compute_text / compute_text_tokens: the EgoNCE text embedding).  Option
@@ -425,7 +436,7 @@ class FrozenInTime(nn.Module):
         +5.5 ms per step (the pass is 256 token rows, but its fp32 GEMMs take 60-100 us instead of 17 and make the companion
         stream the long pole of the EgoNCE backward).  The fused passes (MLM / ITM), whose text side exchanges tokens with the bf16
         video side every layer, stay in the compute dtype.  Off by default."""
-        return torch.float32 if self.text_fp32 else self.compute_dtype
+        return torch.float32 if (self.text_fp32 or self.text_res32) else self.compute_dtype
 
     # ------------------------------------------------------------------ reference API
     def compute_text(self, text_data):
@@ -435,8 +446,8 @@ class FrozenInTime(nn.Module):
         hid = self._text_embeddings(ids, self._text_dtype())
         mask = self._key_mask(am)
         for i in range(self.cfg.depth):
-            hid = self._text_layer(hid, mask, i, B, L)
-        return self._proj_mlp(self._cls_rows(hid, B, L), 'txt_proj')
+            hid = self._text_layer(hid, mask, i, B, L, exact=True)
+        return self._proj_mlp(self._text_operand(self._cls_rows(hid, B, L), exact_ok=True), 'txt_proj')
 
     def compute_text_tokens(self, text_data):
         """model.py:507-522: all token states -> txt_proj."""
@@ -445,8 +456,8 @@ class FrozenInTime(nn.Module):
         hid = self._text_embeddings(ids, self._text_dtype())
         mask = self._key_mask(am)
         for i in range(self.cfg.depth):
-            hid = self._text_layer(hid, mask, i, B, L)
-        return self._proj_mlp(hid, 'txt_proj').reshape(B, L, -1)
+            hid = self._text_layer(hid, mask, i, B, L, exact=True)
+        return self._proj_mlp(self._text_operand(hid, exact_ok=True), 'txt_proj').reshape(B, L, -1)
 
     def _video_features(self, video_data):
         B = video_data.shape[0]
@@ -472,7 +483,7 @@ class FrozenInTime(nn.Module):
         """embeddings + the depth - n_fuse unfused RoBERTa layers (model.py:247-257); returns (hidden, additive key mask)"""
         B, L = input_ids.shape
         mask = self._key_mask(attention_mask)
-        t = self._text_embeddings(input_ids)
+        t = self._text_embeddings(input_ids, torch.float32 if self.text_res32 else None)
         for i in range(self.cfg.depth - self.cfg.n_fuse):
             t = self._text_layer(t, mask, i, B, L)
         return t, mask
@@ -501,7 +512,7 @@ class FrozenInTime(nn.Module):
                 ev = torch.cuda.Event()
                 ev.record()                                                   # v (and t, joined above) are ready here
             t_new, join = self._fork_text(lambda: self._text_layer(t, mask, i, B, L, enc=v), uses=(v, mask), after=ev)
-            v_new = None if (last and not need_video_out) else self._video_block(v, i, B, y=t, y_mask=mask, L=L)
+            v_new = None if (last and not need_video_out) else self._video_block(v, i, B, y=self._text_operand(t), y_mask=mask, L=L)
             join()
             v, t = v_new, t_new
         return v, t
@@ -526,7 +537,7 @@ class FrozenInTime(nn.Module):
             v, t = self._fused_stack(video_data, text_data['input_ids'], text_data['attention_mask'],
                                      video_prefix=data.get('_video_prefix'), text_prefix=data.get('_text_prefix'))
             vf = self._ln(self._cls_rows(v, B, c.seq), 'norm', c.eps_model_norm)            # self.norm(v)[:, 0]  (:275)
-            tf = self._lin(self._cls_rows(t, B, L), 'cross_modal_text_transform')
+            tf = self._lin(self._text_operand(self._cls_rows(t, B, L)), 'cross_modal_text_transform')
             vf = self._lin(vf, 'cross_modal_video_transform')
             ct = self._lin(tf, 'cross_modal_text_pooler.dense', act='tanh')
             cv = self._lin(vf, 'cross_modal_video_pooler.dense', act='tanh')
@@ -545,16 +556,27 @@ class FrozenInTime(nn.Module):
         c = self.cfg
         _, t = self._fused_stack(video, mlm_ids, attention_mask, need_video_out=False, video_prefix=video_prefix,
                                  text_prefix=text_prefix)
-        t = self._lin(t, 'cross_modal_text_transform')
+        t = self._lin(self._text_operand(t), 'cross_modal_text_transform')
         t = self._lin(t, 'mlm_score.transform.dense', act='gelu')
         t = self._ln(t, 'mlm_score.transform.LayerNorm', c.eps_mlm)
         return ops.vocab_linear(t, self.p('mlm_score.decoder.weight'), self.p('mlm_score.bias'), c.vocab)
+
+    def _begin_step(self):
+        """per-step gradient bookkeeping of the block executor (hipops): forget what an aborted step left behind"""
+        ids = self.__dict__.get('_param_ids')
+        if ids is None:
+            ids = self.__dict__['_param_ids'] = frozenset(id(p) for p in self.parameters())
+        ops.begin_step(ids)
+        # under DistributedDataParallel the reducer copies every gradient the moment autograd produces it: the block backward
+        # calls must then join their weight-gradient stream before they return (hipops.set_defer_wgrad_join)
+        ddp = getattr(torch.nn.parallel.DistributedDataParallel, '_active_ddp_module', None)
+        ops.set_defer_wgrad_join(ddp is None)
 
     def forward(self, data, n_embeds, v_embeds, allgather, n_gpu, args, config, loss_egonce, gpu, return_embeds=True,
                 task_names='EgoNCE_ITM_MLM'):
         """model.py:370-487.  Returns (loss, loss_dict, ret)."""
         ret, loss_dict = {}, {}
-        ops.begin_step()
+        self._begin_step()
         if 'Feature_Extraction' in task_names:                                                   # :375-377
             return self.compute_video(data['video'])
         world = getattr(args, 'world_size', 1)
@@ -623,7 +645,9 @@ class FrozenInTime(nn.Module):
             logits = ret.pop('_mlm_logits_padded')
             labels = data['text_mlm_labels'].reshape(-1)
             ce_sum = ops.cross_entropy_sum(logits, labels, c.vocab, -100)
-            cnt = (labels != -100).sum().to(torch.float32)
+            # labels outside [0, vocab) other than the ignore index are skipped by the CE kernels (they cannot index the logits):
+            # count exactly the labels that contribute, so that a collator / vocabulary mismatch cannot mis-normalise the loss
+            cnt = ((labels >= 0) & (labels < c.vocab)).sum().to(torch.float32)
             # the reference all-gathers the (B*L, 50265) logits (412 MB at W=8) and takes the global mean; gathering the
             # two per-rank scalars gives the identical loss and, through AllGather_multi.backward, identical gradients.
             tot = gather(torch.stack([ce_sum, cnt]).reshape(1, 2))

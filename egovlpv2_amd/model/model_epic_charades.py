@@ -39,7 +39,7 @@ class FrozenInTime(_PretrainModel):
         """model_epic_charades.py:410-444.  Returns (loss, loss_dict, ret)."""
         ret, loss_dict = {}, {}
         loss = None
-        ops.begin_step()
+        self._begin_step()
         if 'Dual' in task_names:
             ret = self.infer(data, task_names='Dual')
             video_embeds = allgather(ops.CastFn.apply(ret['video_embeds'], torch.float32), n_gpu, args)

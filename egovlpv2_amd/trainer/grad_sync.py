@@ -37,9 +37,12 @@ class FlatGradSync:
         self.comm = self.world > 1 or (bool(os.environ.get('EGV_SYNC_FORCE')) and dist.is_available() and dist.is_initialized())
         self._works = []
         self._packed = set()
+        self._flats = []
 
     def _on_pack(self, flat, params):
+        # called with the stream current on which `flat` is complete (hipops.set_pack_hook): the collective is ordered after it
         self._packed.update(id(p) for p in params)
+        self._flats.append((flat, params))
         if self.comm:
             self._works.append(dist.all_reduce(flat, group=self.group, async_op=True))
 
@@ -52,12 +55,23 @@ class FlatGradSync:
         ops.set_pack_hook(self._on_pack)
         try:
             (loss * (1.0 / self.world)).backward()
+            if self.comm:
+                rest = [p.grad for p in self.model.parameters() if p.grad is not None and id(p) not in self._packed]
+                self._works += [dist.all_reduce(g, group=self.group, async_op=True) for g in rest]
+                for w in self._works:
+                    w.wait()
+            # The collectives ran IN PLACE on the flat buffers: that reaches p.grad only if autograd kept the views it was handed
+            # (AccumulateGrad steals a gradient by reference when .grad is None, nothing else holds it and no hook is
+            # registered).  A copy made instead would hold the un-reduced local values: check, do not assume.
+            for flat, params in self._flats:
+                lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()
+                for p in params:
+                    g = p.grad
+                    if g is not None and not (lo <= g.data_ptr() < hi):
+                        raise RuntimeError("FlatGradSync: autograd copied a block gradient instead of keeping the view of the flat "
+                                           "buffer (a hook or a live reference on a parameter gradient?): the copy is not reduced")
         finally:
             ops.set_pack_hook(None)
-        if self.comm:
-            rest = [p.grad for p in self.model.parameters() if p.grad is not None and id(p) not in self._packed]
-            self._works += [dist.all_reduce(g, group=self.group, async_op=True) for g in rest]
-            for w in self._works:
-                w.wait()
-        self._works.clear()
-        self._packed.clear()
+            self._works.clear()
+            self._packed.clear()
+            self._flats.clear()

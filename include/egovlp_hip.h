@@ -68,6 +68,24 @@ int egv_gemm_wgrad(int dtype, int M, int N, int K, const void* dY, int ldy, cons
                    float* dW, float* dbias, float scale, const float* gate, void* workspace, long long workspace_bytes,
                    void* stream);
 
+/* Grouped weight gradients: the dW / db of SEVERAL Linear layers over the same M tokens in ONE launch (bf16 operands; N and K
+ * multiples of 256; autograd of video_transformer.py:53,56,120,152,166,183 for one SpaceTimeBlock).  With all tiles of a block in
+ * one launch two to four reduction splits fill the chip; the splits of a tile are summed INSIDE the launch, in split order
+ * (deterministic), by the tile's last arriver -- no slab round trip, no reduction launch.  dw[N,K] (row pitch K) and db[N] (may
+ * be NULL) are fp32 and scaled by *gate when gate != NULL.  cus: the launch is PERSISTENT with at most `cus` workgroups (one per
+ * CU; <= 0: all CUs): a caller that runs it beside other work grants it a share of the chip instead of letting long-running
+ * workgroups take every CU that falls free; with at least `cus` tiles in the group there are no reduction splits at all. */
+typedef struct egv_wgrad_problem {
+    const void* dy; int ldy;            /* [M, N], row pitch ldy elements */
+    const void* x; int ldx;             /* [M, K] */
+    float* dw; float* db;
+    const float* gate;
+    int N, K;
+} egv_wgrad_problem;
+long long egv_gemm_wgrad_grouped_workspace_bytes(int M, int nprob, const egv_wgrad_problem* problems, int cus);   /* -1: group not supported */
+int egv_gemm_wgrad_grouped(int dtype, int M, int nprob, const egv_wgrad_problem* problems, int cus, void* workspace,
+                           long long workspace_bytes, void* stream);
+
 /* ---- LayerNorm (video_transformer.py:196,207,210,304,115; roberta.py:160,336,417; model.py:155;
  * BertPredictionHeadTransform.LayerNorm heads.py:41).  stats = [M][2] fp32 {mean, rstd} (may be NULL in
  * inference).  bwd: dx = LN'(dy) (+ add if not NULL); dgamma/dbeta fp32 [D]. */
@@ -88,6 +106,17 @@ int egv_act_bwd(int dtype, const void* dy, const void* aux, void* out, long long
 /* hidden-state dropout fused with the residual adds it feeds (roberta.py:203,342,422): y = keep(i)/(1-p) * x + r1 + r2;
  * the backward of x is the same call on dy with r1 = r2 = NULL.  mask = counter-based function of (seed, element index). */
 int egv_dropout_add(int dtype, const void* x, const void* r1, const void* r2, void* y, long long n, float p, unsigned int seed, void* stream);
+/* ---- fp32 residual stream of the text tower inside the bf16 mode: bf16 GEMM operands and outputs, LayerNorm input / output and the
+ * residual sums in fp32 -- what torch.autocast does (trainer/trainer_egoclip.py:143) with roberta.py:336-345, :417-426.
+ * dropout_add_mixed: y (ytype) = keep(i)/(1-p) * x (xtype) + r1 (bf16, may be NULL) + r2 (fp32, may be NULL), same mask function as
+ * egv_dropout_add.  layernorm_fwd_res32: y fp32 and (y16 != NULL) its bf16 copy, the next Linear's operand.  layernorm_bwd_res32:
+ * dx (fp32) = LN'(dy16 + dy32) + add32; dy16 bf16 / dy32 fp32 may each be NULL (not both), add32 may be NULL. */
+int egv_dropout_add_mixed(int xtype, const void* x, const void* r1_bf16, const float* r2_f32, int ytype, void* y, long long n, float p,
+                          unsigned int seed, void* stream);
+int egv_layernorm_fwd_res32(const float* x, float* y, void* y16, const float* gamma, const float* beta, float* stats, int M, int D,
+                            float eps, void* stream);
+int egv_layernorm_bwd_res32(const void* dy16, const float* dy32, const float* x, const float* stats, const float* gamma,
+                            const float* add32, float* dx, float* dgamma, float* dbeta, int M, int D, void* workspace, void* stream);
 int egv_cast(int dtype_src, int dtype_dst, const void* src, void* dst, long long n, void* stream);
 /* dst[C][R] (bf16) = src[R][C] (fp32): transposed bf16 compute copy of a weight, so that dgrad runs in the NT form */
 int egv_cast_transpose(const float* src, void* dst, int R, int C, void* stream);
@@ -200,7 +229,9 @@ int egv_adamw_step(const void* table, const int* prefix, int ntensors, int nchun
  * ~4 600.  save/ws: caller-allocated, sizes from the *_bytes queries (ws: forward and backward sizes differ).  All work is
  * enqueued on `stream`; with stream2 != NULL the weight-gradient GEMMs of a backward call run on stream2, forked from and
  * joined back into `stream` inside the call (events from a library-owned pool), so every output is ordered on `stream`
- * when the call returns.  Weights: w[i] = compute-dtype copy W[N,K]; wt[i] = its transpose W^T[K,N] (bf16 mode, may be
+ * when the call returns.  flags & EGV_BLOCK_NO_JOIN (backward, stream2 != NULL): the call returns WITHOUT the join -- dw / db
+ * (not the LayerNorm / gate gradients, not dx / dy) are then ordered on stream2 only, and ws / save / dout must stay untouched
+ * until stream2 has drained; the caller joins once per backward pass (hipops.py does).  Weights: w[i] = compute-dtype copy W[N,K]; wt[i] = its transpose W^T[K,N] (bf16 mode, may be
  * NULL: dgrad then reads W as a [reduction, out] operand); biases, LayerNorm affine terms, gates and ALL gradients fp32.
  * dln_b[i] must be dln_g[i] + D (one [2][D] buffer per LayerNorm).
  *
@@ -208,6 +239,8 @@ int egv_adamw_step(const void* table, const int* prefix, int ntensors, int nchun
  * matrix x[B*S, D], S = 1 + F*N.  L > 0 selects the fused form: y[B*L, D] = text states, y_mask[B, L] additive fp32 key mask,
  * weights 6..8 = qkv_text_i2t (2D x D), qkv_i2t, proj_i2t, LayerNorm 3 = norm_i2t_i, alpha = alpha_i2t (:155-185).
  * Weight order: timeattn.qkv, timeattn.proj, attn.qkv, attn.proj, mlp.fc1, mlp.fc2; LayerNorm order: norm3, norm1, norm2. */
+#define EGV_BLOCK_NO_JOIN 1
+#define EGV_BLOCK_RES_F32 2      /* egv_tlayer_*: hid / out / dout / dhid are fp32 (the text tower's fp32 residual stream), dtype = EGV_BF16 */
 typedef struct egv_vblock_desc {
     int dtype, B, F, N, H, D, Hd, L;
     float eps;
@@ -222,6 +255,7 @@ typedef struct egv_vblock_desc {
     const void* dout; void* dx; void* dy;           /* dy [B*L, D]: gradient of the text states (fused), may be NULL */
     float* dw[9]; float* db[9]; float* dln_g[4]; float* dln_b[4]; float* dalpha;
     void* stream; void* stream2;
+    int flags;                                      /* EGV_BLOCK_* */
 } egv_vblock_desc;
 long long egv_vblock_save_bytes(const egv_vblock_desc* d);
 long long egv_vblock_ws_bytes(const egv_vblock_desc* d, int backward);
@@ -252,6 +286,7 @@ typedef struct egv_tlayer_desc {
     const void* dout; void* dhid; void* denc;       /* denc [B*S, D]: gradient of the video tokens (fused), may be NULL */
     float* dw[10]; float* db[10]; float* dln_g[2]; float* dln_b[2]; float* dalpha;
     void* stream; void* stream2;
+    int flags;                                      /* EGV_BLOCK_* */
 } egv_tlayer_desc;
 long long egv_tlayer_save_bytes(const egv_tlayer_desc* d);
 long long egv_tlayer_ws_bytes(const egv_tlayer_desc* d, int backward);

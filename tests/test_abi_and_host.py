@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(raw, s), s
         assert s in _lib.PROTOTYPES, f"{s} declared in the header but not bound in _lib.py"
-    assert _lib.lib.egv_abi_version() == 1
+    assert _lib.lib.egv_abi_version() == _lib.ABI_VERSION
 
 
 def test_attn_desc_layout_matches_c(tmp_path):

@@ -714,3 +714,55 @@ def test_block_entry_points_match_per_op_composition(ops, dtype, fused):
             if not (name == 'text' and i in (3, 19)):     # key biases have an exactly-zero true gradient: noise / noise
                 # (the gate gradients are dot products of two noisy bf16 vectors: a looser bound)
                 assert _rel(bb, a.double().cpu()) < (1e-5 if dtype == torch.float32 else (1e-1 if a.numel() == 1 else 2e-2)), (name, i)
+
+
+@pytest.mark.parametrize('M', [25096, 4096 + 8, 1100])
+def test_grouped_weight_gradients_bf16(ops, M):
+    """egv_gemm_wgrad_grouped: the six weight gradients of a SpaceTimeBlock (video_transformer.py:53,56,120,152 autograd) in one
+    launch, reduction splits summed by the last arriver, against fp64 math on the bf16 operands (2e-3: fp32 accumulation of M
+    products); bias gradients and the gate factor included; bit-identical between two launches (the sum is in split order)."""
+    D, Hd = 256, 1024
+    shapes = [(D, Hd, True, False), (Hd, D, True, False), (D, D, True, True), (3 * D, D, True, False), (D, D, False, False), (3 * D, D, True, False)]
+    probs, refs = [], []
+    gate = torch.tensor([0.37], device='cuda')
+    for i, (N, K, bias, gated) in enumerate(shapes):
+        dy = _rnd((M, N), torch.bfloat16, 1.0, 10 + i).cuda()
+        x = _rnd((M, K), torch.bfloat16, 1.0, 30 + i).cuda()
+        probs.append((dy, x, bias, gate if gated else None))
+        sc = 0.37 if gated else 1.0
+        refs.append((sc * (dy.double().t() @ x.double()), sc * dy.double().sum(0)))
+    outs = ops.wgrad_grouped(probs, M)
+    torch.cuda.synchronize()
+    for (dw, db), (rw, rb), (N, K, bias, _g) in zip(outs, refs, shapes):
+        assert _rel(dw, rw) < 2e-3, (N, K, _rel(dw, rw))
+        if bias:
+            assert _rel(db, rb) < 2e-3, (N, K, _rel(db, rb))
+    again = ops.wgrad_grouped(probs, M)
+    torch.cuda.synchronize()
+    for (dw, db), (dw2, db2) in zip(outs, again):
+        assert torch.equal(dw, dw2)
+        assert db is None or torch.equal(db, db2)
+
+
+def test_grouped_weight_gradients_under_load_bf16(ops):
+    """the in-launch hand-off of the grouped weight gradients must not depend on dispatch order or timing: the same group, launched
+    while another stream keeps the chip busy with a persistent GEMM and a streaming copy, gives bit-identical results every time"""
+    M, D = 25096, 768
+    dy = [_rnd((M, n), torch.bfloat16, 1.0, 50 + i).cuda() for i, n in enumerate((D, 3 * D, D))]
+    x = [_rnd((M, D), torch.bfloat16, 1.0, 60 + i).cuda() for i in range(3)]
+    probs = [(dy[i], x[i], True, None) for i in range(3)]
+    ref = [(a.clone(), b.clone()) for a, b in ops.wgrad_grouped(probs, M)]
+    torch.cuda.synchronize()
+    a = _rnd((M, 768), torch.bfloat16, 1.0, 70).cuda()
+    w = _rnd((3072, 768), torch.float32, 0.05, 71).cuda()
+    big = torch.empty(256 << 20, dtype=torch.uint8, device='cuda')
+    side = torch.cuda.Stream()
+    for it in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                ops.linear(a, w, None)
+                big.copy_(big.flip(0)) if it % 2 else None
+        outs = ops.wgrad_grouped(probs, M)
+        torch.cuda.synchronize()
+        for (dw, db), (rw, rb) in zip(outs, ref):
+            assert torch.equal(dw, rw) and torch.equal(db, rb), it
