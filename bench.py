@@ -215,44 +215,42 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(a.warmup):
-        try:
-            ld = step()
-        except Exception as e:                      # the flat all-reduce path failed on this software stack: fall back to DDP once
-            if gsync is None or i > 0:
-                raise
-            print(f"[bench] flat gradient sync failed ({type(e).__name__}: {e}); falling back to DistributedDataParallel", file=sys.stderr)
-            ops.set_pack_hook(None)
-            ops.begin_step()
-            for p in model.parameters():
-                p.grad = None
-            from torch.nn.parallel import DistributedDataParallel as DDP
-            gsync, a.grad_sync = None, 'ddp'
-            net = DDP(model, device_ids=[local], static_graph=True, gradient_as_bucket_view=True, find_unused_parameters=False, bucket_cap_mb=64)
-            ld = step()
+        ld = step()                                 # a failure of the default gradient-sync path fails the benchmark on every rank
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         ld = step()
     sync()
     dt = time.perf_counter() - t0
-    # Per-kernel durations for the roofline object: the same K steps once more with one HIP event pair around every GEMM
-    # launch.  This pass runs single-stream (EGV_NO_OVERLAP=1): in the timed pass above text-side and weight-gradient
-    # kernels share the CUs with the kernel being timed, so an event pair there measures co-scheduling, not the kernel.
-    # The event pass is not part of `value`.
+    # Per-kernel durations for the roofline object: the same K steps twice more with one HIP event pair around every GEMM,
+    # attention and LayerNorm launch, on the stream the kernel is launched on -- once exactly as timed above (text-side and
+    # weight-gradient kernels share the CUs with the kernel being timed: "in_step", what rocprofv3 sees in the step) and once
+    # single-stream (EGV_NO_OVERLAP=1: "isolated", the kernel alone on the chip).  Neither pass is part of `value`.
     use_events = not a.no_gemm_events
+    passes = {}
     if use_events:
-        prev = os.environ.get('EGV_NO_OVERLAP')
-        os.environ['EGV_NO_OVERLAP'] = '1'
-        step()
-        sync()
-        ops.prof_reset()
-        ops.prof_enable(True)
-        for _ in range(a.steps):
-            step()
-        sync()
-        ops.prof_enable(False)
-        if prev is None:
-            os.environ.pop('EGV_NO_OVERLAP', None)
+        def event_pass(single_stream):
+            prev = os.environ.get('EGV_NO_OVERLAP')
+            if single_stream:
+                os.environ['EGV_NO_OVERLAP'] = '1'
+            try:
+                step()
+                sync()
+                ops.prof_reset()
+                ops.prof_enable(True)
+                for _ in range(a.steps):
+                    step()
+                sync()
+                ops.prof_enable(False)
+                return ops.prof_collect()
+            finally:
+                if single_stream:
+                    if prev is None:
+                        os.environ.pop('EGV_NO_OVERLAP', None)
+                    else:
+                        os.environ['EGV_NO_OVERLAP'] = prev
+        passes['in_step'] = event_pass(False)
+        passes['isolated'] = event_pass(True)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -261,54 +259,89 @@ def main():
 
     roof = None
     if use_events and rank == 0:
-        recs = ops.prof_collect()
         kinds = {0: 'gemm_kernel<bf16,NT> (generic 128x128)', 1: 'gemm_kernel<bf16,NN> (generic)', 2: 'gemm_kernel<bf16,TN> (generic)',
                  4: 'gemm_kernel<f32,NT>', 5: 'gemm_kernel<f32,NN>', 6: 'gemm_kernel<f32,TN>',
                  8: 'gemm_ring_kernel<256x128> (NT fwd+dgrad, DMA ring)', 10: 'gemm_wgrad_ring_kernel (TN wgrad, 256x128 DMA ring)',
                  12: 'gemm_pp_kernel (NT fwd+dgrad, persistent ping-pong 256x256)', 13: 'gemm_ring_kernel<128x128> (NT, text-side grids)',
-                 14: 'gemm_wgrad_pp_kernel (TN wgrad, ping-pong 256x256)'}
+                 14: 'gemm_wgrad_pp_kernel (TN wgrad, ping-pong 256x256, one launch per gradient)',
+                 15: 'gemm_wgrad_group_kernel (TN wgrad, persistent grouped launch: all weight gradients of a SpaceTimeBlock)'}
         pmc_names = {8: 'gemm_ring_kernel<256x128>', 10: 'gemm_wgrad_ring_kernel', 12: 'gemm_pp_kernel', 13: 'gemm_ring_kernel<128x128>',
-                     14: 'gemm_wgrad_pp_kernel'}
-        agg = {}
-        for fl, ms, kd, by in recs:
-            e = agg.setdefault(kd, [0.0, 0.0, 0, 0.0])
-            e[0] += fl
-            e[1] += ms
-            e[2] += 1
-            e[3] += by
+                     14: 'gemm_wgrad_pp_kernel', 15: 'gemm_wgrad_group_kernel'}
+
+        def aggregate(recs):
+            agg = {}
+            for fl, ms, kd, by in recs:
+                e = agg.setdefault(kd, [0.0, 0.0, 0, 0.0])
+                e[0] += fl
+                e[1] += ms
+                e[2] += 1
+                e[3] += by
+            return agg
+        agg_in, agg_iso = aggregate(passes['in_step']), aggregate(passes['isolated'])
         if os.environ.get('EGV_BENCH_SHAPES'):           # per (kernel kind, FLOPs) breakdown on stderr: which shapes run slow in-step
-            by = {}
-            for fl, ms, kd, _b in recs:
-                e = by.setdefault((kd, fl), [0.0, 0])
-                e[0] += ms
-                e[1] += 1
-            for (kd, fl), (ms, n) in sorted(by.items(), key=lambda kv: -kv[1][0])[:40]:
-                print(f"shape kind={kd} gflop={fl / 1e9:9.2f} n/step={n / a.steps:6.1f} ms/step={ms / a.steps:7.3f} "
-                      f"avg_us={ms / n * 1e3:8.1f} TF={fl * n / (ms * 1e-3) / 1e12 if ms else 0:7.1f}", file=sys.stderr)
-        tot_ms = sum(e[1] for e in agg.values())
-        dom = max(agg, key=lambda k: agg[k][1])
-        fl, ms, n, alg_bytes = agg[dom]
+            for tag, recs in passes.items():
+                by = {}
+                for fl, ms, kd, _b in recs:
+                    e = by.setdefault((kd, fl), [0.0, 0])
+                    e[0] += ms
+                    e[1] += 1
+                for (kd, fl), (ms, n) in sorted(by.items(), key=lambda kv: -kv[1][0])[:40]:
+                    print(f"shape[{tag}] kind={kd} gflop={fl / 1e9:9.2f} n/step={n / a.steps:6.1f} ms/step={ms / a.steps:7.3f} "
+                          f"avg_us={ms / n * 1e3:8.1f} TF={fl * n / (ms * 1e-3) / 1e12 if ms else 0:7.1f}", file=sys.stderr)
+        gemm_kinds = [k for k in agg_in if k < 20]
+        dom = max(gemm_kinds, key=lambda k: agg_in[k][1])
+        fl, ms, n, alg_bytes = agg_in[dom]
         ach = fl / (ms * 1e-3) / 1e12
-        # HBM traffic and MFMA-busy counters of the dominant kernel: rocprofv3 --pmc passes over THIS script (in-step, separate
-        # passes per counter group, gfx950 FETCH_SIZE correction), summarised by tools/pmc_instep.py into profiles/
+        iso = agg_iso.get(dom)
+        ach_iso = iso[0] / (iso[1] * 1e-3) / 1e12 if iso and iso[1] else None
+        # HBM traffic and MFMA-busy counters of the dominant kernel are NOT measured in this run: they come from rocprofv3 --pmc
+        # passes over this script (in-step, separate passes per counter group, gfx950 FETCH_SIZE correction) that were summarised by
+        # tools/pmc_instep.py into a committed file; `source` says which
         traffic = mfma_busy = launches_per_step = None
+        pmc_file = None
+        for cand in ('round3_pmc_instep.json', 'round2_pmc_instep.json'):
+            if os.path.exists(os.path.join(REPO, 'profiles', cand)):
+                pmc_file = cand
+                break
         try:
-            pm = json.load(open(os.path.join(REPO, 'profiles', 'round2_pmc_instep.json')))
+            pm = json.load(open(os.path.join(REPO, 'profiles', pmc_file)))
             ent = pm['kernels'].get(pmc_names.get(dom, ''))
             if ent:
                 traffic = {k: ent[k] for k in ('fetch_bytes_per_launch', 'write_bytes_per_launch', 'traffic_bytes_per_launch', 'method') if k in ent}
                 traffic['algorithmic_bytes_per_launch'] = round(alg_bytes / n)
+                traffic['source'] = f'profiles/{pmc_file} (committed rocprofv3 --pmc passes over this script; not re-measured in this run)'
                 mfma_busy = ent.get('mfma_busy_frac')
             launches_per_step = pm.get('launches_per_step')
         except Exception:
             pass
+
+        def tf_table(agg):
+            return {kinds.get(k, str(k)): {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1) if v[1] else 0.0, "ms_per_step": round(v[1] / a.steps, 2),
+                                           "launches_per_step": v[2] // a.steps} for k, v in agg.items() if k < 20}
+
+        def hbm_class(agg, ks):
+            by = sum(agg[k][3] for k in ks if k in agg)
+            ms_ = sum(agg[k][1] for k in ks if k in agg)
+            nl = sum(agg[k][2] for k in ks if k in agg)
+            if not ms_:
+                return None
+            return {"GB/s": round(by / (ms_ * 1e-3) / 1e9, 1), "frac_of_8TB/s": round(by / (ms_ * 1e-3) / 8e12, 4), "ms_per_step": round(ms_ / a.steps, 2),
+                    "launches_per_step": nl // a.steps}
+        hbm = {"attention (fwd / dQ / dK,dV / one-pass bwd launches, all towers)": {"in_step": hbm_class(agg_in, (20, 21, 22, 23)), "isolated": hbm_class(agg_iso, (20, 21, 22, 23))},
+               "layernorm (fwd + bwd launches)": {"in_step": hbm_class(agg_in, (30, 31)), "isolated": hbm_class(agg_iso, (30, 31))},
+               "bytes": "algorithmic: every operand and result of a launch once"}
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                "mfma_busy_frac_rocprof": mfma_busy,
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "frac_in_step": round(ach / PEAK_BF16_TFLOPS, 4),
+                "frac_isolated": round(ach_iso / PEAK_BF16_TFLOPS, 4) if ach_iso else None,
+                "measured": "HIP events around every launch of the kernel, on its stream, in a repeat of the timed steps: in_step = as timed (two-stream); "
+                            "isolated = single-stream (EGV_NO_OVERLAP=1); frac = in_step",
+                "traffic": traffic, "mfma_busy_frac_rocprof": mfma_busy,
                 "kernel": kinds.get(dom, str(dom)), "launches": n, "avg_launch_ms": round(ms / n, 4),
-                "all_gemm": {kinds.get(k, str(k)): {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1), "ms_per_step": round(v[1] / a.steps, 2),
-                                                    "launches_per_step": v[2] // a.steps} for k, v in agg.items()},
-                "gemm_ms_per_step": round(tot_ms / a.steps, 2), "launches_per_step_rocprof": launches_per_step}
+                "all_gemm": tf_table(agg_in), "all_gemm_isolated": tf_table(agg_iso),
+                "gemm_ms_per_step": round(sum(agg_in[k][1] for k in gemm_kinds) / a.steps, 2),
+                "hbm_bound_classes": hbm,
+                "launches_per_step_rocprof": launches_per_step,
+                "launches_per_step_source": f'profiles/{pmc_file}' if launches_per_step is not None else None}
 
     if rank == 0:
         pairs = world * a.batch * a.steps
@@ -329,6 +362,7 @@ def main():
                "mfma_frac_of_peak": round(value * fpx / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
                "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
                "kernel_launches_per_step": (roof or {}).pop('launches_per_step_rocprof', None),
+               "kernel_launches_per_step_source": (roof or {}).pop('launches_per_step_source', None),
                "losses": losses, "roofline": roof}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, a.text_len, a.workload)

@@ -677,7 +677,7 @@ extern "C" int egv_attn_fwd_covers_extra(int dtype, const egv_attn_desc* d) {
     return egv_attn_fwd_cls_ok(a) ? 1 : 0;
 }
 
-extern "C" int egv_attn_fwd(int dtype, const egv_attn_desc* d, void* stream) {
+static int egv_attn_fwd_impl(int dtype, const egv_attn_desc* d, void* stream) {
     if (check_desc(d, "egv_attn_fwd")) return -1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     AttnArgs a = to_args(d);
@@ -725,7 +725,7 @@ extern "C" int egv_attn_fwd(int dtype, const egv_attn_desc* d, void* stream) {
     return 0;
 }
 
-extern "C" int egv_attn_bwd_dq(int dtype, const egv_attn_desc* d, void* stream) {
+static int egv_attn_bwd_dq_impl(int dtype, const egv_attn_desc* d, void* stream) {
     if (check_desc(d, "egv_attn_bwd_dq")) return -1;
     EGV_CHECK(d->lse && d->delta && d->dO && d->dQ, "egv_attn_bwd_dq: missing lse/delta/dO/dQ");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -764,7 +764,7 @@ extern "C" long long egv_attn_bwd_dkv_workspace_bytes(int B, int G, int H, int k
     return (long long)nsplit * B * G * k_n * H * 2 * HD * 4;
 }
 
-extern "C" int egv_attn_bwd_dkv(int dtype, const egv_attn_desc* d, void* stream) {
+static int egv_attn_bwd_dkv_impl(int dtype, const egv_attn_desc* d, void* stream) {
     if (check_desc(d, "egv_attn_bwd_dkv")) return -1;
     EGV_CHECK(d->lse && d->delta && d->dO && d->dK && d->dV, "egv_attn_bwd_dkv: missing lse/delta/dO/dK/dV");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -808,7 +808,7 @@ extern "C" int egv_attn_bwd_dkv(int dtype, const egv_attn_desc* d, void* stream)
 // With a workspace (d->ws, egv_attn_bwd_fused_workspace_bytes) and an extra row it ALSO produces that row's dQ, dK and dV (per-
 // group partials summed by a second small launch), i.e. it then replaces the two one-row launches as well.
 extern "C" long long egv_attn_bwd_fused_workspace_bytes(int B, int G, int H) { return (long long)B * G * H * 3 * HD * 4; }
-extern "C" int egv_attn_bwd_fused(int dtype, const egv_attn_desc* d, void* stream) {
+static int egv_attn_bwd_fused_impl(int dtype, const egv_attn_desc* d, void* stream) {
     if (check_desc(d, "egv_attn_bwd_fused")) return -1;
     EGV_CHECK(d->lse && d->delta && d->dO && d->dQ && d->dK && d->dV, "egv_attn_bwd_fused: missing lse/delta/dO/dQ/dK/dV");
     if (dtype != EGV_BF16) return 1;
@@ -841,3 +841,34 @@ extern "C" int egv_attn_bwd_extra_reduce(int dtype, const egv_attn_desc* d, int 
     EGV_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- C entry points: the launch logic above, bracketed by the HIP-event instrumentation of bench.py's roofline leg (a no-op unless
+// egv_prof_enable(1)): kind 20 forward, 21 dQ, 22 dK/dV, 23 one-pass backward; bytes = algorithmic traffic (each operand once)
+void* egv_prof_begin(void* stream);
+void egv_prof_end(void* handle, void* stream, double flops, int kind, double bytes);
+static void attn_work(int dtype, const egv_attn_desc* d, int kind, double& flops, double& bytes) {
+    const double rq = (double)d->B * d->G * d->q_n + (double)d->B * (d->extra ? 1 : 0), rk = (double)d->B * d->G * d->k_n + (double)d->B * (d->extra ? 1 : 0);
+    const double row = (double)d->H * 64 * (dtype == EGV_BF16 ? 2 : 4);
+    const double pairs = (double)d->B * d->G * d->H * ((double)d->q_n + (d->extra ? 1 : 0)) * ((double)d->k_n + (d->extra ? 1 : 0));
+    const double mm = 2.0 * 64 * pairs;                           // one q k^T-sized product
+    if (kind == 20) { flops = 2 * mm; bytes = row * (2 * rq + 2 * rk); }
+    else if (kind == 21) { flops = 3 * mm; bytes = row * (3 * rq + 2 * rk); }
+    else if (kind == 22) { flops = 4 * mm; bytes = row * (2 * rq + 4 * rk); }
+    else { flops = 5 * mm; bytes = row * (4 * rq + 4 * rk); }
+}
+#define EGV_ATTN_ENTRY(NAME, KIND)                                                              \
+    extern "C" int NAME(int dtype, const egv_attn_desc* d, void* stream) {                      \
+        void* ph = egv_prof_begin(stream);                                                      \
+        const int rc = NAME##_impl(dtype, d, stream);                                           \
+        if (ph) {                                                                               \
+            double fl = 0, by = 0;                                                              \
+            if (d && rc == 0) attn_work(dtype, d, KIND, fl, by);                                \
+            egv_prof_end(ph, stream, fl, rc == 0 ? KIND : -1, by);                              \
+        }                                                                                       \
+        return rc;                                                                              \
+    }
+EGV_ATTN_ENTRY(egv_attn_fwd, 20)
+EGV_ATTN_ENTRY(egv_attn_bwd_dq, 21)
+EGV_ATTN_ENTRY(egv_attn_bwd_dkv, 22)
+EGV_ATTN_ENTRY(egv_attn_bwd_fused, 23)
+#undef EGV_ATTN_ENTRY

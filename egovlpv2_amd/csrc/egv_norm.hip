@@ -480,10 +480,19 @@ extern "C" int egv_cast_transpose(const float* src, void* dst, int R, int Cc, vo
     return 0;
 }
 
+void* egv_prof_begin(void* stream);
+void egv_prof_end(void* handle, void* stream, double flops, int kind, double bytes);
+struct LnProf {                 // bench.py roofline leg: kind 30 LayerNorm forward, 31 backward; bytes = every operand once
+    void* h; void* st; int kind; double bytes;
+    LnProf(void* stream, int k, double b) : h(egv_prof_begin(stream)), st(stream), kind(k), bytes(b) {}
+    ~LnProf() { if (h) egv_prof_end(h, st, 0.0, kind, bytes); }
+};
+
 extern "C" int egv_layernorm_fwd(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* stats,
                                  int M, int D, float eps, void* stream) {
     EGV_CHECK(D % 4 == 0 && D <= LN_MAXV * 256, "egv_layernorm_fwd: D=%d unsupported", D);
     EGV_CHECK(M > 0, "egv_layernorm_fwd: M=%d", M);
+    LnProf prof(stream, 30, 2.0 * M * D * (dtype == EGV_BF16 ? 2 : 4));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((M + 3) / 4);
     if (dtype == EGV_BF16)
@@ -528,6 +537,7 @@ extern "C" int egv_layernorm_bwd2(int dtype, const void* dy, const void* x, cons
                                   const void* add, const void* add2, void* dx, float* dgamma, float* dbeta, int M, int D,
                                   void* workspace, void* stream) {
     EGV_CHECK(D % 4 == 0 && D <= LN_MAXV * 256, "egv_layernorm_bwd: D=%d unsupported", D);
+    LnProf prof(stream, 31, (3.0 + (add != nullptr) + (add2 != nullptr)) * M * D * (dtype == EGV_BF16 ? 2 : 4));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nb = ln_bwd_blocks(M);
     const int rpb = (M + nb - 1) / nb;

@@ -29,8 +29,9 @@ def main(name):
     args = types.SimpleNamespace(world_size=1, rank=0)
     with torch.no_grad(), torch.autocast('cpu', dtype=torch.bfloat16):
         r = m.infer(data, task_names='EgoNCE', ret={})
-    print(f"{name}: reference under bf16 autocast vs its fp32 values: text_embeds {rel(r['text_embeds'].float(), g['text_embeds']):.2e}, "
-          f"video_embeds {rel(r['video_embeds'].float(), g['video_embeds']):.2e}")
+    out = {'text_embeds': rel(r['text_embeds'].float(), g['text_embeds']), 'video_embeds': rel(r['video_embeds'].float(), g['video_embeds'])}
+    print(f"{name}: reference under bf16 autocast vs its fp32 values: text_embeds {out['text_embeds']:.2e}, "
+          f"video_embeds {out['video_embeds']:.2e}")
     np.random.seed(17)
     torch.manual_seed(17)
     with torch.autocast('cpu', dtype=torch.bfloat16):
@@ -38,8 +39,20 @@ def main(name):
                           task_names='EgoNCE_MLM_ITM')
     for k in ('EgoNCE', 'loss_mlm', 'loss_itm', 'loss_total'):
         ref = float(g['loss_' + k])
-        print(f"   {k}: {float(ld[k]):.6f} vs fp32 {ref:.6f}  (rel {abs(float(ld[k]) - ref) / abs(ref):.2e})")
+        out[k] = abs(float(ld[k]) - ref) / abs(ref)
+        print(f"   {k}: {float(ld[k]):.6f} vs fp32 {ref:.6f}  (rel {out[k]:.2e})")
+    return out
 
 
 if __name__ == '__main__':
-    main(sys.argv[1] if len(sys.argv) > 1 else 'base_f4')
+    # `--write`: (re)generate tests/golden/autocast_error.json -- the reference's own mixed-precision distance from its fp32
+    # values, the yardstick of the bf16 acceptance tests (tests/test_model_parity.py)
+    import json
+    names = [a for a in sys.argv[1:] if not a.startswith('--')] or ['base_f4']
+    res = {n: main(n) for n in names}
+    if '--write' in sys.argv:
+        path = os.path.join(G.REPO, 'tests', 'golden', 'autocast_error.json')
+        old = json.load(open(path)) if os.path.exists(path) else {}
+        old.update(res)
+        json.dump(old, open(path, 'w'), indent=1, sort_keys=True)
+        print('wrote', path)

@@ -5,6 +5,7 @@ vectors produced by the imported reference.  Tolerances:
   activation through the 2x12 layers; see DESIGN.md "Numerics").
 """
 import math
+import os
 import types
 
 import numpy as np
@@ -107,6 +108,18 @@ def test_tiny_embeddings_and_losses_vs_oracle_and_golden(dtype, tol_e, tol_l):
         assert np.allclose(gn[big], g['grad_norms'][big], rtol=0.15)
 
 
+def _bf16_bounds(name):
+    """bf16 acceptance criterion: no worse than 1.1x the distance of the REFERENCE ITSELF, run under
+    torch.autocast(bf16) the way its trainer runs it (trainer/trainer_egoclip.py:143), from its own fp32 values -- per tower for the
+    pooled embeddings; for the losses 1.1x the reference's distance or 5e-4, whichever is larger (the reference's own loss errors are
+    as small as 2e-5 on some fixtures by cancellation).  tests/golden/autocast_error.json is written by oracle/ref_autocast_error.py
+    from the imported reference."""
+    import json
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'autocast_error.json')))[name]
+    return ({k: 1.1 * ref[k] for k in ('text_embeds', 'video_embeds')},
+            {k: max(1.1 * ref[k], 5e-4) for k in ('EgoNCE', 'loss_mlm', 'loss_itm', 'loss_total')})
+
+
 def test_tiny_egonce_only_step_fp32():
     g, cfg, B, L, wseed, bseed = load_golden('tiny')
     sd, data, noun, verb, oc = oracle_setup(cfg, B, L, wseed, bseed)
@@ -130,19 +143,24 @@ def test_base_f4_vs_golden(dtype, tol_e, tol_l):
     1.3e-2 on the pooled embeddings, <= 1.2e-3 on the losses -- tools/bf16_error.py; the bounds keep a margin.)"""
     from egovlpv2_amd.synthetic import make_state_dict, make_batch
     g, cfg, B, L, wseed, bseed = load_golden('base_f4')
+    tol_te = tol_ve = tol_e
+    tol_loss = {k: tol_l for k in ('EgoNCE', 'loss_mlm', 'loss_itm', 'loss_total')}
+    if dtype == torch.bfloat16:
+        eb, tol_loss = _bf16_bounds('base_f4')
+        tol_te, tol_ve = eb['text_embeds'], eb['video_embeds']
     sd = make_state_dict(cfg, wseed)
     data, noun, verb = make_batch(cfg, B, L, bseed)
     m = _build(cfg, sd, dtype)
     with torch.no_grad():
         r = m.infer(_to_cuda(data), task_names='EgoNCE')
-    assert rel_err(r['text_embeds'].float(), g['text_embeds']) < tol_e
-    assert rel_err(r['video_embeds'].float(), g['video_embeds']) < tol_e
+    assert rel_err(r['text_embeds'].float(), g['text_embeds']) < tol_te
+    assert rel_err(r['video_embeds'].float(), g['video_embeds']) < tol_ve
     np.random.seed(17)
     torch.manual_seed(17)
     loss, ld, ret = _forward(m, data, noun, verb, 'EgoNCE_MLM_ITM')
     for k in ('EgoNCE', 'loss_mlm', 'loss_itm', 'loss_total'):
         ref = float(g['loss_' + k])
-        assert abs(float(ld[k]) - ref) <= tol_l * abs(ref), (k, float(ld[k]), ref)
+        assert abs(float(ld[k]) - ref) <= tol_loss[k] * abs(ref), (k, float(ld[k]), ref)
     loss.backward()
     names = [str(x) for x in g['param_names']]
     pd = dict(m.named_parameters())
@@ -163,20 +181,25 @@ def test_base_f16_vs_golden(dtype, tol_e, tol_l):
     embeddings, the three losses with the pinned ITM draws, every parameter-gradient norm."""
     from egovlpv2_amd.synthetic import make_state_dict, make_batch
     g, cfg, B, L, wseed, bseed = load_golden('base_f16')
+    tol_te = tol_ve = tol_e
+    tol_loss = {k: tol_l for k in ('EgoNCE', 'loss_mlm', 'loss_itm', 'loss_total')}
+    if dtype == torch.bfloat16:
+        eb, tol_loss = _bf16_bounds('base_f16')
+        tol_te, tol_ve = eb['text_embeds'], eb['video_embeds']
     assert cfg.frames == 16 and cfg.depth == 12 and L == 32
     sd = make_state_dict(cfg, wseed)
     data, noun, verb = make_batch(cfg, B, L, bseed)
     m = _build(cfg, sd, dtype)
     with torch.no_grad():
         r = m.infer(_to_cuda(data), task_names='EgoNCE')
-    assert rel_err(r['text_embeds'].float(), g['text_embeds']) < tol_e
-    assert rel_err(r['video_embeds'].float(), g['video_embeds']) < tol_e
+    assert rel_err(r['text_embeds'].float(), g['text_embeds']) < tol_te
+    assert rel_err(r['video_embeds'].float(), g['video_embeds']) < tol_ve
     np.random.seed(17)
     torch.manual_seed(17)
     loss, ld, ret = _forward(m, data, noun, verb, 'EgoNCE_MLM_ITM')
     for k in ('EgoNCE', 'loss_mlm', 'loss_itm', 'loss_total'):
         ref = float(g['loss_' + k])
-        assert abs(float(ld[k]) - ref) <= tol_l * abs(ref), (k, float(ld[k]), ref)
+        assert abs(float(ld[k]) - ref) <= tol_loss[k] * abs(ref), (k, float(ld[k]), ref)
     loss.backward()
     names = [str(x) for x in g['param_names']]
     pd = dict(m.named_parameters())
@@ -487,18 +510,27 @@ def test_text_fp32_option_inside_the_bf16_model():
 
 
 def test_training_step_is_bitwise_reproducible():
-    """Two runs of the same three-loss step (same weights, batch, RNG seeds, dropout stream) on the full 16 x 224^2 geometry give
-    bit-identical losses and gradients: no atomics anywhere, every cross-wave / cross-workgroup / cross-stream sum has a fixed
-    order, and the companion streams (text tower, weight gradients) are joined before anything reads what they wrote."""
+    """Three runs of the same three-loss step (same weights, batch, RNG seeds, dropout stream) at the benchmark's batch size on the
+    full 16 x 224^2 geometry give bit-identical losses and gradients.  By design, not by luck: there is no atomic add on the path
+    (the embedding-table gradients -- where <s>, </s>, the padding position and repeated words receive many contributions -- are
+    summed by one owner wave per table row in token order; the grouped weight-gradient launch adds its reduction splits in split
+    order whoever arrives last), every cross-wave / cross-workgroup / cross-stream sum has a fixed order, and the companion streams
+    (text tower, weight gradients) are joined before anything reads what they wrote."""
     from egovlpv2_amd.config import PathConfig
     from egovlpv2_amd.synthetic import make_state_dict, make_batch
     cfg = PathConfig(frames=16, depth=4, n_fuse=2, drop_rate=0.1)
-    B, L = 3, 32
+    B, L = 8, 32
     sd = make_state_dict(cfg, 21)
     data, noun, verb = make_batch(cfg, B, L, 2024)
+    # every sentence repeats a few word ids (and shares <s> / </s> / position rows with all the others)
+    ids = data['text']['input_ids']
+    ids[:, 5] = ids[:, 3]
+    ids[:, 7] = ids[0, 3]
+    ids[1::2, 9] = ids[0, 4]
+    data['text_mlm_ids'][:, 7] = data['text_mlm_ids'][0, 3]
     m = _build(cfg, sd, torch.bfloat16).train()
     runs = []
-    for _ in range(2):
+    for _ in range(3):
         m.zero_grad(set_to_none=True)
         m.seed_dropout(123)
         np.random.seed(3)
@@ -507,6 +539,11 @@ def test_training_step_is_bitwise_reproducible():
         loss.backward()
         torch.cuda.synchronize()
         runs.append((float(loss.detach()), {n: p.grad.clone() for n, p in m.named_parameters()}))
-    assert runs[0][0] == runs[1][0]
-    for n in runs[0][1]:
-        assert torch.equal(runs[0][1][n], runs[1][1][n]), n
+    for r in runs[1:]:
+        assert runs[0][0] == r[0]
+        for n in ('text_model.embeddings.word_embeddings.weight', 'text_model.embeddings.position_embeddings.weight',
+                  'text_model.embeddings.token_type_embeddings.weight'):
+            assert torch.equal(runs[0][1][n], r[1][n]), n
+            assert runs[0][1][n].abs().sum() > 0, n
+        for n in runs[0][1]:
+            assert torch.equal(runs[0][1][n], r[1][n]), n
