@@ -137,6 +137,7 @@ PROTOTYPES = {
     'egv_vblock_ws_bytes': (i64, [C.POINTER(VBlockDesc), i32]),
     'egv_vblock_fwd': (i32, [C.POINTER(VBlockDesc)]),
     'egv_vblock_bwd': (i32, [C.POINTER(VBlockDesc)]),
+    'egv_vblock_bwd_defers': (i32, [C.POINTER(VBlockDesc)]),
     'egv_tlayer_save_bytes': (i64, [C.POINTER(TLayerDesc)]),
     'egv_tlayer_ws_bytes': (i64, [C.POINTER(TLayerDesc), i32]),
     'egv_tlayer_fwd': (i32, [C.POINTER(TLayerDesc)]),

@@ -404,6 +404,13 @@ extern "C" int egv_vblock_fwd(const egv_vblock_desc* d) {
     return 0;
 }
 
+// 1 if egv_vblock_bwd(d) with EGV_BLOCK_NO_JOIN set would return with weight-gradient work still running on d->stream2 (the caller
+// then owes the join and must keep ws / save / dout alive until stream2 has drained), 0 if the call joins by itself anyway
+extern "C" int egv_vblock_bwd_defers(const egv_vblock_desc* d) {
+    const long long M = (long long)d->B * (1 + (long long)d->F * d->N);
+    return (vgroup_ok(d) && d->stream2 && d->stream2 != d->stream && M >= 4096) ? 1 : 0;
+}
+
 extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
     const int dt = d->dtype;
     const size_t es = esz(dt);

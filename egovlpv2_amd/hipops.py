@@ -856,7 +856,7 @@ def _acc_forward(key, track, fused):
     needs_input_grad is True for parameters even under torch.no_grad())."""
     if track:
         for k in ((key, 0), (key, 1)) if fused else ((key, 0),):
-            e = _acc.setdefault(k, {'uses': 0, 'done': 0, 'flat': None, 'views': None, 'params': None, 'side': None})
+            e = _acc.setdefault(k, {'uses': 0, 'done': 0, 'flat': None, 'views': None, 'params': None, 'side': None, 'stream': None, 'event': None})
             e['uses'] += 1
 
 
@@ -906,12 +906,18 @@ def _acc_part(k, flat, views, params, side=None):
         if side is not None:                                  # nothing may touch the views before the join: join now
             side[1].wait_stream(side[0])
         return views
+    cur = torch.cuda.current_stream()
     if e['flat'] is None:
         e['flat'], e['views'], e['params'], e['side'] = flat, views, params, side
     else:
+        if e['stream'] != cur.cuda_stream:
+            # the uses of one block ran on different streams (the model keeps a tower on one stream, so this is the exception):
+            # order this stream after the previous contribution and keep the allocator informed
+            cur.wait_event(e['event'])
+            e['flat'].record_stream(cur)
         sd = side or e['side']
         if sd is not None:                                    # one of the two buffers is still being written on the companion
-            sd[0].wait_stream(torch.cuda.current_stream())
+            sd[0].wait_stream(cur)
             with torch.cuda.stream(sd[0]):
                 e['flat'].add_(flat)
             flat.record_stream(sd[0])
@@ -919,12 +925,17 @@ def _acc_part(k, flat, views, params, side=None):
             e['side'] = sd
         else:
             e['flat'].add_(flat)
+    e['stream'] = cur.cuda_stream
+    if e['done'] + 1 < e['uses']:
+        e['event'] = torch.cuda.Event()
+        e['event'].record(cur if e['side'] is None else e['side'][0])
     e['done'] += 1
     if e['done'] >= e['uses']:
         del _acc[k]
         sd = e['side']
         if _pack_hook[0] is not None:
             if sd is not None:
+                sd[0].wait_stream(cur)                        # (the LayerNorm / gate gradients of the buffer were written on the calling stream)
                 with torch.cuda.stream(sd[0]):
                     _pack_hook[0](e['flat'], e['params'])
             else:
@@ -1040,7 +1051,7 @@ class VideoBlockFn(Function):
             d.dln_g[3], d.dln_b[3] = _p(g[24]), _p(g[25])
             d.dalpha = _p(g[26])
         d.stream2 = _side_stream_ptr()
-        side = _defer_side(params) if d.stream2 else None
+        side = _defer_side(params) if (d.stream2 and lib.egv_vblock_bwd_defers(C.byref(d))) else None
         if side is not None:
             # the grouped weight-gradient launch of this call keeps running on the companion stream after the call returns:
             # everything it reads or writes must outlive it in the caching allocator, and the calling stream is joined at the

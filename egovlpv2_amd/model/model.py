@@ -248,18 +248,22 @@ class FrozenInTime(nn.Module):
         hook fires (tests/test_multirank_gpu.py runs both modes against the oracle)."""
         return not os.environ.get('EGV_NO_OVERLAP') and torch.cuda.is_available()
 
-    def _fork_text(self, fn, uses=(), after=None):
+    def _fork_text(self, fn, uses=(), after=None, kind='text'):
         """Run text-encoder work (latency-bound: a dozen workgroups per kernel) on a second HIP stream so that it overlaps
         the video blocks; autograd replays each backward node on the stream of its forward, so the overlap holds for
         backward too.  The side stream starts after `after` (an event of the calling stream) or, by default, after everything
         queued on the calling stream so far.  `uses`: tensors allocated on the calling stream that fn reads -- they are
         recorded on the side stream, otherwise the caching allocator may recycle them while side-stream kernels (forward
         or backward) are still queued.  Returns (out, join); join() orders the calling stream after fn's work only."""
-        if not self._overlap() or os.environ.get('EGV_TEXT_STREAM', '1') == '0':
+        if not self._overlap() or os.environ.get('EGV_TEXT_STREAM', '1') == '0' or (kind == 'tail' and os.environ.get('EGV_TAIL_STREAM', '1') == '0'):
             return fn(), (lambda: None)
+        kind = 'text'                                          # the loss tails follow the text tower on its stream
         main = torch.cuda.current_stream()
-        if getattr(self, '_side', None) is None or self._side.device != main.device:
-            self._side = ops.companion_stream(main.device, 'text')
+        sides = self.__dict__.setdefault('_sides', {})
+        # ONE companion stream for the text tower and the loss tails.  (A second one for the ITM pass's text prefix -- which queues
+        # behind the MLM pass's fused text layers here -- was measured: + 13 ms per step; every further HIP stream costs the others.)
+        if sides.get(kind) is None or sides[kind].device != main.device:
+            sides[kind] = ops.companion_stream(main.device, 'text')
             # Text-side parameters get their gradients from nodes that ran on the companion stream, while their AccumulateGrad
             # nodes (kept alive by DDP's reducer) belong to the stream DDP was built on.  The engine orders the two streams before
             # every accumulation -- that is the documented behaviour this design relies on (see _overlap) -- so the per-step
@@ -267,7 +271,7 @@ class FrozenInTime(nn.Module):
             warn_off = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
             if warn_off is not None:
                 warn_off(False)
-        side = self._side
+        side = sides[kind]
         if after is None:
             side.wait_stream(main)
         else:
@@ -511,7 +515,7 @@ class FrozenInTime(nn.Module):
             if overlap:
                 ev = torch.cuda.Event()
                 ev.record()                                                   # v (and t, joined above) are ready here
-            t_new, join = self._fork_text(lambda: self._text_layer(t, mask, i, B, L, enc=v), uses=(v, mask), after=ev)
+            t_new, join = self._fork_text(lambda: self._text_layer(t, mask, i, B, L, enc=v), uses=(v, mask, t), after=ev)
             v_new = None if (last and not need_video_out) else self._video_block(v, i, B, y=self._text_operand(t), y_mask=mask, L=L)
             join()
             v, t = v_new, t_new
@@ -551,11 +555,15 @@ class FrozenInTime(nn.Module):
         return ret
 
     def _mlm_logits_padded(self, video, mlm_ids, attention_mask, video_prefix=None, text_prefix=None):
+        """MLM branch of infer (model.py:346-365): fused stack without its dead last video block, then the head"""
+        _, t = self._fused_stack(video, mlm_ids, attention_mask, need_video_out=False, video_prefix=video_prefix,
+                                 text_prefix=text_prefix)
+        return self._mlm_head(t)
+
+    def _mlm_head(self, t):
         """MLM tail (model.py:360-365, heads.py:38-50); the vocabulary axis is padded to a multiple of 128 so that the
         logits rows stay 16-byte aligned (padded columns are excluded from the CE and get zero gradient)."""
         c = self.cfg
-        _, t = self._fused_stack(video, mlm_ids, attention_mask, need_video_out=False, video_prefix=video_prefix,
-                                 text_prefix=text_prefix)
         t = self._lin(self._text_operand(t), 'cross_modal_text_transform')
         t = self._lin(t, 'mlm_score.transform.dense', act='gelu')
         t = self._ln(t, 'mlm_score.transform.LayerNorm', c.eps_mlm)
@@ -582,36 +590,93 @@ class FrozenInTime(nn.Module):
         world = getattr(args, 'world_size', 1)
         gather = (lambda t: allgather(t, n_gpu, args))
         c = self.cfg
+        joins = []                                   # companion-stream work the calling stream has not been ordered after yet
+        loss_terms = []
+        itm_w = None
+        want_itm = 'ITM' in task_names
         if 'EgoNCE' in task_names:                                                               # :380-400
-            ret = self.infer(data, task_names='EgoNCE')
-            video_embeds = gather(ops.CastFn.apply(ret['video_embeds'], torch.float32))
-            text_embeds = gather(ops.CastFn.apply(ret['text_embeds'], torch.float32))
-            n_all, v_all = gather(n_embeds.float()), gather(v_embeds.float())
-            output = sim_matrix(text_embeds, video_embeds)
-            if config['loss']['type'] == 'EgoNCE':
-                sim_v = sim_matrix(v_all, v_all)
-                sim_n = sim_matrix(n_all, n_all)
-                loss, mask_bool, temp = loss_egonce(output, sim_v, sim_n)
+            # infer(task_names='EgoNCE') with its tail on the companion stream: the video tower runs on the calling stream, the text
+            # tower on the text stream (as in infer); the two projection heads' tail -- vid_proj, the gathers, the three similarity
+            # matrices, the EgoNCE loss and the ITM sampling weights, ~30 launches of a few microseconds -- follows the text tower
+            # on the text stream instead of sitting between the EgoNCE tower and the MLM / ITM prefix on the calling stream (0.8 ms
+            # forward, 0.5 ms backward per step)
+            self._prepare_weights()
+            self.task_names = 'EgoNCE'
+            text_data = data['text']
+            text_embeds_l, join_txt = self._fork_text(lambda: self.compute_text(text_data),
+                                                      uses=(text_data['input_ids'], text_data['attention_mask']))
+            feats = self._video_features(data['video'])
+            rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else getattr(args, 'rank', 0)
+            bsz = data['video'].size(0)
+
+            def egonce_tail(weights):
+                video_embeds_l = self._proj_mlp(feats, 'vid_proj')
+                video_embeds = gather(ops.CastFn.apply(video_embeds_l, torch.float32))
+                text_embeds = gather(ops.CastFn.apply(text_embeds_l, torch.float32))
+                n_all, v_all = gather(n_embeds.float()), gather(v_embeds.float())
+                output = sim_matrix(text_embeds, video_embeds)
+                if config['loss']['type'] == 'EgoNCE':
+                    sim_v = sim_matrix(v_all, v_all)
+                    sim_n = sim_matrix(n_all, n_all)
+                    loss_e, mask_bool, temp = loss_egonce(output, sim_v, sim_n)
+                else:
+                    loss_e, mask_bool, temp = loss_egonce(output)
+                w_host = ev_w = None
+                if weights:
+                    # The sampling weights of the ITM branch (:438-447) only depend on the EgoNCE branch: compute them and start the
+                    # device->host copy now, so that the copy (and the host-side draw below) overlaps the MLM pass instead of
+                    # draining the GPU queue.
+                    with torch.no_grad():
+                        sl = slice(bsz * rank, bsz * (rank + 1))
+                        w_v2t = F.softmax(output[sl] / temp, dim=1).masked_fill(mask_bool[sl], 0)
+                        w_t2v = F.softmax(output.t()[sl] / temp, dim=1).masked_fill(mask_bool[sl], 0)
+                        w_dev = torch.stack([w_v2t, w_t2v]).float()
+                        w_host = self._pinned('itm_w', w_dev.shape, torch.float32)     # cached: pinned allocation stalls the device
+                        w_host.copy_(w_dev, non_blocking=True)
+                        ev_w = torch.cuda.Event()
+                        ev_w.record()
+                return (video_embeds_l, output, loss_e), (w_host, ev_w)
+
+            def finish_egonce():
+                (video_embeds_l, output, loss_e), _ = tail_state['out']
+
+                def join_egonce():
+                    join_txt()
+                    tail_state['join']()
+                    cur = torch.cuda.current_stream()
+                    for t_ in (video_embeds_l, output, loss_e):
+                        t_.record_stream(cur)
+                joins.append(join_egonce)
+                ret.update({'text_embeds': text_embeds_l, 'video_embeds': video_embeds_l, 'sim_v2t': output, 'sim_t2v': output.t()})
+                loss_dict['EgoNCE'] = loss_e
+                loss_terms.insert(0, (1.0, loss_e))
+            tail_state = {}
+            loss_dict['EgoNCE'] = None                      # (keeps the reference's key order)
+            late_tail = want_itm and os.environ.get('EGV_EGONCE_TAIL_LATE', '1') != '0'
+            if late_tail:
+                # The ITM draw needs the similarities NOW, but the engine runs backward nodes in reverse creation order and the text
+                # stream executes in order: a differentiable tail created here has its backward enqueued behind the backward of both
+                # text prefixes (created below), and the EgoNCE tower's first backward block waits for it (1.1 ms of calling-stream
+                # idle time).  So: the sampling weights from a no-grad evaluation here, the differentiable tail (the same ~30 small
+                # launches, on the text stream) right after the text prefixes of the MLM and ITM passes have been created.
+                with torch.no_grad():
+                    (_, itm_w), _join_w = self._fork_text(lambda: egonce_tail(True), uses=(feats, n_embeds, v_embeds), kind='tail')
+
+                def make_tail():
+                    tail_state['out'], tail_state['join'] = self._fork_text(lambda: egonce_tail(False), uses=(feats, n_embeds, v_embeds), kind='tail')
+                    finish_egonce()
             else:
-                loss, mask_bool, temp = loss_egonce(output)
-            ret.update({'sim_v2t': output, 'sim_t2v': output.t()})
-            loss_dict.update({'EgoNCE': loss})
+                tail_state['out'], tail_state['join'] = self._fork_text(lambda: egonce_tail(want_itm), uses=(feats, n_embeds, v_embeds), kind='tail')
+                itm_w = tail_state['out'][1]
+                finish_egonce()
 
         itm_pre = None
         if 'ITM' in task_names:                                                                  # :426-447
-            # The sampling weights only depend on the EgoNCE branch: compute them and start the device->host copy now, so
-            # that the copy (and the host-side draw below) overlaps the MLM pass instead of draining the GPU queue.
             rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else getattr(args, 'rank', 0)
             bsz = data['video'].size(0)
-            with torch.no_grad():
-                sl = slice(bsz * rank, bsz * (rank + 1))
-                w_v2t = F.softmax(ret['sim_v2t'][sl] / temp, dim=1).masked_fill(mask_bool[sl], 0)
-                w_t2v = F.softmax(ret['sim_t2v'][sl] / temp, dim=1).masked_fill(mask_bool[sl], 0)
-                w_dev = torch.stack([w_v2t, w_t2v]).float()
-                w_host = self._pinned('itm_w', w_dev.shape, torch.float32)     # cached: pinned allocation stalls the device
-                w_host.copy_(w_dev, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record()
+            if itm_w is None:
+                raise ValueError("task 'ITM' needs the EgoNCE branch in the same call: its hard negatives are drawn from the EgoNCE similarities (model.py:438-447)")
+            w_host, ev = itm_w
             # the gathers of the ITM branch (:429-431) are issued here so that the text stream can start on the ITM
             # batch while the calling stream is still busy with the MLM pass
             # (the reference all-gathers the pixels here, :430; with the shared prefix only the prefix tokens of the clips that
@@ -640,22 +705,13 @@ class FrozenInTime(nn.Module):
             v_pre = self._video_prefix(data['video'])                       # overlaps the MLM text prefix
             data_mlm = dict(data, _video_prefix=v_pre, _text_prefix=txt_mlm)
 
-        if 'MLM' in task_names:                                                                  # :404-422
-            ret = self.infer(data_mlm, task_names='MLM', ret=ret)
-            logits = ret.pop('_mlm_logits_padded')
-            labels = data['text_mlm_labels'].reshape(-1)
-            ce_sum = ops.cross_entropy_sum(logits, labels, c.vocab, -100)
-            # labels outside [0, vocab) other than the ignore index are skipped by the CE kernels (they cannot index the logits):
-            # count exactly the labels that contribute, so that a collator / vocabulary mismatch cannot mis-normalise the loss
-            cnt = ((labels >= 0) & (labels < c.vocab)).sum().to(torch.float32)
-            # the reference all-gathers the (B*L, 50265) logits (412 MB at W=8) and takes the global mean; gathering the
-            # two per-rank scalars gives the identical loss and, through AllGather_multi.backward, identical gradients.
-            tot = gather(torch.stack([ce_sum, cnt]).reshape(1, 2))
-            loss_mlm = tot[:, 0].sum() / tot[:, 1].sum()
-            loss = loss + loss_mlm
-            loss_dict.update({'loss_mlm': loss_mlm})
-
-        if 'ITM' in task_names:                                                                  # :426-483
+        def itm_draw():
+            """model.py:438-468: ITM labels and hard negatives, then the ITM batch's text side.  With the shared prefix this runs BEFORE
+            the MLM pass is enqueued: the draw needs the EgoNCE branch on the host (one event wait) while the calling stream still
+            has the whole unfused video prefix queued, the ITM text prefix then sits on the text stream AHEAD of the MLM pass's
+            fused text layers (which wait for the video blocks step by step) -- it is ready when the ITM fused stack starts -- and
+            in backward the MLM pass's text side is enqueued before the ITM text prefix, i.e. it runs beside the ITM pass instead
+            of holding up the first MLM video block (1.8 + 3.2 ms of calling-stream idle time per step)."""
             rank, bsz, w_host, ev, all_video, all_text_ids, all_text_masks, ev_in = itm_pre
             pos_len = bsz // 2
             itm_labels = torch.cat([torch.ones(pos_len), torch.zeros(bsz - pos_len)])
@@ -699,6 +755,45 @@ class FrozenInTime(nn.Module):
             else:
                 data_itm = {'text': {'input_ids': all_text_ids.index_select(0, txt_idx),
                                      'attention_mask': all_text_masks.index_select(0, txt_idx)}}
+            return dict(itm_labels=itm_labels, neg_log=neg_log, vid_idx=vid_idx, vid_list=vid_list, labels_dev=labels_dev, data_itm=data_itm)
+
+        itm_state = itm_draw() if ('ITM' in task_names and share_prefix and os.environ.get('EGV_ITM_DRAW_EARLY', '1') != '0') else None
+        if itm_state is not None and 'EgoNCE' in task_names and late_tail:
+            make_tail()          # after both text prefixes were created, before the fused stacks: see late_tail above
+
+        if 'MLM' in task_names:                                                                  # :404-422
+            # infer(task_names='MLM') with the head, the cross entropy and the loss arithmetic on the text stream: in backward the
+            # head and the last fused text layer -- which the first MLM video block's backward has to wait for -- then run beside
+            # the ITM pass's backward instead of after it (2.2 ms of calling-stream idle time per step)
+            self._prepare_weights()
+            self.task_names = 'MLM'
+            _, t_mlm = self._fused_stack(data_mlm['video'], data['text_mlm_ids'], data['text']['attention_mask'], need_video_out=False,
+                                         video_prefix=data_mlm.get('_video_prefix'), text_prefix=data_mlm.get('_text_prefix'))
+            labels = data['text_mlm_labels'].reshape(-1)
+
+            def mlm_tail():
+                logits = self._mlm_head(t_mlm)
+                ce_sum = ops.cross_entropy_sum(logits, labels, c.vocab, -100)
+                # labels outside [0, vocab) other than the ignore index are skipped by the CE kernels (they cannot index the
+                # logits): count exactly the labels that contribute, so that a collator / vocabulary mismatch cannot mis-normalise
+                # the loss
+                cnt = ((labels >= 0) & (labels < c.vocab)).sum().to(torch.float32)
+                # the reference all-gathers the (B*L, 50265) logits (412 MB at W=8) and takes the global mean; gathering the
+                # two per-rank scalars gives the identical loss and, through AllGather_multi.backward, identical gradients.
+                tot = gather(torch.stack([ce_sum, cnt]).reshape(1, 2))
+                return logits, tot[:, 0].sum() / tot[:, 1].sum()
+            (logits, loss_mlm), join_mlm = self._fork_text(mlm_tail, uses=(t_mlm, labels), kind='tail')
+            joins.append(join_mlm)
+            Bm, Lm = data['text_mlm_ids'].shape
+            ret.update({'cross_attn_mlm_logits': logits.reshape(Bm, Lm, -1)[..., :c.vocab]})
+            loss_dict.update({'loss_mlm': loss_mlm})
+            loss_terms.append((1.0, loss_mlm))
+
+        if 'ITM' in task_names:                                                                  # :426-483
+            rank, bsz, w_host, ev, all_video, all_text_ids, all_text_masks, ev_in = itm_pre
+            drawn = itm_state if itm_state is not None else itm_draw()
+            itm_labels, neg_log, vid_idx, vid_list, labels_dev, data_itm = (drawn[k] for k in ('itm_labels', 'neg_log', 'vid_idx', 'vid_list',
+                                                                                               'labels_dev', 'data_itm'))
             if share_prefix:
                 lo = rank * bsz
                 remote = sorted({j for j in vid_list if not lo <= j < lo + bsz})
@@ -722,11 +817,21 @@ class FrozenInTime(nn.Module):
             ce_sum = ops.cross_entropy_sum(ops.CastFn.apply(itm_logits, torch.float32).contiguous(), labels_dev.contiguous(), 2, -100)
             tot = gather(torch.stack([ce_sum, torch.full_like(ce_sum, float(bsz))]).reshape(1, 2))
             loss_itm = tot[:, 0].sum() / tot[:, 1].sum()
-            loss = loss + 2 * loss_itm
             loss_dict.update({'loss_itm': loss_itm})
+            loss_terms.append((2.0, loss_itm))
             ret['_itm_labels'] = itm_labels
             ret['_itm_neg_log'] = neg_log
 
+        if 'EgoNCE' in task_names and late_tail and 'out' not in tail_state:
+            make_tail()
+        # everything the companion streams produced is ordered before the calling stream here; the total in the reference's order
+        # of additions (EgoNCE + MLM, + 2 ITM: model.py:420,480)
+        for j in joins:
+            j()
+        loss = None
+        for wgt, term in loss_terms:
+            term = term if wgt == 1.0 else wgt * term
+            loss = term if loss is None else loss + term
         loss_dict.update({'loss_total': loss})
         return loss, loss_dict, ret
 

@@ -261,6 +261,8 @@ long long egv_vblock_save_bytes(const egv_vblock_desc* d);
 long long egv_vblock_ws_bytes(const egv_vblock_desc* d, int backward);
 int egv_vblock_fwd(const egv_vblock_desc* d);
 int egv_vblock_bwd(const egv_vblock_desc* d);
+/* 1 if egv_vblock_bwd(d) with EGV_BLOCK_NO_JOIN would return with weight-gradient work still running on d->stream2 */
+int egv_vblock_bwd_defers(const egv_vblock_desc* d);
 
 /* RobertaLayer.forward (roberta.py:444-505) on hid[B*L, D]: self attention (:257-327, separate q/k/v Linears, additive key
  * mask, probability dropout), RobertaSelfOutput (:335-345), optional text-to-image cross attention over enc[B*S, D] (video

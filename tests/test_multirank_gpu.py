@@ -106,7 +106,10 @@ def _worker(rank, world, port, q, steps, overlap, gsync='ddp'):
                 if n.endswith('.key.bias'):
                     continue                                    # true gradient is exactly zero (softmax shift invariance)
                 err = (a - r).norm().item() / (r.norm().item() + 1e-6)
-                worst['grad'] = max(worst['grad'], err)
+                if err > worst['grad']:
+                    worst['grad'], worst['grad_at'] = err, f'{n} (step {step})'
+                if err > 5e-3:
+                    worst.setdefault('bad', []).append((n, step, round(err, 4)))
         q.put((rank, 'ok', worst))
         dist.destroy_process_group()
     except Exception as e:                                        # surface the failure in the parent
