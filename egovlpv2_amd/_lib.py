@@ -14,7 +14,7 @@ import torch  # noqa: F401  -- must be imported first: the HIP runtime torch bun
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libegovlp_hip.so')
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 EGV_F32, EGV_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 
@@ -71,6 +71,7 @@ class TLayerDesc(C.Structure):
         ('dw', vp * 10), ('db', vp * 10), ('dln_g', vp * 2), ('dln_b', vp * 2), ('dalpha', vp),
         ('stream', vp), ('stream2', vp),
         ('flags', i32),
+        ('w_qkv', vp), ('wt_qkv', vp), ('b_qkv', vp), ('w_ckv', vp), ('wt_ckv', vp), ('b_ckv', vp),
     ]
 
 
@@ -107,6 +108,8 @@ PROTOTYPES = {
     'egv_cast_transpose': (i32, [vp, vp, i32, i32, vp]),
     'egv_transpose': (i32, [i32, i32, vp, vp, i32, i32, i32, vp]),
     'egv_cast_weights': (i32, [vp, vp, i32, i32, vp]),
+    'egv_cast_weights_ld': (i32, [vp, vp, i32, i32, vp]),
+    'egv_copy_segments': (i32, [vp, i32, vp]),
     'egv_stream_create': (i32, [i32, C.POINTER(vp)]),
     'egv_attn_split_workspace_bytes': (i64, [i32, i32, i32, i32, i32, i32]),
     'egv_attn_fwd': (i32, [i32, C.POINTER(AttnDesc), vp]),

@@ -543,6 +543,14 @@ struct TLayout {
 
 // EGV_BLOCK_RES_F32 (bf16 mode only): the residual stream -- layer input / output, the two pre-LayerNorm sums and the output of the
 // attention LayerNorm -- is fp32, GEMM operands and outputs stay bf16 (what torch.autocast does, trainer/trainer_egoclip.py:143)
+// merged same-input projections (bf16 mode, pointers supplied by the caller)
+inline bool tmq(const egv_tlayer_desc* d) { return d->dtype == EGV_BF16 && d->w_qkv != nullptr; }
+inline bool tmc(const egv_tlayer_desc* d) { return d->dtype == EGV_BF16 && d->S > 0 && d->w_ckv != nullptr; }
+// the weight gradients over the B*L text rows as ONE grouped launch (egv_gemm5.hip) at the end of the backward call
+inline bool tgroup(const egv_tlayer_desc* d) {
+    static const bool on = !getenv("EGV_TEXT_WGRAD_GROUP") || atoi(getenv("EGV_TEXT_WGRAD_GROUP")) != 0;
+    return on && d->dtype == EGV_BF16 && (d->D % 256) == 0 && (d->Hd % 256) == 0 && d->B * d->L >= 64;
+}
 inline bool tres32(const egv_tlayer_desc* d) { return (d->flags & EGV_BLOCK_RES_F32) && d->dtype == EGV_BF16; }
 
 TLayout tlayout(const egv_tlayer_desc* d) {
@@ -553,11 +561,12 @@ TLayout tlayout(const egv_tlayer_desc* d) {
     const size_t BL = (size_t)d->B * d->L, BS = (size_t)d->B * d->S, D = d->D, Hd = d->Hd, H = d->H;
     const bool fused = d->S > 0, drop = d->drop_p > 0.f;
     auto T = [&](size_t n) { return b.take_off(n); };
-    L.q = T(BL * D * es); L.k = T(BL * D * es); L.v = T(BL * D * es); L.ctx = T(BL * D * es); L.lse = T(BL * H * 4);
+    L.q = T(BL * 3 * D * es); L.k = L.q + BL * D * es; L.v = L.q + 2 * BL * D * es;     // one [BL, 3D] matrix when the projections are merged
+    L.ctx = T(BL * D * es); L.lse = T(BL * H * 4);
     if (fused || drop || tres32(d)) L.a0 = T(BL * D * es);
     if (fused && drop) L.a0d = T(BL * D * es);
     if (fused) {
-        L.cq = T(BL * D * es); L.ck = T(BS * D * es); L.cv = T(BS * D * es); L.cctx = T(BL * D * es); L.lse_c = T(BL * H * 4);
+        L.cq = T(BL * D * es); L.ck = T(BS * 2 * D * es); L.cv = L.ck + BS * D * es; L.cctx = T(BL * D * es); L.lse_c = T(BL * H * 4);
         L.pg = T(BL * D * es);
     }
     L.a_pre = T(BL * D * rs); L.stats0 = T(BL * 8); L.a = T(BL * D * rs); L.pre = T(BL * Hd * es); L.act = T(BL * Hd * es);
@@ -583,6 +592,21 @@ TPlan tplan(const egv_tlayer_desc* d) {
 }
 }  // namespace
 
+namespace {
+long long tgroup_ws_bytes(const egv_tlayer_desc* d) {
+    if (!tgroup(d)) return 0;
+    const int D = d->D, Hd = d->Hd;
+    egv_wgrad_problem pr[8];
+    int n = 0;
+    auto add = [&](int N, int K) { pr[n] = egv_wgrad_problem{}; pr[n].N = N; pr[n].K = K; ++n; };
+    add(D, Hd); add(Hd, D); add(D, D);
+    if (tmq(d)) add(3 * D, D); else { add(D, D); add(D, D); add(D, D); }
+    if (d->S > 0) { add(D, D); add(D, D); }
+    const long long b = egv_gemm_wgrad_grouped_workspace_bytes(d->B * d->L, n, pr, 0);
+    return b > 0 ? b : 0;
+}
+}  // namespace
+
 extern "C" long long egv_tlayer_save_bytes(const egv_tlayer_desc* d) { return (long long)tlayout(d).total; }
 
 extern "C" long long egv_tlayer_ws_bytes(const egv_tlayer_desc* d, int backward) {
@@ -594,7 +618,8 @@ extern "C" long long egv_tlayer_ws_bytes(const egv_tlayer_desc* d, int backward)
         auto mx = [&](long long v) { if (v > wg) wg = v; };
         mx(egv_gemm_wgrad_workspace_bytes((int)D, (int)D, (int)BL)); mx(egv_gemm_wgrad_workspace_bytes((int)Hd, (int)D, (int)BL));
         mx(egv_gemm_wgrad_workspace_bytes((int)D, (int)Hd, (int)BL));
-        if (d->S > 0) mx(egv_gemm_wgrad_workspace_bytes((int)D, (int)D, (int)BS));
+        if (d->S > 0) mx(egv_gemm_wgrad_workspace_bytes(2 * (int)D, (int)D, (int)BS));
+        tot += al((size_t)tgroup_ws_bytes(d)) + 256;
         tot += al((size_t)wg) + al((size_t)egv_layernorm_bwd_workspace_bytes((int)BL, (int)D));
         tot += 17 * al(BL * D * es) + 3 * al(BL * D * 4) + al(BL * Hd * es) + 2 * al(BL * H * 4) + 4096;
         if (d->S > 0) tot += 3 * al(BS * D * es) + 4096;
@@ -626,10 +651,20 @@ extern "C" int egv_tlayer_fwd(const egv_tlayer_desc* d) {
         BCHK(egv_cast(EGV_F32, EGV_BF16, d->hid, sv + L.hid16, n, st));
         hid_op = sv + L.hid16;
     }
-    BCHK(lin_fwd(dt, BL, D, D, hid_op, d->w[TW_Q], d->b[TW_Q], sv + L.q, 0, nullptr, nullptr, nullptr, nullptr, st));
-    BCHK(lin_fwd(dt, BL, D, D, hid_op, d->w[TW_K], d->b[TW_K], sv + L.k, 0, nullptr, nullptr, nullptr, nullptr, st));
-    BCHK(lin_fwd(dt, BL, D, D, hid_op, d->w[TW_V], d->b[TW_V], sv + L.v, 0, nullptr, nullptr, nullptr, nullptr, st));
-    BCHK(tp.self.fwd(sv + L.q, D, sv + L.k, sv + L.v, D, sv + L.ctx, (float*)(sv + L.lse), aws, tp.awb, st));
+    const bool mq = tmq(d), mc = tmc(d);
+    const size_t es_ = esz(dt);
+    char* qp = sv + L.q;
+    char* kp = mq ? qp + (size_t)D * es_ : sv + L.k;
+    char* vp = mq ? qp + (size_t)2 * D * es_ : sv + L.v;
+    const int ldqkv = mq ? 3 * D : D;
+    if (mq) {
+        BCHK(lin_fwd(dt, BL, 3 * D, D, hid_op, d->w_qkv, d->b_qkv, qp, 0, nullptr, nullptr, nullptr, nullptr, st));
+    } else {
+        BCHK(lin_fwd(dt, BL, D, D, hid_op, d->w[TW_Q], d->b[TW_Q], qp, 0, nullptr, nullptr, nullptr, nullptr, st));
+        BCHK(lin_fwd(dt, BL, D, D, hid_op, d->w[TW_K], d->b[TW_K], kp, 0, nullptr, nullptr, nullptr, nullptr, st));
+        BCHK(lin_fwd(dt, BL, D, D, hid_op, d->w[TW_V], d->b[TW_V], vp, 0, nullptr, nullptr, nullptr, nullptr, st));
+    }
+    BCHK(tp.self.fwd(qp, ldqkv, kp, vp, ldqkv, sv + L.ctx, (float*)(sv + L.lse), aws, tp.awb, st));
     if (!fused) {
         if (r32) {
             BCHK(lin_fwd(dt, BL, D, D, sv + L.ctx, d->w[TW_AO], d->b[TW_AO], sv + L.a0, 0, nullptr, nullptr, nullptr, nullptr, st));
@@ -648,9 +683,15 @@ extern "C" int egv_tlayer_fwd(const egv_tlayer_desc* d) {
             a0x = sv + L.a0d;
         }
         BCHK(lin_fwd(dt, BL, D, D, a0x, d->w[TW_CQ], d->b[TW_CQ], sv + L.cq, 0, nullptr, nullptr, nullptr, nullptr, st));
-        BCHK(lin_fwd(dt, BS, D, D, d->enc, d->w[TW_CK], d->b[TW_CK], sv + L.ck, 0, nullptr, nullptr, nullptr, nullptr, st));
-        BCHK(lin_fwd(dt, BS, D, D, d->enc, d->w[TW_CV], d->b[TW_CV], sv + L.cv, 0, nullptr, nullptr, nullptr, nullptr, st));
-        BCHK(tp.cross.fwd(sv + L.cq, D, sv + L.ck, sv + L.cv, D, sv + L.cctx, (float*)(sv + L.lse_c), aws, tp.awb, st));
+        char* ckp = sv + L.ck;
+        char* cvp = mc ? ckp + (size_t)D * es_ : sv + L.cv;
+        if (mc) {
+            BCHK(lin_fwd(dt, BS, 2 * D, D, d->enc, d->w_ckv, d->b_ckv, ckp, 0, nullptr, nullptr, nullptr, nullptr, st));
+        } else {
+            BCHK(lin_fwd(dt, BS, D, D, d->enc, d->w[TW_CK], d->b[TW_CK], ckp, 0, nullptr, nullptr, nullptr, nullptr, st));
+            BCHK(lin_fwd(dt, BS, D, D, d->enc, d->w[TW_CV], d->b[TW_CV], cvp, 0, nullptr, nullptr, nullptr, nullptr, st));
+        }
+        BCHK(tp.cross.fwd(sv + L.cq, D, ckp, cvp, mc ? 2 * D : D, sv + L.cctx, (float*)(sv + L.lse_c), aws, tp.awb, st));
         if (!drop && !r32) {
             // alpha_t2i * dense(cctx) + a0 + hidden (roberta.py:486-488)
             BCHK(lin_fwd(dt, BL, D, D, sv + L.cctx, d->w[TW_CO], d->b[TW_CO], sv + L.a_pre, 0, d->alpha, a0x, d->hid, sv + L.pg, st));
@@ -704,34 +745,104 @@ extern "C" int egv_tlayer_bwd(const egv_tlayer_desc* d) {
     {
         auto mx = [&](long long v) { if (v > wgb) wgb = v; };
         mx(egv_gemm_wgrad_workspace_bytes(D, D, BL)); mx(egv_gemm_wgrad_workspace_bytes(Hd, D, BL)); mx(egv_gemm_wgrad_workspace_bytes(D, Hd, BL));
-        if (fused) mx(egv_gemm_wgrad_workspace_bytes(D, D, BS));
+        if (fused) mx(egv_gemm_wgrad_workspace_bytes(2 * D, D, BS));
     }
     void* wgw = ws.take((size_t)wgb);
     void* lnw = ws.take((size_t)egv_layernorm_bwd_workspace_bytes(BL, D));
     const size_t nb = (size_t)BL * D * es;
     void* df_pre = ws.take(nb); void* df0 = ws.take(nb); void* dpre = ws.take((size_t)BL * Hd * es); void* da = ws.take(nb);
     void* da_pre = ws.take(nb); void* da0 = ws.take(nb); void* dctx = ws.take(nb);
-    void* dq = ws.take(nb); void* dk = ws.take(nb); void* dv = ws.take(nb); void* t1 = ws.take(nb); void* t2 = ws.take(nb);
+    const bool mq = tmq(d), mc = tmc(d);
+    char* dqkv = (char*)ws.take(3 * nb);                          // [BL, 3D] when the projections are merged, else three [BL, D] blocks
+    void *dq = dqkv, *dk = mq ? dqkv + (size_t)D * es : dqkv + nb, *dv = mq ? dqkv + (size_t)2 * D * es : dqkv + 2 * nb;
+    const int lddqkv = mq ? 3 * D : D;
+    void* t1 = ws.take(nb); void* t2 = ws.take(nb);
     float* delta = (float*)ws.take((size_t)BL * H * 4);
     void *dyg = nullptr, *dcctx = nullptr, *dcq = nullptr, *dck = nullptr, *dcv = nullptr, *da0d = nullptr, *te = nullptr;
     float* delta_c = nullptr;
     if (fused) {
         dyg = ws.take(nb); dcctx = ws.take(nb); dcq = ws.take(nb); da0d = ws.take(nb);
-        dck = ws.take((size_t)BS * D * es); dcv = ws.take((size_t)BS * D * es); te = ws.take((size_t)BS * D * es);
+        char* dckv = (char*)ws.take((size_t)2 * BS * D * es);
+        dck = dckv; dcv = mc ? dckv + (size_t)D * es : dckv + (size_t)BS * D * es;
+        te = ws.take((size_t)BS * D * es);
         delta_c = (float*)ws.take((size_t)BL * H * 4);
     }
     void* dotw = ws.take(4096);
     if (!ws.ok()) { egv_set_error("egv_tlayer_bwd: workspace too small (%zu > %zu)", ws.off, ws.cap); return -1; }
     const long long n = (long long)BL * D;
-    auto wgrad = [&](int rows, int N, int K, const void* dz, const void* x, int w, const float* gate) -> int {
-        return lin_wgrad(dt, rows, N, K, dz, N, x, d->dw[w], d->db[w], gate, wgw, wgb, fk.begin());
-    };
     // dx = dz W + res (dgrad whose output also receives a skip gradient)
     auto dgrad_res = [&](int rows, int N, int K, const void* dz, int w, void* dx, const void* res, const float* gate) -> int {
         if (d->wt[w]) return egv_gemm(dt, 0, 0, rows, K, N, dz, N, d->wt[w], N, dx, K, 0, nullptr, 0, gate, res, nullptr, nullptr, nullptr, 0, K, 1.0f, st);
         return egv_gemm(dt, 0, 1, rows, K, N, dz, N, d->w[w], K, dx, K, 0, nullptr, 0, gate, res, nullptr, nullptr, nullptr, 0, K, 1.0f, st);
     };
 
+    // weight gradients over the B*L text rows: collected and launched together at the end of the call (ONE persistent grouped
+    // launch on this stream instead of 4-6 launches of 20 us that use a dozen CUs each); those over the B*S video rows of a fused
+    // layer keep their own launches on the companion stream
+    const bool grp_on = tgroup(d);
+    egv_wgrad_problem grp[8];
+    int ngrp = 0;
+    const long long gwb = grp_on ? tgroup_ws_bytes(d) : 0;
+    void* gws = grp_on ? ws.take((size_t)gwb) : nullptr;
+    if (!ws.ok()) { egv_set_error("egv_tlayer_bwd: workspace too small (%zu > %zu)", ws.off, ws.cap); return -1; }
+    auto wgrad_ld = [&](int rows, int N, int K, const void* dz, int ldz, const void* x, int w, const float* gate) -> int {
+        if (grp_on && rows == BL) {
+            egv_wgrad_problem& q = grp[ngrp++];
+            q.dy = dz; q.ldy = ldz; q.x = x; q.ldx = K; q.dw = d->dw[w]; q.db = d->db[w]; q.gate = gate; q.N = N; q.K = K;
+            return 0;
+        }
+        return lin_wgrad(dt, rows, N, K, dz, ldz, x, d->dw[w], d->db[w], gate, wgw, wgb, fk.begin());
+    };
+    auto wgrad = [&](int rows, int N, int K, const void* dz, const void* x, int w, const float* gate) -> int {
+        return wgrad_ld(rows, N, K, dz, N, x, w, gate);
+    };
+    const int ldckv = mc ? 2 * D : D;
+    const char* qp = sv + L.q;
+    const char* kp = mq ? qp + (size_t)D * es : sv + L.k;
+    const char* vp = mq ? qp + (size_t)2 * D * es : sv + L.v;
+    const int ldqkv = mq ? 3 * D : D;
+    const char* ckp = fused ? sv + L.ck : nullptr;
+    const char* cvp = fused ? (mc ? ckp + (size_t)D * es : sv + L.cv) : nullptr;
+    // gradients of the q / k / v projections: weight gradients (one [3D, D] problem when merged) and the data gradient
+    // out = dq Wq + dk Wk + dv Wv (+ res), ONE GEMM with K = 3D when merged
+    auto qkv_grads = [&](const void* hid_op, void* out, const void* res) -> int {
+        if (mq) {
+            BCHK(wgrad_ld(BL, 3 * D, D, dqkv, 3 * D, hid_op, TW_Q, nullptr));
+            if (d->wt_qkv) return egv_gemm(dt, 0, 0, BL, D, 3 * D, dqkv, 3 * D, d->wt_qkv, 3 * D, out, D, 0, nullptr, 0, nullptr, res, nullptr, nullptr, nullptr, 0, D, 1.0f, st);
+            return egv_gemm(dt, 0, 1, BL, D, 3 * D, dqkv, 3 * D, d->w_qkv, D, out, D, 0, nullptr, 0, nullptr, res, nullptr, nullptr, nullptr, 0, D, 1.0f, st);
+        }
+        BCHK(wgrad(BL, D, D, dq, hid_op, TW_Q, nullptr));
+        BCHK(wgrad(BL, D, D, dk, hid_op, TW_K, nullptr));
+        BCHK(wgrad(BL, D, D, dv, hid_op, TW_V, nullptr));
+        auto one = [&](const void* dz, int w, void* dx, const void* r) -> int {
+            if (d->wt[w]) return egv_gemm(dt, 0, 0, BL, D, D, dz, D, d->wt[w], D, dx, D, 0, nullptr, 0, nullptr, r, nullptr, nullptr, nullptr, 0, D, 1.0f, st);
+            return egv_gemm(dt, 0, 1, BL, D, D, dz, D, d->w[w], D, dx, D, 0, nullptr, 0, nullptr, r, nullptr, nullptr, nullptr, 0, D, 1.0f, st);
+        };
+        BCHK(one(dq, TW_Q, t1, res));
+        BCHK(one(dk, TW_K, t2, t1));
+        return one(dv, TW_V, out, t2);
+    };
+    // gradients of the text-to-image key / value projections over the video tokens
+    auto ckv_grads = [&]() -> int {
+        if (mc) {
+            BCHK(lin_wgrad(dt, BS, 2 * D, D, dck, 2 * D, d->enc, d->dw[TW_CK], d->db[TW_CK], nullptr, wgw, wgb, fk.begin()));
+            if (!d->denc) return 0;
+            if (d->wt_ckv) return egv_gemm(dt, 0, 0, BS, D, 2 * D, dck, 2 * D, d->wt_ckv, 2 * D, d->denc, D, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, D, 1.0f, st);
+            return egv_gemm(dt, 0, 1, BS, D, 2 * D, dck, 2 * D, d->w_ckv, D, d->denc, D, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, D, 1.0f, st);
+        }
+        BCHK(lin_wgrad(dt, BS, D, D, dck, D, d->enc, d->dw[TW_CK], d->db[TW_CK], nullptr, wgw, wgb, fk.begin()));
+        BCHK(lin_wgrad(dt, BS, D, D, dcv, D, d->enc, d->dw[TW_CV], d->db[TW_CV], nullptr, wgw, wgb, fk.begin()));
+        if (d->denc) {
+            BCHK(lin_dgrad(dt, BS, D, D, dck, d->w[TW_CK], d->wt[TW_CK], te, nullptr, nullptr, 0, st));
+            BCHK(dgrad_res(BS, D, D, dcv, TW_CV, d->denc, te, nullptr));
+        }
+        return 0;
+    };
+    auto finish = [&]() -> int {
+        if (ngrp) BCHK(egv_gemm_wgrad_grouped(dt, BL, ngrp, grp, 0, gws, gwb, st));
+        fk.join();
+        return 0;
+    };
     const bool r32 = tres32(d);
     if (r32) {
         // ---- fp32 residual stream: the gradients of the fp32 tensors (layer output, the two pre-LayerNorm sums, the attention
@@ -764,16 +875,11 @@ extern "C" int egv_tlayer_bwd(const egv_tlayer_desc* d) {
             BCHK(egv_dot(dt, dyg, sv + L.pg, n, d->dalpha, 1.0f, dotw, st));
             BCHK(wgrad(BL, D, D, dyg, sv + L.cctx, TW_CO, d->alpha));
             BCHK(lin_dgrad(dt, BL, D, D, dyg, d->w[TW_CO], d->wt[TW_CO], dcctx, d->alpha, nullptr, 0, st));
-            BCHK(tp.cross.bwd(sv + L.cq, D, sv + L.ck, sv + L.cv, D, sv + L.cctx, (float*)const_cast<char*>(sv + L.lse_c), dcctx, dcq, D, dck, dcv, D, delta_c,
+            BCHK(tp.cross.bwd(sv + L.cq, D, ckp, cvp, ldckv, sv + L.cctx, (float*)const_cast<char*>(sv + L.lse_c), dcctx, dcq, D, dck, dcv, ldckv, delta_c,
                               aws, tp.awb, st));
             BCHK(wgrad(BL, D, D, dcq, a0x, TW_CQ, nullptr));
             BCHK(lin_dgrad(dt, BL, D, D, dcq, d->w[TW_CQ], d->wt[TW_CQ], da0d, nullptr, nullptr, 0, st));
-            BCHK(wgrad(BS, D, D, dck, d->enc, TW_CK, nullptr));
-            BCHK(wgrad(BS, D, D, dcv, d->enc, TW_CV, nullptr));
-            if (d->denc) {
-                BCHK(lin_dgrad(dt, BS, D, D, dck, d->w[TW_CK], d->wt[TW_CK], te, nullptr, nullptr, 0, st));
-                BCHK(dgrad_res(BS, D, D, dcv, TW_CV, d->denc, te, nullptr));
-            }
+            BCHK(ckv_grads());
             // a0 (after its dropout) feeds the cross-attention query AND the residual: (bf16 data gradient + fp32 da_pre), then the
             // dropout of attention.output
             BCHK(egv_dropout_add_mixed(EGV_BF16, da0d, nullptr, da_pre32, EGV_F32, s32, n, 0.f, 0u, st));
@@ -781,17 +887,11 @@ extern "C" int egv_tlayer_bwd(const egv_tlayer_desc* d) {
         }
         BCHK(wgrad(BL, D, D, d_ao, sv + L.ctx, TW_AO, nullptr));
         BCHK(lin_dgrad(dt, BL, D, D, d_ao, d->w[TW_AO], d->wt[TW_AO], dctx, nullptr, nullptr, 0, st));
-        BCHK(tp.self.bwd(sv + L.q, D, sv + L.k, sv + L.v, D, sv + L.ctx, (float*)const_cast<char*>(sv + L.lse), dctx, dq, D, dk, dv, D, delta, aws, tp.awb, st));
-        BCHK(wgrad(BL, D, D, dq, sv + L.hid16, TW_Q, nullptr));
-        BCHK(wgrad(BL, D, D, dk, sv + L.hid16, TW_K, nullptr));
-        BCHK(wgrad(BL, D, D, dv, sv + L.hid16, TW_V, nullptr));
-        BCHK(lin_dgrad(dt, BL, D, D, dq, d->w[TW_Q], d->wt[TW_Q], t1, nullptr, nullptr, 0, st));
-        BCHK(dgrad_res(BL, D, D, dk, TW_K, t2, t1, nullptr));
-        BCHK(dgrad_res(BL, D, D, dv, TW_V, t1, t2, nullptr));
+        BCHK(tp.self.bwd(qp, ldqkv, kp, vp, ldqkv, sv + L.ctx, (float*)const_cast<char*>(sv + L.lse), dctx, dq, lddqkv, dk, dv, lddqkv, delta, aws, tp.awb, st));
+        BCHK(qkv_grads(sv + L.hid16, dctx, nullptr));         // (dctx is free again: the bf16 sum of the three data gradients)
         // dhid (fp32) = data gradients of q / k / v (bf16 sum) + the residual path
-        BCHK(egv_dropout_add_mixed(EGV_BF16, t1, nullptr, da_pre32, EGV_F32, d->dhid, n, 0.f, 0u, st));
-        fk.join();
-        return 0;
+        BCHK(egv_dropout_add_mixed(EGV_BF16, dctx, nullptr, da_pre32, EGV_F32, d->dhid, n, 0.f, 0u, st));
+        return finish();
     }
     // out = LN(f_pre)
     BCHK(egv_layernorm_bwd2(dt, d->dout, sv + L.f_pre, (const float*)(sv + L.stats1), d->ln_g[TL_OUT], nullptr, nullptr, df_pre, d->dln_g[TL_OUT],
@@ -825,16 +925,11 @@ extern "C" int egv_tlayer_bwd(const egv_tlayer_desc* d) {
         BCHK(egv_dot(dt, dy_, sv + L.pg, n, d->dalpha, 1.0f, dotw, st));
         BCHK(wgrad(BL, D, D, dy_, sv + L.cctx, TW_CO, d->alpha));
         BCHK(lin_dgrad(dt, BL, D, D, dy_, d->w[TW_CO], d->wt[TW_CO], dcctx, d->alpha, nullptr, 0, st));
-        BCHK(tp.cross.bwd(sv + L.cq, D, sv + L.ck, sv + L.cv, D, sv + L.cctx, (float*)const_cast<char*>(sv + L.lse_c), dcctx, dcq, D, dck, dcv, D, delta_c,
+        BCHK(tp.cross.bwd(sv + L.cq, D, ckp, cvp, ldckv, sv + L.cctx, (float*)const_cast<char*>(sv + L.lse_c), dcctx, dcq, D, dck, dcv, ldckv, delta_c,
                           aws, tp.awb, st));
         BCHK(wgrad(BL, D, D, dcq, a0x, TW_CQ, nullptr));
         BCHK(dgrad_res(BL, D, D, dcq, TW_CQ, da0d, da_pre, nullptr));                       // a0 also feeds the residual
-        BCHK(wgrad(BS, D, D, dck, d->enc, TW_CK, nullptr));
-        BCHK(wgrad(BS, D, D, dcv, d->enc, TW_CV, nullptr));
-        if (d->denc) {
-            BCHK(lin_dgrad(dt, BS, D, D, dck, d->w[TW_CK], d->wt[TW_CK], te, nullptr, nullptr, 0, st));
-            BCHK(dgrad_res(BS, D, D, dcv, TW_CV, d->denc, te, nullptr));
-        }
+        BCHK(ckv_grads());
         d_ao = da0d;
         if (drop) {
             BCHK(egv_dropout_add(dt, da0d, nullptr, nullptr, da0, n, p, d->seeds[1], st));
@@ -843,13 +938,7 @@ extern "C" int egv_tlayer_bwd(const egv_tlayer_desc* d) {
     }
     BCHK(wgrad(BL, D, D, d_ao, sv + L.ctx, TW_AO, nullptr));
     BCHK(lin_dgrad(dt, BL, D, D, d_ao, d->w[TW_AO], d->wt[TW_AO], dctx, nullptr, nullptr, 0, st));
-    BCHK(tp.self.bwd(sv + L.q, D, sv + L.k, sv + L.v, D, sv + L.ctx, (float*)const_cast<char*>(sv + L.lse), dctx, dq, D, dk, dv, D, delta, aws, tp.awb, st));
-    BCHK(wgrad(BL, D, D, dq, d->hid, TW_Q, nullptr));
-    BCHK(wgrad(BL, D, D, dk, d->hid, TW_K, nullptr));
-    BCHK(wgrad(BL, D, D, dv, d->hid, TW_V, nullptr));
-    BCHK(dgrad_res(BL, D, D, dq, TW_Q, t1, da_pre, nullptr));
-    BCHK(dgrad_res(BL, D, D, dk, TW_K, t2, t1, nullptr));
-    BCHK(dgrad_res(BL, D, D, dv, TW_V, d->dhid, t2, nullptr));
-    fk.join();
-    return 0;
+    BCHK(tp.self.bwd(qp, ldqkv, kp, vp, ldqkv, sv + L.ctx, (float*)const_cast<char*>(sv + L.lse), dctx, dq, lddqkv, dk, dv, lddqkv, delta, aws, tp.awb, st));
+    BCHK(qkv_grads(d->hid, d->dhid, da_pre));
+    return finish();
 }

@@ -243,7 +243,7 @@ struct GroupPlan {
     long long nslab;
 };
 static int group_plan(int M, int nprob, const egv_wgrad_problem* pr, int cus, GroupPlan& gp) {
-    if (nprob < 1 || nprob > WG_MAXP || M < 512) return 0;
+    if (nprob < 1 || nprob > WG_MAXP || M < 64) return 0;
     gp.ntile = 0;
     for (int i = 0; i < nprob; ++i) {
         if ((pr[i].N % 256) || (pr[i].K % 256) || pr[i].N <= 0 || pr[i].K <= 0) return 0;
@@ -274,7 +274,7 @@ extern "C" int egv_gemm_wgrad_grouped(int dtype, int M, int nprob, const egv_wgr
     EGV_CHECK(dtype == EGV_BF16, "egv_gemm_wgrad_grouped: bf16 operands only");
     GroupPlan gp;
     cus = group_cus(cus);
-    EGV_CHECK(pr && group_plan(M, nprob, pr, cus, gp), "egv_gemm_wgrad_grouped: unsupported group (1..%d problems, N and K multiples of 256, M >= 512)", WG_MAXP);
+    EGV_CHECK(pr && group_plan(M, nprob, pr, cus, gp), "egv_gemm_wgrad_grouped: unsupported group (1..%d problems, N and K multiples of 256, M >= 64)", WG_MAXP);
     EGV_CHECK(workspace && workspace_bytes >= egv_gemm_wgrad_grouped_workspace_bytes(M, nprob, pr, cus), "egv_gemm_wgrad_grouped: workspace too small");
     WgGroup g{};
     const int ntile = gp.ntile;

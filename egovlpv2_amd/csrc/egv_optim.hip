@@ -72,7 +72,21 @@ struct CastRec {          // 32 bytes, one per tensor; R and C are multiples of 
     int R, C;
 };
 
-__global__ __launch_bounds__(256) void cast_weights_kernel(const CastRec* __restrict__ table, const int* __restrict__ prefix, int ntensors) {
+struct CastRecLd {        // 40 bytes: the same with a row pitch for the transposed copy (merged same-input projections)
+    const float* src;
+    bf16_t* dst;
+    bf16_t* dst_t;        // element (c, r) at dst_t[c * ldt + r]
+    int R, C, ldt, pad;
+};
+struct SegRec { const float* src; float* dst; long long n; };
+
+__global__ __launch_bounds__(256) void copy_segments_kernel(const SegRec* __restrict__ table) {
+    const SegRec s = table[blockIdx.x];
+    for (long long i = threadIdx.x; i < s.n; i += 256) s.dst[i] = s.src[i];
+}
+
+template <typename REC>
+__global__ __launch_bounds__(256) void cast_weights_kernel(const REC* __restrict__ table, const int* __restrict__ prefix, int ntensors) {
     __shared__ float tile[64][65];
     const int c = blockIdx.x;
     int lo = 0, hi = ntensors;                       // largest t with prefix[t] <= c
@@ -80,7 +94,9 @@ __global__ __launch_bounds__(256) void cast_weights_kernel(const CastRec* __rest
         const int mid = (lo + hi) >> 1;
         if (prefix[mid] <= c) lo = mid; else hi = mid;
     }
-    const CastRec rec = table[lo];
+    const REC rec = table[lo];
+    int ldt = rec.R;
+    if constexpr (sizeof(REC) == sizeof(CastRecLd)) ldt = reinterpret_cast<const CastRecLd&>(rec).ldt;
     const int t = c - prefix[lo], tiles_c = rec.C >> 6;
     const int r0 = (t / tiles_c) << 6, c0 = (t % tiles_c) << 6;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;          // 16 lanes x 4 floats per 64-wide row, 16 rows per pass
@@ -97,7 +113,7 @@ __global__ __launch_bounds__(256) void cast_weights_kernel(const CastRec* __rest
     for (int i = 0; i < 4; ++i) {
         const int cc = ty + i * 16;                                  // column of the source tile = row of the transposed copy
         u32x2_t o = {pack_bf16x2(tile[tx * 4 + 0][cc], tile[tx * 4 + 1][cc]), pack_bf16x2(tile[tx * 4 + 2][cc], tile[tx * 4 + 3][cc])};
-        *reinterpret_cast<u32x2_t*>(rec.dst_t + (size_t)(c0 + cc) * rec.R + r0 + tx * 4) = o;
+        *reinterpret_cast<u32x2_t*>(rec.dst_t + (size_t)(c0 + cc) * ldt + r0 + tx * 4) = o;
     }
 }
 
@@ -108,8 +124,23 @@ using namespace egv;
 // pointers 16-byte aligned); prefix: device int32[ntensors + 1], prefix[t] = number of 64x64 tiles before tensor t.
 extern "C" int egv_cast_weights(const void* table, const int* prefix, int ntensors, int ntiles, void* stream) {
     EGV_CHECK(table && prefix && ntensors > 0 && ntiles > 0, "egv_cast_weights: empty table");
-    hipLaunchKernelGGL(cast_weights_kernel, dim3(ntiles), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const CastRec*)table,
+    hipLaunchKernelGGL(cast_weights_kernel<CastRec>, dim3(ntiles), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const CastRec*)table,
                        prefix, ntensors);
+    EGV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int egv_cast_weights_ld(const void* table, const int* prefix, int ntensors, int ntiles, void* stream) {
+    EGV_CHECK(table && prefix && ntensors > 0 && ntiles > 0, "egv_cast_weights_ld: empty table");
+    hipLaunchKernelGGL(cast_weights_kernel<CastRecLd>, dim3(ntiles), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const CastRecLd*)table,
+                       prefix, ntensors);
+    EGV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int egv_copy_segments(const void* table, int nseg, void* stream) {
+    EGV_CHECK(table && nseg > 0, "egv_copy_segments: empty table");
+    hipLaunchKernelGGL(copy_segments_kernel, dim3(nseg), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const SegRec*)table);
     EGV_LAUNCH_CHECK();
     return 0;
 }

@@ -120,8 +120,8 @@ def compute_weight_t(w: torch.Tensor, dtype: torch.dtype):
         return None
     key = id(w)
     ent = _wtcache.get(key)
-    if ent is not None and ent[0] == w._version and ent[1].device == w.device and ent[2] is w:
-        return _cross_stream(ent)
+    if ent is not None and ent[0] == w._version and ent[2] is w and (ent[1] is None or ent[1].device == w.device):
+        return None if ent[1] is None else _cross_stream(ent)
     N, K = w.shape
     out = torch.empty(K, N, dtype=dtype, device=w.device)
     src = w.detach()
@@ -133,12 +133,18 @@ def compute_weight_t(w: torch.Tensor, dtype: torch.dtype):
 
 
 _wprep = {}
+_wmerged = {}            # id(first weight of a group) -> (versions, merged W [sum R, C], merged W^T [C, sum R], merged bias or None, members, stream, event)
 
 
-def prepare_weights(weights, dtype: torch.dtype):
+def prepare_weights(weights, dtype: torch.dtype, groups=()):
     """One launch that makes the bf16 W and W^T compute copies of every listed fp32 [R, C] weight (R, C multiples of 64) and
     seeds the two caches above, so that the forward/backward of the step finds them ready.  Weights that do not qualify are
-    left to the lazy per-tensor path.  A no-op when the copies of the current parameter versions already exist."""
+    left to the lazy per-tensor path.  A no-op when the copies of the current parameter versions already exist.
+
+    groups: tuples (weights, biases) of Linears that read the SAME input (query / key / value of a RoBERTa layer, key / value of its
+    text-to-image cross attention): their copies are laid out as ONE [sum R, C] matrix (row blocks) and ONE [C, sum R] transposed matrix
+    (column blocks, written with a row pitch), and their biases are concatenated by a second small launch, so that the layer can run
+    them as one GEMM (merged_weights).  The per-weight entries of the caches are views of the merged buffers."""
     if dtype != torch.bfloat16:
         return
     ws = [w for w in weights if w.dim() == 2 and w.dtype == torch.float32 and w.is_contiguous() and w.is_cuda
@@ -154,26 +160,86 @@ def prepare_weights(weights, dtype: torch.dtype):
     ent = _wprep.get(key)
     ptrs = [w.data_ptr() for w in ws]
     if ent is None or ent['ptrs'] != ptrs:
-        outs = [(torch.empty(w.shape, dtype=dtype, device=w.device), torch.empty(w.shape[1], w.shape[0], dtype=dtype, device=w.device))
-                for w in ws]
-        arr = np.zeros(len(ws), dtype=[('s', '<u8'), ('d', '<u8'), ('t', '<u8'), ('R', '<i4'), ('C', '<i4')])
+        dev = ws[0].device
+        in_list = {id(w) for w in ws}
+        member = {}                                    # id(w) -> (merged W, merged W^T, row offset, total rows)
+        merged = []
+        for gw, gb in groups:
+            if not all(id(w) in in_list for w in gw) or len({w.shape[1] for w in gw}) != 1:
+                continue
+            R, Cc = sum(w.shape[0] for w in gw), gw[0].shape[1]
+            mw, mt = torch.empty(R, Cc, dtype=dtype, device=dev), torch.empty(Cc, R, dtype=dtype, device=dev)
+            mb = torch.empty(R, dtype=torch.float32, device=dev) if (gb and all(b_ is not None for b_ in gb)) else None
+            off = 0
+            for w in gw:
+                member[id(w)] = (mw, mt, off, R)
+                off += w.shape[0]
+            merged.append((gw, gb, mw, mt, mb))
+        outs, ldts = [], []
+        for w in ws:
+            m = member.get(id(w))
+            if m is None:
+                outs.append((torch.empty(w.shape, dtype=dtype, device=dev), torch.empty(w.shape[1], w.shape[0], dtype=dtype, device=dev)))
+                ldts.append(w.shape[0])
+            else:
+                mw, mt, off, R = m
+                outs.append((mw[off:off + w.shape[0]], mt[:, off:off + w.shape[0]]))       # W^T block: row pitch R (only the merged matrix is used)
+                ldts.append(R)
+        arr = np.zeros(len(ws), dtype=[('s', '<u8'), ('d', '<u8'), ('t', '<u8'), ('R', '<i4'), ('C', '<i4'), ('ldt', '<i4'), ('pad', '<i4')])
         arr['s'] = ptrs
         arr['d'] = [o[0].data_ptr() for o in outs]
         arr['t'] = [o[1].data_ptr() for o in outs]
         arr['R'] = [w.shape[0] for w in ws]
         arr['C'] = [w.shape[1] for w in ws]
+        arr['ldt'] = ldts
         prefix = np.zeros(len(ws) + 1, dtype=np.int32)
         prefix[1:] = np.cumsum([(w.shape[0] // 64) * (w.shape[1] // 64) for w in ws])
-        dev = ws[0].device
         pin = torch.from_numpy(arr.view(np.uint8).copy()).pin_memory()
         pre = torch.from_numpy(prefix).pin_memory()
+        segs = [(b_, mb, o) for gw, gb, mw, mt, mb in merged if mb is not None
+                for b_, o in zip(gb, np.cumsum([0] + [w.shape[0] for w in gw])[:-1])]
+        seg_tab = seg_pin = None
+        if segs:
+            sarr = np.zeros(len(segs), dtype=[('s', '<u8'), ('d', '<u8'), ('n', '<i8')])
+            sarr['s'] = [b_.data_ptr() for b_, _, _ in segs]
+            sarr['d'] = [mb.data_ptr() + 4 * int(o) for _, mb, o in segs]
+            sarr['n'] = [b_.numel() for b_, _, _ in segs]
+            seg_pin = torch.from_numpy(sarr.view(np.uint8).copy()).pin_memory()
+            seg_tab = seg_pin.to(dev, non_blocking=True)
         ent = _wprep[key] = {'ptrs': ptrs, 'outs': outs, 'table': pin.to(dev, non_blocking=True), 'prefix': pre.to(dev, non_blocking=True),
-                             'ntiles': int(prefix[-1]), 'pins': (pin, pre), 'refs': ws}
-    check(lib.egv_cast_weights(_p(ent['table']), _p(ent['prefix']), len(ws), ent['ntiles'], _st()), 'egv_cast_weights')
+                             'ntiles': int(prefix[-1]), 'pins': (pin, pre, seg_pin), 'refs': ws, 'merged': merged, 'segs': seg_tab, 'nseg': len(segs),
+                             'bias_ptrs': [b_.data_ptr() for b_, _, _ in segs]}
+    check(lib.egv_cast_weights_ld(_p(ent['table']), _p(ent['prefix']), len(ws), ent['ntiles'], _st()), 'egv_cast_weights_ld')
+    if ent['nseg']:
+        check(lib.egv_copy_segments(_p(ent['segs']), ent['nseg'], _st()), 'egv_copy_segments')
     ev, st = _cast_event(), _st()
     for w, (o, ot) in zip(ws, ent['outs']):
         _wcache[id(w)] = (w._version, o, w, st, ev)
-        _wtcache[id(w)] = (w._version, ot, w, st, ev)
+        # a member of a merged group has no transposed copy of its own (its block of the merged W^T has the group's row pitch):
+        # an un-merged dgrad on it reads W as a [reduction, out] operand
+        _wtcache[id(w)] = (w._version, ot if ot.is_contiguous() else None, w, st, ev)
+    for gw, gb, mw, mt, mb in ent['merged']:
+        vers = tuple(w._version for w in gw) + tuple(b_._version for b_ in (gb or ()) if b_ is not None)
+        _wmerged[id(gw[0])] = (vers, mw, mt, mb, (gw, gb), st, ev)
+
+
+def merged_weights(ws, bs):
+    """(W [sum R, C], W^T [C, sum R], bias [sum R]) of a group prepared by prepare_weights(..., groups=...), or None when the group has
+    no current merged copies (parameters changed since, another dtype, lazy per-tensor casts)"""
+    ent = _wmerged.get(id(ws[0]))
+    if ent is None:
+        return None
+    gw, gb = ent[4]
+    if len(gw) != len(ws) or any(a is not b for a, b in zip(gw, ws)) or (ent[3] is not None and any(a is not b for a, b in zip(gb, bs))):
+        return None
+    vers = tuple(w._version for w in ws) + (tuple(b_._version for b_ in bs) if ent[3] is not None else ())
+    if vers != ent[0] or ent[3] is None:
+        return None
+    c = _wcache.get(id(ws[0]))
+    if c is None or c[4] is not ent[6]:                     # the per-weight copies were re-made by another path since
+        return None
+    _cross_stream((ent[0], ent[1], None, ent[5], ent[6]))
+    return ent[1], ent[2], ent[3]
 
 
 def dgrad(dz, weight, dx, M, N, K, gate=None, aux=None, dact=0):
@@ -810,14 +876,16 @@ def _fill_weights(d, weights, dtype):
 class _GradPack:
     """one flat fp32 buffer holding the gradients of every parameter of a block call; views are handed to autograd"""
 
-    def __init__(self, params, device):
+    def __init__(self, params, device, order=None):
+        """order: the parameter indices in the order they are laid out in the flat buffer (default: as listed) -- weights whose
+        gradients one GEMM writes as one matrix (merged query / key / value) are made adjacent this way; views stay in list order"""
         sizes = [p.numel() for p in params]
         self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
-        self.views = []
+        self.views = [None] * len(params)
         off = 0
-        for p, n in zip(params, sizes):
-            self.views.append(self.flat[off:off + n].view(p.shape))
-            off += n
+        for i in (order if order is not None else range(len(params))):
+            self.views[i] = self.flat[off:off + sizes[i]].view(params[i].shape)
+            off += sizes[i]
 
 
 # Parameter gradients of a block that is used several times per step (EgoNCE / MLM / ITM passes share the backbones): every
@@ -1097,8 +1165,21 @@ class TextLayerFn(Function):
         if fused:
             d.alpha = _p(params[24])
             d.enc = _p(enc)
+        if d.dtype == L.EGV_BF16:
+            m = merged_weights([params[0], params[2], params[4]], [params[1], params[3], params[5]])
+            if m is not None:
+                d.w_qkv, d.wt_qkv, d.b_qkv = _p(m[0]), _p(m[1]), _p(m[2])
+            if fused:
+                m = merged_weights([params[18], params[20]], [params[19], params[21]])
+                if m is not None:
+                    d.w_ckv, d.wt_ckv, d.b_ckv = _p(m[0]), _p(m[1]), _p(m[2])
         d.stream = _st()
         return d
+
+    # flat gradient layout: [Wq Wk Wv | bq bk bv | ...] and, in the fused extras, [Wcq bcq | Wck Wcv | bck bcv | ...]: the merged
+    # projections write their weight / bias gradients as one matrix / one vector
+    ORDER = [0, 2, 4, 1, 3, 5] + list(range(6, 16))
+    ORDER_FUSED = ORDER + [16, 17, 18, 20, 19, 21, 22, 23, 24]
 
     @staticmethod
     def forward(ctx, cfg, hid, mask, enc, *params):
@@ -1128,7 +1209,7 @@ class TextLayerFn(Function):
         denc = torch.empty_like(enc) if (fused and ctx.needs_input_grad[3]) else None
         if cfg[9] and dout.dtype != torch.float32:
             dout = dout.float()
-        gp = _GradPack(params, hid.device)
+        gp = _GradPack(params, hid.device, TextLayerFn.ORDER_FUSED if fused else TextLayerFn.ORDER)
         nwsb = lib.egv_tlayer_ws_bytes(C.byref(d), 1)
         ws = torch.empty(nwsb, dtype=torch.uint8, device=hid.device)
         d.save, d.save_bytes, d.ws, d.ws_bytes = _p(save), save.numel(), _p(ws), nwsb
@@ -1385,3 +1466,4 @@ def invalidate_weight_cache():
     """Drop the compute-dtype weight copies (call once per optimisation step: the fp32 masters changed)."""
     _wcache.clear()
     _wtcache.clear()
+    _wmerged.clear()

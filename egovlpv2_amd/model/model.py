@@ -300,7 +300,19 @@ class FrozenInTime(nn.Module):
         if lst is None:
             lst = self.__dict__['_gemm_weights'] = [p for n, p in self.named_parameters()
                                                     if p.dim() == 2 and n.endswith('.weight') and 'embeddings' not in n]
-        ops.prepare_weights(lst, self.compute_dtype)
+            # Linears that read the same input run as one GEMM (csrc/egv_block.cpp): query / key / value of every RoBERTa layer
+            # (roberta.py:257-270) and key / value of the text-to-image cross attention (roberta.py:241-242)
+            groups = []
+            c = self.cfg
+            for i in range(c.depth):
+                pfx = f'text_model.encoder.layer.{i}'
+                sets = [[f'{pfx}.attention.self.{m}' for m in ('query', 'key', 'value')]]
+                if i >= c.depth - c.n_fuse:
+                    sets.append([f'{pfx}.crossattention_t2i.self.{m}' for m in ('key', 'value')])
+                for names in sets:
+                    groups.append(([self.p(n + '.weight') for n in names], [self.p(n + '.bias') for n in names]))
+            self.__dict__['_gemm_groups'] = groups if os.environ.get('EGV_MERGE_PROJ', '1') != '0' else []
+        ops.prepare_weights(lst, self.compute_dtype, groups=self.__dict__['_gemm_groups'])
 
     def p(self, name: str) -> torch.Tensor:
         if self._P is None:

@@ -215,6 +215,13 @@ int egv_egonce_bwd(const float* x, const float* sim_v, const float* sim_n, const
    {const float* src; void* dst; void* dst_t; int R; int C} with R % 64 == C % 64 == 0; prefix: device int32[ntensors + 1],
    prefix[t] = number of 64x64 tiles before tensor t; ntiles = prefix[ntensors]. */
 int egv_cast_weights(const void* table, const int* prefix, int ntensors, int ntiles, void* stream);
+/* The same with a row pitch for the transposed copy: 40-byte records {const float* src; void* dst; void* dst_t; int R; int C; int ldt;
+   int pad} -- dst_t[c * ldt + r]; several weights that share their input (query / key / value) then land side by side in ONE
+   [C, sum R] transposed matrix (and, with consecutive dst blocks, in ONE [sum R, C] matrix). */
+int egv_cast_weights_ld(const void* table, const int* prefix, int ntensors, int ntiles, void* stream);
+/* fp32 segment copies in one launch (the concatenated biases of merged projections): table = device array of 24-byte records
+   {const float* src; float* dst; long long n} */
+int egv_copy_segments(const void* table, int nseg, void* stream);
 /* ---- fused multi-tensor AdamW (set_optim_schedule.py:108 -> transformers 4.30 AdamW: eps on sqrt(v) without bias
  * correction of the denominator, step_size = lr*sqrt(1-b2^t)/(1-b1^t), weight decay p -= lr*wd*p AFTER the update).
  * table: device array of 32-byte records {float* p; const float* g; float* m; float* v; int n; int pad}, one per tensor;
@@ -289,6 +296,12 @@ typedef struct egv_tlayer_desc {
     float* dw[10]; float* db[10]; float* dln_g[2]; float* dln_b[2]; float* dalpha;
     void* stream; void* stream2;
     int flags;                                      /* EGV_BLOCK_* */
+    /* Same-input projections as ONE GEMM (bf16 mode; each may be NULL -> three / two separate GEMMs): w_qkv = [query ; key ; value]
+     * rows [3D, D], wt_qkv its transpose [D, 3D], b_qkv [3D] (roberta.py:257-270 reads hidden_states three times); w_ckv = text-to-image
+     * [key ; value] [2D, D] over the video tokens (roberta.py:241-242,274-277), wt_ckv [D, 2D], b_ckv [2D].  With w_qkv set, dw[1], dw[2]
+     * must follow dw[0] contiguously ([3D, D] fp32) and db[1], db[2] follow db[0]; with w_ckv set, dw[8] follows dw[7] and db[8] db[7]. */
+    const void* w_qkv; const void* wt_qkv; const float* b_qkv;
+    const void* w_ckv; const void* wt_ckv; const float* b_ckv;
 } egv_tlayer_desc;
 long long egv_tlayer_save_bytes(const egv_tlayer_desc* d);
 long long egv_tlayer_ws_bytes(const egv_tlayer_desc* d, int backward);
