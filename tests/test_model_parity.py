@@ -547,3 +547,69 @@ def test_training_step_is_bitwise_reproducible():
             assert runs[0][1][n].abs().sum() > 0, n
         for n in runs[0][1]:
             assert torch.equal(runs[0][1][n], r[1][n]), n
+
+
+def test_long_clip_full_size_properties_bf16():
+    """BASELINE.json configs[3] at its full size: ViT-B/16 + RoBERTa-base at full depth, B = 16 clips of 32 x 224^2 frames
+    (6273 video tokens per clip, 33-key time attention), 77-token captions, inference-only `infer('EgoNCE')`.  No oracle finishes
+    this size in seconds, so size-independent properties: every output finite and non-degenerate, the rows of one sample do not
+    depend on its position in the batch or on the other samples (bitwise: same kernels, same per-sample reduction orders), and the
+    `Feature_Extraction` short-circuit of forward() returns the same video embeddings."""
+    from egovlpv2_amd.config import PathConfig
+    from egovlpv2_amd.synthetic import make_state_dict, make_batch
+    cfg = PathConfig(frames=32)
+    sd = make_state_dict(cfg, 5)
+    m = _build(cfg, sd, torch.bfloat16).eval()
+    data, _, _ = make_batch(cfg, 16, 77, 13)
+    cu = _to_cuda(data)
+    with torch.no_grad():
+        full = m.infer(cu, task_names='EgoNCE')
+        feat = m(cu, None, None, None, None, None, None, None, None, task_names='Feature_Extraction')
+        pick = [11, 2]
+        part = {'video': cu['video'][pick], 'text': {k: v[pick] for k, v in cu['text'].items()}}
+        sub = m.infer(part, task_names='EgoNCE')
+    assert full['video_embeds'].shape == (16, cfg.proj_dim) and full['text_embeds'].shape == (16, cfg.proj_dim)
+    for k in ('video_embeds', 'text_embeds'):
+        v = full[k].float()
+        assert torch.isfinite(v).all(), k
+        assert float(v.std(0).mean()) > 0, k          # the 16 rows differ
+        assert torch.equal(full[k][pick], sub[k]), k
+    assert torch.equal(feat, full['video_embeds'])
+
+
+def test_vit_large_full_depth_step_properties_bf16():
+    """BASELINE.json configs[4] geometry at full depth in bf16 (the fp8 weight path is not built): ViT-L/14 (24 blocks, d = 1024,
+    16 heads, 257 keys per space-attention group) + a RoBERTa-large-shaped text tower (24 layers), 6 fused, B = 4 clips of
+    16 x 224^2 frames, 32 tokens, the three-loss training step.  Properties at full size: the losses and every gradient are
+    finite, every parameter that takes part receives a non-zero gradient, and a second run of the same step is bit-identical."""
+    from egovlpv2_amd.config import PathConfig
+    from egovlpv2_amd.synthetic import make_state_dict, make_batch
+    cfg = PathConfig(depth=24, n_fuse=6, patch=14, dim=1024, heads=16, drop_rate=0.1)
+    B, L = 4, 32
+    sd = make_state_dict(cfg, 8)
+    data, noun, verb = make_batch(cfg, B, L, 99)
+    m = _build(cfg, sd, torch.bfloat16).train()
+    del sd
+    runs = []
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        m.seed_dropout(7)
+        np.random.seed(4)
+        torch.manual_seed(4)
+        loss, ld, _ = _forward(m, data, noun, verb, 'EgoNCE_MLM_ITM')
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append(({k: float(ld[k].detach()) for k in ('EgoNCE', 'loss_mlm', 'loss_itm', 'loss_total')},
+                     {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    l0, g0 = runs[0]
+    assert all(math.isfinite(v) for v in l0.values()), l0
+    assert 0.0 < l0['loss_itm'] < 5.0 and 0.0 < l0['loss_mlm'] < 30.0, l0
+    for n, g in g0.items():
+        assert torch.isfinite(g).all(), n
+    for n in ('video_model.blocks.23.mlp.fc1.weight', 'video_model.blocks.0.attn.qkv.weight',
+              'text_model.encoder.layer.23.output.dense.weight', 'text_model.encoder.layer.0.attention.self.query.weight',
+              'video_model.patch_embed.proj.weight', 'text_model.embeddings.word_embeddings.weight'):
+        assert float(g0[n].float().abs().sum()) > 0, n
+    assert runs[1][0] == l0
+    for n, g in g0.items():
+        assert torch.equal(g, runs[1][1][n]), n
