@@ -29,6 +29,11 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     float* colsum;                      // wgrad only: fp32 [gridDim.z][M] partial column sums of the A operand (dY), or null
     GemmEpi e;
+    // MX-fp8 form of the persistent kernel (egv_gemm3.hip, egv_mx.hip): A / B hold e4m3 codes (lda / ldb in BYTES = elements), the
+    // E8M0 block scales come in the lane order of egv_mx.hip (role 0 for A, role 1 for B)
+    const unsigned char* sa = nullptr;
+    const unsigned char* sb = nullptr;
+    int mx = 0;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {

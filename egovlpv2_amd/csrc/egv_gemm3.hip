@@ -41,6 +41,9 @@ template <int N> __device__ __forceinline__ void pp_wait_vmcnt() { asm volatile(
 constexpr int PP_UNIT = 16384;            // bytes per staged unit
 constexpr int PP_BUF = 4 * PP_UNIT;       // bytes per K-tile buffer
 constexpr int PP_LDS = 2 * PP_BUF + 16384; // + 1 KiB per wave of dummy DMA target (DMAs issued past the last tile) + 1 KiB per wave: the tile's 256 bias values
+constexpr int PP_LDS_MX = PP_LDS + 8192;   // MX-fp8 form: + a 4-deep ring of 2 KiB block-scale slabs (8 pieces of 256 B: A blocks (wr, sub), B blocks wc)
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
 
 struct PPTile {
     int m0, n0;
@@ -59,20 +62,23 @@ enum { PP_PLAIN = 0, PP_LAST = 1, PP_FIRST_CHAIN = 2, PP_FIRST_COLD = 3, PP_SECO
 // extra vector-memory operations issued in phase p of a K-tile of kind `kind` (NSQ stores per quadrant of a deferred epilogue,
 // 1 bias DMA per tile); with a BULK epilogue (residual / GELU' operand kinds) the tile's NST stores are issued between the
 // last K-tile and the next tile's first one
-__host__ __device__ constexpr int pp_extra(int kind, int p, int NSQ, bool bulk) {
-    if (kind == PP_LAST) return p == 1 ? 1 : 0;
-    if (kind == PP_FIRST_CHAIN && !bulk) return (p & 1) ? 0 : 2 * NSQ;
-    return 0;
+// (MX-fp8 form: + the K-tile's scale DMA, issued in phase 3 right BEFORE that phase's unit)
+__host__ __device__ constexpr int pp_extra(int kind, int p, int NSQ, bool bulk, bool mx = false) {
+    const int s = (mx && p == 3) ? 1 : 0;
+    if (kind == PP_LAST) return s + (p == 1 ? 1 : 0);
+    if (kind == PP_FIRST_CHAIN && !bulk) return s + ((p & 1) ? 0 : 2 * NSQ);
+    return s;
 }
 __host__ __device__ constexpr int pp_prev_kind(int kind) {
     return kind == PP_FIRST_CHAIN ? PP_LAST : kind == PP_SECOND_CHAIN ? PP_FIRST_CHAIN : kind == PP_SECOND_COLD ? PP_FIRST_COLD : PP_PLAIN;
 }
 // operations younger than the unit staged 4 phases ago, at the wait of phase p: the DMAs of the last 4 phases + the extras
-__host__ __device__ constexpr int pp_nwait(int kind, int p, int NSQ, bool bulk) {
+__host__ __device__ constexpr int pp_nwait(int kind, int p, int NSQ, bool bulk, bool mx = false) {
     int n = 8;
-    for (int q = 0; q <= p; ++q) n += pp_extra(kind, q, NSQ, bulk);
+    for (int q = 0; q <= p; ++q) n += pp_extra(kind, q, NSQ, bulk, mx);
     if (kind != PP_FIRST_COLD)                      // before a cold first K-tile there is only the prologue (nothing younger)
-        for (int q = p + 1; q < 4; ++q) n += pp_extra(pp_prev_kind(kind), q, NSQ, bulk);
+        for (int q = p + 1; q < 4; ++q) n += pp_extra(pp_prev_kind(kind), q, NSQ, bulk, mx);
+    else if (mx && p < 3) n += 1;                   // ... except the prologue's scale DMA of K-tile 1, issued where a phase 3 would have
     if (kind == PP_FIRST_CHAIN && bulk) n += 4 * NSQ;  // the previous tile's bulk epilogue (all of its stores) sits between the tiles
     return n;
 }
@@ -84,9 +90,16 @@ __host__ __device__ constexpr int pp_nwait(int kind, int p, int NSQ, bool bulk) 
 //   IM  : 16-row fragments per A sub-tile and wave row: 4 = 256-row tiles; 3 = 192-row tiles (wave tile 96 x 64, 12 MFMAs per
 //         phase, 12 KB A units) for the N = 768 GEMMs, whose 98 x 3 = 294 tiles of 256 rows leave the second round of a
 //         224-workgroup grid one third full (131 x 3 = 393 tiles of 3/4 the work: 1.5 instead of 2 tile-times)
-template <int X1K, bool PREK, bool ACTK, bool STAMPS = false, int IM = 4>
+//   MX  : MX-fp8 operands (egv_mx.hip): a K-tile is 128 e4m3 elements -- the SAME 128-byte row pieces, staging, swizzle and
+//         fragment reads (v_mfma_scale_f32_16x16x128_f8f6f4 takes k = 16 fg .. +15 in registers 0-3 and 64 + 16 fg .. +15 in
+//         registers 4-7 of lane group fg: exactly the two 16-byte chunks a lane reads for the two bf16 K-halves), half as many
+//         MFMAs of twice the length, twice the flops per staged byte; block scales arrive by one 256-byte LDS-DMA per wave and
+//         K-tile (4-deep ring) and are read as one dword per lane and sub-tile
+template <int X1K, bool PREK, bool ACTK, bool STAMPS = false, int IM = 4, bool MX = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntiles) {
     static_assert(IM == 4 || IM == 3, "A sub-tile of 4 or 3 fragments");
+    static_assert(!MX || IM == 4, "MX-fp8 form: 256-row tiles only (64-row scale blocks)");
+    constexpr unsigned int ES = MX ? 1u : 2u;                      // bytes per operand element
     constexpr int BM = IM * 64, WM = IM * 32, SM = IM * 16;        // tile rows, rows per wave row, rows per A sub-tile and wave row
     constexpr int NSQ = PREK ? 2 * IM : IM;
     constexpr bool BULK = X1K != 0;                                // residual / GELU' operand: epilogue in one piece at the tile's end
@@ -96,7 +109,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
     const int wave = wave_id();
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, fg = lane >> 4;
-    const int KT = g.K >> 6;
+    const int KT = MX ? g.K >> 7 : g.K >> 6;
     const GemmEpi& e = g.e;
 
     // ---- tile walk: workgroup w takes tiles first, first + G, ... of an order in which the 32 workgroups of one XCD (w % 8)
@@ -110,10 +123,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
 
     // ---- staging geometry of this lane: unit row rho = (p*8 + wave)*8 + (lane>>3), source chunk (lane&7) ^ (lane>>3)
     const int srow = lane >> 3;
-    const int schunk = ((lane & 7) ^ srow) * 8;                   // element offset inside the 64-wide K-tile
+    const unsigned int schunk = ((lane & 7) ^ srow) * 16;         // byte offset inside the 128-byte row piece of a K-tile
     unsigned int soff[4][2];                                      // byte offsets (from A / B) of this lane's source rows: [unit][piece]
+    unsigned int sc_tile = 0;                                     // MX: this wave's scale piece of the staging tile (byte offset in K-tile 0)
+    const unsigned int sc_kstride = MX ? (unsigned int)(wave < 4 ? ((g.M + 255) >> 8) * 4 : (g.N + 63) >> 6) * 256u : 0u;   // per K-tile
+    const unsigned char* sc_base = wave < 4 ? g.sa : g.sb;        // waves 0-3 fetch the A blocks (wr', sub') = (wave >> 1, wave & 1), waves 4-7 the B blocks wc' = wave - 4
     auto set_stage_tile = [&](int t) {
         const PPTile tl = pp_tile(t, g.tiles_n, BM);
+        if constexpr (MX) sc_tile = (unsigned int)(wave < 4 ? (tl.m0 >> 6) + wave : min((tl.n0 >> 6) + wave - 4, ((g.N + 63) >> 6) - 1)) * 256u;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int rho = (p * 8 + wave) * 8 + srow;            // 0..127
@@ -121,24 +138,24 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                 // A units: rho -> tile row (rho>>6)*128 + sub*64 + (rho&63)
                 const int ra0 = min(tl.m0 + (rho >> 6) * 128 + (rho & 63), g.M - 1);
                 const int ra1 = min(tl.m0 + (rho >> 6) * 128 + 64 + (rho & 63), g.M - 1);
-                soff[0][p] = (unsigned int)(ra0 * g.lda + schunk) * 2u;
-                soff[3][p] = (unsigned int)(ra1 * g.lda + schunk) * 2u;
+                soff[0][p] = (unsigned int)(ra0 * g.lda) * ES + schunk;
+                soff[3][p] = (unsigned int)(ra1 * g.lda) * ES + schunk;
             } else {
                 // 96-row A units: this wave stages rows wave*12 .. +11 -- piece 0 = 8 rows, piece 1 = 4 rows (lanes 0..31 only);
                 // unit row ra -> tile row (ra/48)*96 + sub*48 + ra%48; source chunk (lane&7) ^ (ra&7) (the reads' swizzle)
                 const int ra = min(wave * 12 + p * 8 + srow, 95);
                 const int ra0 = min(tl.m0 + (ra / 48) * 96 + (ra % 48), g.M - 1);
                 const int ra1 = min(tl.m0 + (ra / 48) * 96 + 48 + (ra % 48), g.M - 1);
-                const int sch = ((lane & 7) ^ (ra & 7)) * 8;
-                soff[0][p] = (unsigned int)(ra0 * g.lda + sch) * 2u;
-                soff[3][p] = (unsigned int)(ra1 * g.lda + sch) * 2u;
+                const unsigned int sch = ((lane & 7) ^ (ra & 7)) * 16;
+                soff[0][p] = (unsigned int)(ra0 * g.lda) * ES + sch;
+                soff[3][p] = (unsigned int)(ra1 * g.lda) * ES + sch;
             }
             // B units: rho = wc'*32 + j'*16 + q -> column wc'*64 + sub*32 + (q>>2)*8 + j'*4 + (q&3)
             const int wcp = rho >> 5, jp = (rho >> 4) & 1, q = rho & 15;
             const int cb0 = min(tl.n0 + wcp * 64 + (q >> 2) * 8 + jp * 4 + (q & 3), g.N - 1);
             const int cb1 = min(tl.n0 + wcp * 64 + 32 + (q >> 2) * 8 + jp * 4 + (q & 3), g.N - 1);
-            soff[1][p] = (unsigned int)(cb0 * g.ldb + schunk) * 2u;
-            soff[2][p] = (unsigned int)(cb1 * g.ldb + schunk) * 2u;
+            soff[1][p] = (unsigned int)(cb0 * g.ldb) * ES + schunk;
+            soff[2][p] = (unsigned int)(cb1 * g.ldb) * ES + schunk;
         }
     };
     // staging cursor: units are issued in the fixed order U0(kt) U1(kt) U2(kt) U3(kt) U0(kt+1) ... across tiles
@@ -167,6 +184,21 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                      : "=&s"(keep), "=&s"(ex)
                      : "v"(voff), "s"(base), "s"(lds_dst)
                      : "memory");
+    };
+    auto stage_scales = [&]() {                                   // MX: the cursor's K-tile, 256 B per wave into ring slot s_gkt & 3
+        if constexpr (MX) {
+            const unsigned int live = s_tile_seq < my_tiles ? ~0u : 0u;
+            const unsigned int dst = lds0 + 2 * PP_BUF + 16384 + (s_gkt & 3) * 2048 + wave * 256;
+            const unsigned int d = dummy_lds + ((dst - dummy_lds) & live);
+            unsigned int l4 = lane;
+            asm volatile("v_lshlrev_b32 %0, 2, %0" : "+v"(l4));   // recomputed per use: not a register held across the K loop
+            const unsigned int voff = (l4 + sc_tile + (unsigned int)s_kt * sc_kstride) & live;
+            unsigned int keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(voff), "s"(sc_base), "s"(__builtin_amdgcn_readfirstlane(d))
+                         : "memory");
+        }
     };
     auto stage_unit = [&](int u) {                                // u is a compile-time constant at every call site
         const unsigned int live = s_tile_seq < my_tiles ? ~0u : 0u;   // past my last tile: harmless DMAs into the dummy slab keep
@@ -266,6 +298,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
     };
     f32x4_t acc[2 * IM][4];                                       // (s*IM+i, t*2+j'); written by the first MFMAs of every tile
     bf16x8_t af[IM][2], bf0[2][2], bf1[2][2];
+    int sc_a0 = 0, sc_a1 = 0, sc_b = 0;                           // MX: block scales of the K-tile (A sub-tiles 0 / 1: byte i; B: byte t*2+j')
+    auto sc_read = [&](int slot, int piece) {                     // this lane's dword of a 256-byte scale piece
+        unsigned int l4 = lane;
+        asm volatile("v_lshlrev_b32 %0, 2, %0" : "+v"(l4));
+        return *reinterpret_cast<const int*>(smem + 2 * PP_BUF + 16384 + slot * 2048 + piece * 256 + l4);
+    };
 
     // convert + store the two quadrants (s, 0), (s, 1) of the finished tile `tl`: 8 full-line stores (16 with the pre-activation)
     u32x4_t xop2[X1K == 3 ? 2 : 1][X1K == 3 ? IM : 1][2];      // second residual (gated i2t projection: x + gate * y + skip)
@@ -354,24 +392,46 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
     // ---- prologue: the first tile's bias (and residual quadrants 0, 1) first, then U0..U3 of K-tile 0 and U0 U1 of K-tile 1
     // (the units the steady-state schedule would have issued before phase 0)
     PPTile cur = pp_tile(first, g.tiles_n, BM);
+    stage_scales();
     stage_unit(0); stage_unit(1); stage_unit(2); stage_unit(3);
     advance_cursor();
-    stage_unit(0); stage_unit(1);
-    pp_wait_vmcnt<8>();                                           // U0(0), U1(0) landed (this wave's pieces)
+    stage_unit(0);
+    stage_scales();
+    stage_unit(1);
+    pp_wait_vmcnt<8 + (MX ? 1 : 0)>();                            // U0(0), U1(0) (and the scales of K-tile 0) landed (this wave's pieces)
     __builtin_amdgcn_s_barrier();
 
     // one K-tile = 4 phases.  KIND selects the vmcnt counts and the extra work of the phases:
     //   FIRST_CHAIN: quadrant epilogues of the previous tile `prev` + accumulator init (bias / residual) + operand loads of
     //                quadrants 2, 3;  FIRST_COLD: the same without a previous tile;  LAST: next tile's bias and the operand
     //                loads of quadrants 0, 1 (of `nxt` for a residual, of `cur` for a GELU' operand).
+// MX form: the scaled MFMAs of a cold tile start from a zero C and depend on nothing but their fragments -- without a scheduling
+// fence at the phase boundaries hipcc moves them across the barriers (and spills accumulators to make room)
+#define PP_PIN() do { } while (0)
+#define PP_CAT8(X) __builtin_shufflevector(__builtin_bit_cast(i32x4_t, (X)[0]), __builtin_bit_cast(i32x4_t, (X)[1]), 0, 1, 2, 3, 4, 5, 6, 7)
+#define PP_MX1(S, BF, T, ZERO, I, JP)                                                                                      \
+    acc[(S) * IM + (I)][(T) * 2 + (JP)] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                                \
+        PP_CAT8(BF[JP]), PP_CAT8(af[I]), (ZERO) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[(S) * IM + (I)][(T) * 2 + (JP)], 0, 0, \
+        (T) * 2 + (JP), sc_b, (I), (S) == 0 ? sc_a0 : sc_a1)
 #define PP_MFMA(S, BF, T, ZERO)                                                                                            \
     do {                                                                                                                   \
         __builtin_amdgcn_s_setprio(1);                                                                                     \
+        if constexpr (MX) {                                                                                                \
+            /* pinned inside the phase: every MFMA reads sc_b (defined here, after the barrier) and its result is consumed */ \
+            /* by an empty volatile statement before the closing barrier -- hipcc otherwise sinks all 32 to the loop's end */ \
+            asm volatile("" : "+v"(sc_b));                                                                                 \
+            PP_MX1(S, BF, T, ZERO, 0, 0); PP_MX1(S, BF, T, ZERO, 0, 1); PP_MX1(S, BF, T, ZERO, 1, 0); PP_MX1(S, BF, T, ZERO, 1, 1); \
+            PP_MX1(S, BF, T, ZERO, 2, 0); PP_MX1(S, BF, T, ZERO, 2, 1);                                                    \
+            if constexpr (IM == 4) { PP_MX1(S, BF, T, ZERO, 3, 0); PP_MX1(S, BF, T, ZERO, 3, 1); }                         \
+            _Pragma("unroll") for (int i = 0; i < IM; ++i)                                                                 \
+            _Pragma("unroll") for (int jp = 0; jp < 2; ++jp) asm volatile("" : "+v"(acc[(S) * IM + i][(T) * 2 + jp]));     \
+        } else {                                                                                                           \
         _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                                   \
         _Pragma("unroll") for (int i = 0; i < IM; ++i)                                                                     \
         _Pragma("unroll") for (int jp = 0; jp < 2; ++jp)                                                                   \
             acc[(S) * IM + i][(T) * 2 + jp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                     \
                 BF[jp][kh], af[i][kh], ((ZERO) && kh == 0) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[(S) * IM + i][(T) * 2 + jp], 0, 0, 0); \
+        }                                                                                                                  \
         __builtin_amdgcn_s_setprio(0);                                                                                     \
     } while (0)
 #define PP_KTILE(KIND, BUFIDX)                                                                                             \
@@ -382,7 +442,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
         const unsigned char* buf = smem + ((BUFIDX) & 1) * PP_BUF;                                                         \
         /* ---------------- phase 0: read A sub 0 (U0) + B sub 0 (U1); stage U2 of kt+1; quadrant 0 = (0,0) */             \
         {                                                                                                                  \
-            if (CHAIN && !BULK) pp_wait_vmcnt<6>();         /* the bias DMA of LAST phase 1 (this wave's own slab) landed */ \
+            if (CHAIN && !BULK) pp_wait_vmcnt<6 + (MX ? 1 : 0)>();   /* the bias DMA of LAST phase 1 (this wave's own slab) landed */ \
             if (CHAIN && !BULK) pair_epilogue(0, prev);                                                                             \
             const unsigned char* pa = buf + 0 * PP_UNIT + a_base;                                                          \
             const unsigned char* pb = buf + 1 * PP_UNIT + b_base;                                                          \
@@ -394,11 +454,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                 af[i][0] = *reinterpret_cast<const bf16x8_t*>(pa + i * 2048 + swz0);                                       \
                 af[i][1] = *reinterpret_cast<const bf16x8_t*>(pa + i * 2048 + swz1);                                       \
             }                                                                                                              \
+            if constexpr (MX) {                                                                                            \
+                sc_a0 = sc_read((BUFIDX) & 3, wr * 2 + 0);                                                                 \
+                sc_b = sc_read((BUFIDX) & 3, 4 + wc);                                                                      \
+            }                                                                                                              \
             stage_unit(2);                                                                                                 \
-            pp_wait_vmcnt<pp_nwait(KIND, 0, NSQ, BULK)>();                                                              \
+            pp_wait_vmcnt<pp_nwait(KIND, 0, NSQ, BULK, MX)>();                                                          \
             __builtin_amdgcn_s_barrier();                                                                                  \
+            PP_PIN();                                                                                                      \
             PP_MFMA(0, bf0, 0, FIRSTK);                                                                                 \
             __builtin_amdgcn_s_barrier();                                                                                  \
+            PP_PIN();                                                                                                      \
         }                                                                                                                  \
         /* ---------------- phase 1: read B sub 1 (U2); stage U3 of kt+1; quadrant 1 = (0,1) */                            \
         {                                                                                                                  \
@@ -410,10 +476,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
             }                                                                                                              \
             stage_unit(3);                                                                                                 \
             advance_cursor();                                                                                              \
-            pp_wait_vmcnt<pp_nwait(KIND, 1, NSQ, BULK)>();                                                              \
+            pp_wait_vmcnt<pp_nwait(KIND, 1, NSQ, BULK, MX)>();                                                          \
             __builtin_amdgcn_s_barrier();                                                                                  \
+            PP_PIN();                                                                                                      \
             PP_MFMA(0, bf1, 1, FIRSTK);                                                                                 \
             __builtin_amdgcn_s_barrier();                                                                                  \
+            PP_PIN();                                                                                                      \
         }                                                                                                                  \
         /* ---------------- phase 2: read A sub 1 (U3); stage U0 of kt+2; quadrant 2 = (1,1) */                            \
         {                                                                                                                  \
@@ -423,19 +491,25 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                 af[i][0] = *reinterpret_cast<const bf16x8_t*>(pa + i * 2048 + swz0);                                       \
                 af[i][1] = *reinterpret_cast<const bf16x8_t*>(pa + i * 2048 + swz1);                                       \
             }                                                                                                              \
+            if constexpr (MX) sc_a1 = sc_read((BUFIDX) & 3, wr * 2 + 1);                                                   \
             stage_unit(0);                                                                                                 \
-            pp_wait_vmcnt<pp_nwait(KIND, 2, NSQ, BULK)>();                                                              \
+            pp_wait_vmcnt<pp_nwait(KIND, 2, NSQ, BULK, MX)>();                                                          \
             __builtin_amdgcn_s_barrier();                                                                                  \
+            PP_PIN();                                                                                                      \
             PP_MFMA(1, bf1, 1, FIRSTK);                                                                                 \
             __builtin_amdgcn_s_barrier();                                                                                  \
+            PP_PIN();                                                                                                      \
         }                                                                                                                  \
         /* ---------------- phase 3: no reads; stage U1 of kt+2; quadrant 3 = (1,0) */                                     \
         {                                                                                                                  \
+            stage_scales();                                                                                                \
             stage_unit(1);                                                                                                 \
-            pp_wait_vmcnt<pp_nwait(KIND, 3, NSQ, BULK)>();                                                              \
+            pp_wait_vmcnt<pp_nwait(KIND, 3, NSQ, BULK, MX)>();                                                          \
             __builtin_amdgcn_s_barrier();                                                                                  \
+            PP_PIN();                                                                                                      \
             PP_MFMA(1, bf0, 0, FIRSTK);                                                                                 \
             __builtin_amdgcn_s_barrier();                                                                                  \
+            PP_PIN();                                                                                                      \
         }                                                                                                                  \
     } while (0)
 
@@ -488,7 +562,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                         for (int t = 0; t < 2; ++t)
                             xop2[s][i][t] = __builtin_amdgcn_raw_buffer_load_b128(rs_x2, q_off(cur, true, s, i, t, false), 0, 0);
             }
-            pp_wait_vmcnt<6 + (X1K == 3 ? 8 : 4) * IM>();                               // the bias DMA of LAST phase 1 (16 operand loads are younger)
+            pp_wait_vmcnt<6 + (MX ? 1 : 0) + (X1K == 3 ? 8 : 4) * IM>();                // the bias DMA of LAST phase 1 (16 operand loads are younger)
             pair_epilogue(0, cur);
             pair_epilogue(1, cur);
         }
@@ -497,6 +571,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
     }
 #undef PP_KTILE
 #undef PP_MFMA
+#undef PP_MX1
+#undef PP_PIN
+#undef PP_CAT8
 #undef PP_STAMP
     // ---- the last tile's epilogue
     pp_wait_vmcnt<0>();                                           // its bias slab (and the dummy DMAs)
@@ -623,4 +700,76 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
 #endif
     PP_LAUNCH(0, false, false);
 #undef PP_LAUNCH
+}
+
+// ---- MX-fp8 form (BASELINE.json configs[4]: "fp8 MFMA weight path") ---------------------------------------------------------
+// C[M,N] (bf16) = epi( sum_k sa[m,k/32] A[m,k] * sb[n,k/32] B[n,k] ): A, B e4m3 codes (row pitch = K bytes), sa / sb the E8M0 block
+// scales in the lane order written by egv_quant_mx (role 0 / role 1).  Same epilogues as egv_gemm (bias, activation, saved
+// pre-activation, gate-free residual, activation-derivative operand).  There is no other kernel behind it: shapes the persistent
+// kernel does not take are an error.
+void* egv_prof_begin(void* stream);
+void egv_prof_end(void* handle, void* stream, double flops, int kind, double bytes);
+extern "C" int egv_gemm_mx(int M, int N, int K, const void* Aq, const void* Ascales, const void* Bq, const void* Bscales, void* C, int ldc,
+                           const float* bias, int act, const void* res1, void* pre, const void* aux, int dact, int ldr, void* stream) {
+    EGV_CHECK(M > 0 && N > 0 && K > 0 && Aq && Ascales && Bq && Bscales && C, "egv_gemm_mx: null / empty operand");
+    EGV_CHECK((K % 128) == 0 && K >= 384 && (N % 64) == 0, "egv_gemm_mx: K %% 128 == 0, K >= 384, N %% 64 == 0 required (N=%d K=%d)", N, K);
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!ldr) ldr = ldc;
+    EGV_CHECK(al16(Aq) && al16(Bq) && al16(C) && al16(res1) && al16(pre) && al16(aux) && al16(bias) && (reinterpret_cast<uintptr_t>(Ascales) & 3) == 0 &&
+              (reinterpret_cast<uintptr_t>(Bscales) & 3) == 0 && (ldc % 8) == 0 && (ldr % 8) == 0, "egv_gemm_mx: 16-byte aligned operands and ldc, ldr %% 8 == 0 required");
+    EGV_CHECK((long long)M * K < (1LL << 31) && (long long)N * K < (1LL << 31) && (long long)M * ldc < (1LL << 30) && (long long)M * ldr < (1LL << 30),
+              "egv_gemm_mx: operand beyond 32-bit byte offsets");
+    EGV_CHECK(!(res1 && (dact || act || pre)) && !(dact && (act || pre)) && !(pre && !act), "egv_gemm_mx: epilogue combination not built");
+    EGV_CHECK(!dact || aux, "egv_gemm_mx: dact without aux");
+    GemmArgs g{};
+    g.A = Aq; g.B = Bq; g.C = C;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = K; g.ldb = K; g.ldc = ldc;
+    g.a_vec_ok = g.b_vec_ok = g.c_vec_ok = 1;
+    g.k_per_split = K;
+    g.e.bias = bias; g.e.res1 = res1; g.e.pre = pre; g.e.aux = aux; g.e.act = act; g.e.dact = dact; g.e.ldr = ldr; g.e.scale = 1.0f;
+    g.sa = reinterpret_cast<const unsigned char*>(Ascales);
+    g.sb = reinterpret_cast<const unsigned char*>(Bscales);
+    g.mx = 1;
+    g.tiles_n = (N + 255) / 256;
+    g.tiles_m = (M + 255) / 256;
+    const int ntiles = g.tiles_m * g.tiles_n;
+    static int ncu_dev = 0;
+    if (!ncu_dev) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipGetDeviceProperties(&prop, dev);
+        ncu_dev = prop.multiProcessorCount > 0 ? (prop.multiProcessorCount / 8) * 8 : 256;
+        if (ncu_dev < 8) ncu_dev = 8;
+    }
+    int ncu = ncu_dev;
+    if (g_cu_limit > 0 && g_cu_limit < ncu) ncu = g_cu_limit >= 8 ? (g_cu_limit / 8) * 8 : 8;
+    const int rounds = (ntiles + ncu - 1) / ncu;
+    int grid = (((ntiles + rounds - 1) / rounds + 7) / 8) * 8;
+    if (grid > ncu) grid = ncu;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    void* ph = egv_prof_begin(stream);
+#define MX_LAUNCH(X, P, AC)                                                                                                \
+    do {                                                                                                                   \
+        static bool attr = false;                                                                                          \
+        if (!attr) {                                                                                                       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<X, P, AC, false, 4, true>),             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_MX);                              \
+            attr = true;                                                                                                   \
+        }                                                                                                                  \
+        hipLaunchKernelGGL((gemm_pp_kernel<X, P, AC, false, 4, true>), dim3(grid), dim3(512), PP_LDS_MX, st, g, ntiles);   \
+    } while (0)
+    if (res1) MX_LAUNCH(1, false, false);
+    else if (dact) MX_LAUNCH(2, false, false);
+    else if (pre) MX_LAUNCH(0, true, true);
+    else if (act) MX_LAUNCH(0, false, true);
+    else MX_LAUNCH(0, false, false);
+#undef MX_LAUNCH
+    // algorithmic bytes: fp8 operands + scales once, the bf16 output and every bf16 epilogue operand once
+    const double abytes = (double)M * K * (1.0 + 1.0 / 32) + (double)N * K * (1.0 + 1.0 / 32) +
+                          2.0 * M * N * (1 + (res1 != nullptr) + (pre != nullptr) + (aux != nullptr));
+    egv_prof_end(ph, stream, 2.0 * M * N * K, 16, abytes);
+    EGV_LAUNCH_CHECK();
+    return 0;
 }

@@ -280,6 +280,27 @@ def gemm(x, w, out, *, a_trans=0, b_trans=0, M, N, K, lda, ldb, ldc, bias=None, 
                        _p(gate), _p(res1), _p(res2), _p(pre), _p(aux), dact, ldc, float(scale), _st()), 'egv_gemm')
 
 
+def quant_mx(x, role):
+    """bf16 [R, K] -> (codes uint8 [R, K], scale bytes uint8) in the MXFP8 E4M3 format of egv_quant_mx; role 0 = the GEMM's A
+    operand (activations / output gradients), role 1 = its B operand (weights)"""
+    R, K = x.shape
+    assert x.dtype == torch.bfloat16 and x.stride(1) == 1
+    q = torch.empty(R, K, dtype=torch.uint8, device=x.device)
+    nb = lib.egv_mx_scale_bytes(R, K, role)
+    assert nb > 0, (R, K, role)
+    sc = torch.full((nb,), 0x7f, dtype=torch.uint8, device=x.device)
+    check(lib.egv_quant_mx(_p(x), R, K, x.stride(0), _p(q), _p(sc), role, _st()), 'egv_quant_mx')
+    return q, sc
+
+
+def gemm_mx(aq, asc, bq, bsc, M, N, K, *, bias=None, act=0, res1=None, pre=None, aux=None, dact=0):
+    """bf16 C[M,N] = epi(A B^T) on MX-fp8 operands (egv_gemm_mx); aq [M,K] / bq [N,K] codes, asc / bsc their scale bytes"""
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=aq.device)
+    check(lib.egv_gemm_mx(M, N, K, _p(aq), _p(asc), _p(bq), _p(bsc), _p(out), N, _p(bias), act, _p(res1), _p(pre), _p(aux), dact, N,
+                          _st()), 'egv_gemm_mx')
+    return out
+
+
 def wgrad(dy, x, M, N, K, gate=None, scale=1.0, ldy=None, bias=False):
     """dW[N,K] fp32 = scale*gate * dy[M,N]^T x[M,K]  (and, with bias=True, db[N] = scale*gate * colsum(dy) from the same pass)"""
     dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)

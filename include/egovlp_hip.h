@@ -222,6 +222,23 @@ int egv_cast_weights_ld(const void* table, const int* prefix, int ntensors, int 
 /* fp32 segment copies in one launch (the concatenated biases of merged projections): table = device array of 24-byte records
    {const float* src; float* dst; long long n} */
 int egv_copy_segments(const void* table, int nseg, void* stream);
+/* ---- MX-fp8 weight GEMMs (BASELINE.json configs[4]: ViT-L/14 + RoBERTa-large, "fp8 MFMA weight path"; the reference has no
+ * fp8 code: what it replaces are the bf16 forward / dgrad GEMMs of video_transformer.py:53,56,120,152,166,183 under a block-scaled
+ * fp8 format).  Format: OCP MXFP8 E4M3 -- e4m3fn codes, one E8M0 scale 2^(s-127) per 32 consecutive elements of the contraction
+ * dimension, s = the smallest power of two that brings the block's largest magnitude to <= 448 (nothing saturates).
+ * egv_quant_mx: x bf16 [R,K] (row pitch ld) -> q [R,K] codes (row pitch K) + the scale bytes in the lane order of the
+ * v_mfma_scale_f32_16x16x128_f8f6f4 consumers (csrc/egv_mx.hip): role 0 = the GEMM's A operand (activations, output gradients),
+ * role 1 = its B operand (weights).  Scale rows past R are not written: fill the array with 0x7f once.
+ * egv_quant_mx_batch: many tensors in one launch -- 40-byte records {const void* src; void* q; void* scales; int R, K, ld, role},
+ * prefix[t] = workgroups before tensor t (a tensor takes ceil(R * K / 32 / 256)).
+ * egv_gemm_mx: C[M,N] (bf16) = epi( A B^T ) with both operands quantised along K; epilogue as egv_gemm (bias, act, saved
+ * pre-activation `pre`, residual res1, activation-derivative operand aux/dact).  K % 128 == 0, K >= 384, N % 64 == 0. */
+long long egv_mx_scale_bytes(int R, int K, int role);
+int egv_quant_mx(const void* x, int R, int K, int ld, void* q, void* scales, int role, void* stream);
+int egv_quant_mx_batch(const void* table, const int* prefix, int ntensors, int nblocks, void* stream);
+int egv_gemm_mx(int M, int N, int K, const void* Aq, const void* Ascales, const void* Bq, const void* Bscales, void* C, int ldc,
+                const float* bias, int act, const void* res1, void* pre, const void* aux, int dact, int ldr, void* stream);
+
 /* ---- fused multi-tensor AdamW (set_optim_schedule.py:108 -> transformers 4.30 AdamW: eps on sqrt(v) without bias
  * correction of the denominator, step_size = lr*sqrt(1-b2^t)/(1-b1^t), weight decay p -= lr*wd*p AFTER the update).
  * table: device array of 32-byte records {float* p; const float* g; float* m; float* v; int n; int pad}, one per tensor;

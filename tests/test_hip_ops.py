@@ -766,3 +766,72 @@ def test_grouped_weight_gradients_under_load_bf16(ops):
         torch.cuda.synchronize()
         for (dw, db), (rw, rb) in zip(outs, ref):
             assert torch.equal(dw, rw) and torch.equal(db, rb), it
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# MX-fp8 operand format and GEMM (BASELINE.json configs[4])
+# ---------------------------------------------------------------------------------------------------------------------------
+def _mx_inputs(R, K, seed, spread=True):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(R, K, generator=g)
+    if spread:      # block maxima across ~40 binades, exact powers of two and 1.75 * 2^e (the boundary of the scale rule), zero blocks
+        x = x * torch.exp2(torch.randint(-20, 20, (R, K // 32, 1), generator=g).float()).expand(R, K // 32, 32).reshape(R, K)
+        x[0, :32] = 0.0
+        x[1, :32] = 0.0; x[1, 3] = 1.75 * 2.0 ** -3
+        x[2, :32] = 0.0; x[2, 5] = -(1.75 + 2.0 ** -7) * 2.0 ** 4
+        x[3, :32] = 0.0; x[3, 7] = 2.0 ** 9
+    return x.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize('R,K,role', [(300, 384, 0), (256, 1024, 1), (77, 128, 0), (1024, 4096, 1), (4113, 1024, 0)])
+def test_mx_quantisation_is_bit_exact(ops, R, K, role):
+    """egv_quant_mx against the oracle: every e4m3 code and every E8M0 scale byte, in the lane order of its GEMM role"""
+    from oracle import mx_quant as O
+    x = _mx_inputs(R, K, 5 + R)
+    q, sc = ops.quant_mx(x.cuda(), role)
+    codes, e8 = O.quantize(x)
+    assert torch.equal(q.cpu(), codes)
+    assert torch.equal(sc.cpu(), O.scale_layout(e8, role))
+    # the format's own bound: |dequant - x| <= 2^-4 of the block maximum (3 mantissa bits at the top binade, coarser below)
+    d = O.dequantize(codes, e8)
+    amax = x.float().reshape(R, K // 32, 32).abs().amax(-1, keepdim=True).expand(R, K // 32, 32).reshape(R, K)
+    assert ((d - x.float()).abs() <= amax * 2.0 ** -4 + 1e-30).all()
+
+
+@pytest.mark.parametrize('M,N,K', [(256, 256, 384), (1000, 768, 768), (4113, 1024, 1024), (515, 3072, 1024), (2049, 1024, 4096), (300, 320, 512)])
+def test_mx_gemm_vs_dequantised_reference(ops, M, N, K):
+    """egv_gemm_mx = exact product of the dequantised operands up to fp32 accumulation and the bf16 rounding of the output;
+    ragged M (partial last tile), N not a multiple of the 256-wide tile, bias epilogue"""
+    from oracle import mx_quant as O
+    a, b = _mx_inputs(M, K, 1, spread=False), (_mx_inputs(N, K, 2, spread=False).float() * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N)
+    aq, asc = ops.quant_mx(a.cuda(), 0)
+    bq, bsc = ops.quant_mx(b.cuda(), 1)
+    out = ops.gemm_mx(aq, asc, bq, bsc, M, N, K, bias=bias.cuda()).float().cpu()
+    ref = (O.gemm_ref(a, b) + bias.double()).float()
+    assert _rel(out, ref) < 3e-3                      # bf16 output rounding (2^-9 per element)
+    assert (out - ref).abs().max() <= 2.0 ** -7 * ref.abs().max()
+
+
+def test_mx_gemm_epilogues_vs_reference(ops):
+    """the epilogue kinds the block executor uses: GELU with the saved pre-activation (fc1), residual (proj / fc2), GELU' operand
+    (fc2 dgrad)"""
+    from oracle import mx_quant as O
+    M, N, K = 1030, 1024, 512
+    a, b = _mx_inputs(M, K, 3, spread=False), (_mx_inputs(N, K, 4, spread=False).float() * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N)
+    aq, asc = ops.quant_mx(a.cuda(), 0)
+    bq, bsc = ops.quant_mx(b.cuda(), 1)
+    lin = (O.gemm_ref(a, b) + bias.double()).float()
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device='cuda')
+    out = ops.gemm_mx(aq, asc, bq, bsc, M, N, K, bias=bias.cuda(), act=1, pre=pre)
+    assert _rel(pre.float().cpu(), lin) < 3e-3
+    assert _rel(out.float().cpu(), torch.nn.functional.gelu(lin)) < 4e-3
+    res = torch.randn(M, N).to(torch.bfloat16)
+    out = ops.gemm_mx(aq, asc, bq, bsc, M, N, K, bias=bias.cuda(), res1=res.cuda())
+    assert _rel(out.float().cpu(), lin + res.float()) < 3e-3
+    u = torch.randn(M, N).to(torch.bfloat16)
+    out = ops.gemm_mx(aq, asc, bq, bsc, M, N, K, aux=u.cuda(), dact=1)
+    uu = u.float().requires_grad_(True)
+    torch.nn.functional.gelu(uu).sum().backward()
+    assert _rel(out.float().cpu(), (lin - bias) * uu.grad) < 4e-3
