@@ -98,7 +98,7 @@ __host__ __device__ constexpr int pp_nwait(int kind, int p, int NSQ, bool bulk, 
 template <int X1K, bool PREK, bool ACTK, bool STAMPS = false, int IM = 4, bool MX = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntiles) {
     static_assert(IM == 4 || IM == 3, "A sub-tile of 4 or 3 fragments");
-    static_assert(!MX || IM == 4, "MX-fp8 form: 256-row tiles only (64-row scale blocks)");
+    static_assert(!MX || IM == 3, "MX-fp8 form: 192-row tiles only (48-row scale blocks; the 256-row form does not fit 256 registers)");
     constexpr unsigned int ES = MX ? 1u : 2u;                      // bytes per operand element
     constexpr int BM = IM * 64, WM = IM * 32, SM = IM * 16;        // tile rows, rows per wave row, rows per A sub-tile and wave row
     constexpr int NSQ = PREK ? 2 * IM : IM;
@@ -126,11 +126,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
     const unsigned int schunk = ((lane & 7) ^ srow) * 16;         // byte offset inside the 128-byte row piece of a K-tile
     unsigned int soff[4][2];                                      // byte offsets (from A / B) of this lane's source rows: [unit][piece]
     unsigned int sc_tile = 0;                                     // MX: this wave's scale piece of the staging tile (byte offset in K-tile 0)
-    const unsigned int sc_kstride = MX ? (unsigned int)(wave < 4 ? ((g.M + 255) >> 8) * 4 : (g.N + 63) >> 6) * 256u : 0u;   // per K-tile
+    const unsigned int sc_kstride = MX ? (unsigned int)(wave < 4 ? ((g.M + 191) / 192) * 4 : (g.N + 63) >> 6) * 256u : 0u;   // per K-tile
     const unsigned char* sc_base = wave < 4 ? g.sa : g.sb;        // waves 0-3 fetch the A blocks (wr', sub') = (wave >> 1, wave & 1), waves 4-7 the B blocks wc' = wave - 4
     auto set_stage_tile = [&](int t) {
         const PPTile tl = pp_tile(t, g.tiles_n, BM);
-        if constexpr (MX) sc_tile = (unsigned int)(wave < 4 ? (tl.m0 >> 6) + wave : min((tl.n0 >> 6) + wave - 4, ((g.N + 63) >> 6) - 1)) * 256u;
+        if constexpr (MX) sc_tile = (unsigned int)(wave < 4 ? tl.m0 / 48 + wave : min((tl.n0 >> 6) + wave - 4, ((g.N + 63) >> 6) - 1)) * 256u;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int rho = (p * 8 + wave) * 8 + srow;            // 0..127
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
     //                loads of quadrants 0, 1 (of `nxt` for a residual, of `cur` for a GELU' operand).
 // MX form: the scaled MFMAs of a cold tile start from a zero C and depend on nothing but their fragments -- without a scheduling
 // fence at the phase boundaries hipcc moves them across the barriers (and spills accumulators to make room)
-#define PP_PIN() do { } while (0)
+#define PP_PIN() do { if constexpr (MX) __builtin_amdgcn_sched_barrier(0); } while (0)
 #define PP_CAT8(X) __builtin_shufflevector(__builtin_bit_cast(i32x4_t, (X)[0]), __builtin_bit_cast(i32x4_t, (X)[1]), 0, 1, 2, 3, 4, 5, 6, 7)
 #define PP_MX1(S, BF, T, ZERO, I, JP)                                                                                      \
     acc[(S) * IM + (I)][(T) * 2 + (JP)] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                                \
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
             asm volatile("" : "+v"(sc_b));                                                                                 \
             PP_MX1(S, BF, T, ZERO, 0, 0); PP_MX1(S, BF, T, ZERO, 0, 1); PP_MX1(S, BF, T, ZERO, 1, 0); PP_MX1(S, BF, T, ZERO, 1, 1); \
             PP_MX1(S, BF, T, ZERO, 2, 0); PP_MX1(S, BF, T, ZERO, 2, 1);                                                    \
-            if constexpr (IM == 4) { PP_MX1(S, BF, T, ZERO, 3, 0); PP_MX1(S, BF, T, ZERO, 3, 1); }                         \
+            if constexpr (IM == 4) { PP_MX1(S, BF, T, ZERO, IM - 1, 0); PP_MX1(S, BF, T, ZERO, IM - 1, 1); }               \
             _Pragma("unroll") for (int i = 0; i < IM; ++i)                                                                 \
             _Pragma("unroll") for (int jp = 0; jp < 2; ++jp) asm volatile("" : "+v"(acc[(S) * IM + i][(T) * 2 + jp]));     \
         } else {                                                                                                           \
@@ -444,6 +444,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
         {                                                                                                                  \
             if (CHAIN && !BULK) pp_wait_vmcnt<6 + (MX ? 1 : 0)>();   /* the bias DMA of LAST phase 1 (this wave's own slab) landed */ \
             if (CHAIN && !BULK) pair_epilogue(0, prev);                                                                             \
+            if (CHAIN && !BULK) PP_PIN();                                                                                  \
             const unsigned char* pa = buf + 0 * PP_UNIT + a_base;                                                          \
             const unsigned char* pb = buf + 1 * PP_UNIT + b_base;                                                          \
             _Pragma("unroll") for (int jp = 0; jp < 2; ++jp) {                                                             \
@@ -461,10 +462,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
             stage_unit(2);                                                                                                 \
             pp_wait_vmcnt<pp_nwait(KIND, 0, NSQ, BULK, MX)>();                                                          \
             __builtin_amdgcn_s_barrier();                                                                                  \
-            PP_PIN();                                                                                                      \
             PP_MFMA(0, bf0, 0, FIRSTK);                                                                                 \
             __builtin_amdgcn_s_barrier();                                                                                  \
-            PP_PIN();                                                                                                      \
         }                                                                                                                  \
         /* ---------------- phase 1: read B sub 1 (U2); stage U3 of kt+1; quadrant 1 = (0,1) */                            \
         {                                                                                                                  \
@@ -478,14 +477,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
             advance_cursor();                                                                                              \
             pp_wait_vmcnt<pp_nwait(KIND, 1, NSQ, BULK, MX)>();                                                          \
             __builtin_amdgcn_s_barrier();                                                                                  \
-            PP_PIN();                                                                                                      \
             PP_MFMA(0, bf1, 1, FIRSTK);                                                                                 \
             __builtin_amdgcn_s_barrier();                                                                                  \
-            PP_PIN();                                                                                                      \
         }                                                                                                                  \
         /* ---------------- phase 2: read A sub 1 (U3); stage U0 of kt+2; quadrant 2 = (1,1) */                            \
         {                                                                                                                  \
             if (CHAIN && !BULK) pair_epilogue(1, prev);                                                                             \
+            if (CHAIN && !BULK) PP_PIN();                                                                                  \
             const unsigned char* pa = buf + 3 * PP_UNIT + a_base;                                                          \
             _Pragma("unroll") for (int i = 0; i < IM; ++i) {                                                               \
                 af[i][0] = *reinterpret_cast<const bf16x8_t*>(pa + i * 2048 + swz0);                                       \
@@ -495,10 +493,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
             stage_unit(0);                                                                                                 \
             pp_wait_vmcnt<pp_nwait(KIND, 2, NSQ, BULK, MX)>();                                                          \
             __builtin_amdgcn_s_barrier();                                                                                  \
-            PP_PIN();                                                                                                      \
             PP_MFMA(1, bf1, 1, FIRSTK);                                                                                 \
             __builtin_amdgcn_s_barrier();                                                                                  \
-            PP_PIN();                                                                                                      \
         }                                                                                                                  \
         /* ---------------- phase 3: no reads; stage U1 of kt+2; quadrant 3 = (1,0) */                                     \
         {                                                                                                                  \
@@ -506,10 +502,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
             stage_unit(1);                                                                                                 \
             pp_wait_vmcnt<pp_nwait(KIND, 3, NSQ, BULK, MX)>();                                                          \
             __builtin_amdgcn_s_barrier();                                                                                  \
-            PP_PIN();                                                                                                      \
             PP_MFMA(1, bf0, 0, FIRSTK);                                                                                 \
             __builtin_amdgcn_s_barrier();                                                                                  \
-            PP_PIN();                                                                                                      \
         }                                                                                                                  \
     } while (0)
 
@@ -732,7 +726,7 @@ extern "C" int egv_gemm_mx(int M, int N, int K, const void* Aq, const void* Asca
     g.sb = reinterpret_cast<const unsigned char*>(Bscales);
     g.mx = 1;
     g.tiles_n = (N + 255) / 256;
-    g.tiles_m = (M + 255) / 256;
+    g.tiles_m = (M + 191) / 192;
     const int ntiles = g.tiles_m * g.tiles_n;
     static int ncu_dev = 0;
     if (!ncu_dev) {
@@ -754,11 +748,11 @@ extern "C" int egv_gemm_mx(int M, int N, int K, const void* Aq, const void* Asca
     do {                                                                                                                   \
         static bool attr = false;                                                                                          \
         if (!attr) {                                                                                                       \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<X, P, AC, false, 4, true>),             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<X, P, AC, false, 3, true>),             \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_MX);                              \
             attr = true;                                                                                                   \
         }                                                                                                                  \
-        hipLaunchKernelGGL((gemm_pp_kernel<X, P, AC, false, 4, true>), dim3(grid), dim3(512), PP_LDS_MX, st, g, ntiles);   \
+        hipLaunchKernelGGL((gemm_pp_kernel<X, P, AC, false, 3, true>), dim3(grid), dim3(512), PP_LDS_MX, st, g, ntiles);   \
     } while (0)
     if (res1) MX_LAUNCH(1, false, false);
     else if (dact) MX_LAUNCH(2, false, false);

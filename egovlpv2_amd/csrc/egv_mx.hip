@@ -10,12 +10,13 @@
 // Outputs: q[R][K] fp8 codes, row-major (the GEMM stages them exactly like its bf16 operands: 128-byte row pieces by LDS-DMA),
 // and the scale bytes in the order the v_mfma_scale_f32_16x16x128_f8f6f4 lanes want them (measured lane mapping: lane (fr, fg) of
 // a 16-row fragment supplies the scale of row fr, 32-element block fg, in the byte its op_sel names):
-//     s[ktile][block of 64 rows][fg = k-block in the 128-wide K-tile][fr][4 bytes]
-// so that the 256 bytes of (K-tile, 64-row block) are one coalesced 4-byte-per-lane load for a wave, each lane receiving the
-// bytes of ITS four fragments.  Which row of the block sits in (fr, byte) depends on the operand's role in the GEMM tile:
-//   role 0 (A: activations / output gradients): row = byte * 16 + fr                    (fragments i = 0..3 of a 64-row sub-tile)
-//   role 1 (B: weights): row = (byte >> 1) * 32 + (fr >> 2) * 8 + (byte & 1) * 4 + (fr & 3)   (the B-row permutation of
-//           egv_gemm3.hip that makes a lane's accumulators 8 consecutive output columns)
+//     s[ktile][row block][fg = k-block in the 128-wide K-tile][fr][4 bytes]
+// so that the 256 bytes of (K-tile, row block) are one coalesced 4-byte-per-lane load for a wave, each lane receiving the
+// bytes of ITS fragments.  Which row of the block sits in (fr, byte) depends on the operand's role in the GEMM tile:
+//   role 0 (A: activations / output gradients; blocks of 48 rows = one sub-tile of a wave row of the 192-row tile):
+//           row = byte * 16 + fr, byte = fragment i = 0..2 (byte 3 unused)
+//   role 1 (B: weights; blocks of 64 rows): row = (byte >> 1) * 32 + (fr >> 2) * 8 + (byte & 1) * 4 + (fr & 3)   (the B-row
+//           permutation of egv_gemm3.hip that makes a lane's accumulators 8 consecutive output columns)
 // Bytes of rows past R are never written: allocate the array once, filled with 0x7f (scale 1).
 #include "egv_common.h"
 
@@ -28,7 +29,7 @@ struct MxRec {             // 40 bytes, one per tensor of a batched launch
     int R, K, ld, role;
 };
 
-__host__ __device__ inline int mx_nblk(int R, int role) { return role == 0 ? ((R + 255) / 256) * 4 : (R + 63) / 64; }
+__host__ __device__ inline int mx_nblk(int R, int role) { return role == 0 ? ((R + 191) / 192) * 4 : (R + 63) / 64; }
 
 __device__ __forceinline__ void mx_quant_block(const MxRec& rec, int idx) {
     const int KB = rec.K >> 5;
@@ -64,10 +65,10 @@ __device__ __forceinline__ void mx_quant_block(const MxRec& rec, int idx) {
     u32x4_t* dst = reinterpret_cast<u32x4_t*>(rec.q + (size_t)row * rec.K + kb * 32);
     dst[0] = o[0];
     dst[1] = o[1];
-    const int ktile = kb >> 2, fg = kb & 3, blk = row >> 6, rb = row & 63;
-    int fr, byte;
-    if (rec.role == 0) { fr = rb & 15; byte = rb >> 4; }
-    else { const int x = rb & 31; fr = ((x >> 3) << 2) | (x & 3); byte = (rb >> 5) * 2 + ((x >> 2) & 1); }
+    const int ktile = kb >> 2, fg = kb & 3;
+    int blk, fr, byte;
+    if (rec.role == 0) { blk = row / 48; const int rb = row - blk * 48; fr = rb & 15; byte = rb >> 4; }
+    else { blk = row >> 6; const int rb = row & 63, x = rb & 31; fr = ((x >> 3) << 2) | (x & 3); byte = (rb >> 5) * 2 + ((x >> 2) & 1); }
     rec.s[(((size_t)ktile * mx_nblk(rec.R, rec.role) + blk) * 4 + fg) * 64 + fr * 4 + byte] = (unsigned char)e8;
 }
 

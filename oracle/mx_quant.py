@@ -39,13 +39,14 @@ def scale_layout(e8: torch.Tensor, role: int) -> torch.Tensor:
     """[R, K/32] scale exponents -> the byte array egv_quant_mx writes (rows past R hold 0x7f)"""
     R, KB = e8.shape
     assert KB % 4 == 0
-    nblk = ((R + 255) // 256) * 4 if role == 0 else (R + 63) // 64
+    nblk = ((R + 191) // 192) * 4 if role == 0 else (R + 63) // 64
     out = torch.full((KB // 4, nblk, 4, 16, 4), 0x7f, dtype=torch.uint8)
     r = torch.arange(R)
-    blk, rb = r // 64, r % 64
-    if role == 0:
+    if role == 0:           # 48-row blocks: one sub-tile of a wave row of the GEMM's 192-row tile; byte = 16-row fragment 0..2
+        blk, rb = r // 48, r % 48
         fr, byte = rb % 16, rb // 16
-    else:
+    else:                   # 64-row blocks in the B-row permutation of the GEMM tile
+        blk, rb = r // 64, r % 64
         x = rb % 32
         fr, byte = ((x // 8) * 4) | (x % 4), (rb // 32) * 2 + ((x // 4) % 2)
     for kb in range(KB):
