@@ -14,7 +14,7 @@ import torch  # noqa: F401  -- must be imported first: the HIP runtime torch bun
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libegovlp_hip.so')
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 EGV_F32, EGV_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 
@@ -53,6 +53,7 @@ class VBlockDesc(C.Structure):
         ('dw', vp * 9), ('db', vp * 9), ('dln_g', vp * 4), ('dln_b', vp * 4), ('dalpha', vp),
         ('stream', vp), ('stream2', vp),
         ('flags', i32),
+        ('wq', vp * 9), ('wq_s', vp * 9), ('wtq', vp * 9), ('wtq_s', vp * 9),
     ]
 
 
@@ -82,6 +83,7 @@ class WgradProblem(C.Structure):
 
 BLOCK_NO_JOIN = 1
 BLOCK_RES_F32 = 2
+BLOCK_FP8 = 4
 
 
 # name -> (restype, argtypes); every symbol declared in include/egovlp_hip.h

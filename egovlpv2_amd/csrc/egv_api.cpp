@@ -17,7 +17,7 @@ void egv_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int egv_abi_version(void) { return 3; }
+extern "C" int egv_abi_version(void) { return 4; }
 
 extern "C" int egv_stream_create(int priority, void** stream) {
     if (!stream) { egv_set_error("egv_stream_create: null output pointer"); return -1; }

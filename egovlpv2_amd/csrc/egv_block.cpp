@@ -283,6 +283,31 @@ VLayout vlayout(const egv_vblock_desc* d) {
 
 // the weight gradients of a block go out as ONE grouped launch (egv_gemm5.hip) at the end of the backward call when the shapes
 // allow it: bf16, D and Hd multiples of 256, enough tokens
+// MX-fp8 forward / dgrad GEMMs (BASELINE.json configs[4]): bf16 block, flag set, shapes the MX kernel takes
+bool vfp8_on(const egv_vblock_desc* d) {
+    return (d->flags & EGV_BLOCK_FP8) && d->dtype == EGV_BF16 && (d->D % 128) == 0 && (d->Hd % 128) == 0 && d->D >= 384;
+}
+// scratch of one quantised A operand: codes [M, Kmax] + scale bytes
+size_t vfp8_ws_bytes(const egv_vblock_desc* d) {
+    if (!vfp8_on(d)) return 0;
+    const long long M = (long long)d->B * (1 + (long long)d->F * d->N);
+    const int Kmax = d->Hd > 3 * d->D ? d->Hd : 3 * d->D;
+    return al((size_t)M * Kmax) + al((size_t)egv_mx_scale_bytes((int)M, Kmax, 0)) + 4096;
+}
+struct Fp8 {                                     // quantise-then-GEMM for one block call
+    bool on;
+    int M;
+    void* q;
+    void* s;
+    void* st;
+    // y = epi(x W^T): x bf16 [M, K] -> MX codes, then the block-scaled GEMM on (wq, wq_s) [N, K]
+    int lin(int N, int K, const void* x, const void* wq, const void* wq_s, const float* b, void* y, int act, const void* r1, void* pre,
+            const void* aux, int dact) const {
+        if (egv_quant_mx(x, M, K, K, q, s, 0, st)) return -1;
+        return egv_gemm_mx(M, N, K, q, s, wq, wq_s, y, N, b, act, r1, pre, aux, dact, N, st);
+    }
+};
+
 bool vgroup_ok(const egv_vblock_desc* d) {
     static const bool on = !getenv("EGV_WGRAD_GROUP") || atoi(getenv("EGV_WGRAD_GROUP")) != 0;
     const long long M = (long long)d->B * (1 + (long long)d->F * d->N);
@@ -344,7 +369,7 @@ extern "C" long long egv_vblock_ws_bytes(const egv_vblock_desc* d, int backward)
         Plain p{d->dtype, d->B, d->H, d->D, (int)S, d->L, 0.125f, 0.f, 0u, nullptr};
         if (p.ws_bytes() > attn) attn = p.ws_bytes();
     }
-    size_t tot = al((size_t)attn) + 4096;
+    size_t tot = al((size_t)attn) + 4096 + vfp8_ws_bytes(d);
     if (backward) {
         long long wg = 0;
         auto mx = [&](long long v) { if (v > wg) wg = v; };
@@ -374,33 +399,44 @@ extern "C" int egv_vblock_fwd(const egv_vblock_desc* d) {
     Plain px{dt, d->B, d->H, D, S, d->L, 0.125f, 0.f, 0u, d->y_mask};
     if (fused && px.ws_bytes() > awb) awb = px.ws_bytes();
     void* aws = ws.take((size_t)awb);
+    Fp8 f8{vfp8_on(d), M, nullptr, nullptr, st};
+    if (f8.on) {
+        const int Kmax = Hd > 3 * D ? Hd : 3 * D;
+        f8.q = ws.take((size_t)M * Kmax);
+        f8.s = ws.take((size_t)egv_mx_scale_bytes(M, Kmax, 0));
+    }
     if (!ws.ok()) { egv_set_error("egv_vblock_fwd: workspace too small"); return -1; }
+    // one Linear over the M video tokens: MX-fp8 when the desc carries the quantised weight, bf16 otherwise
+    auto lin = [&](int w, int N, int K, const void* x, void* y, int act, const void* r1, void* pre) -> int {
+        if (f8.on && d->wq[w] && d->wq_s[w]) return f8.lin(N, K, x, d->wq[w], d->wq_s[w], d->b[w], y, act, r1, pre, nullptr, 0);
+        return lin_fwd(dt, M, N, K, x, d->w[w], d->b[w], y, act, nullptr, r1, nullptr, pre, st);
+    };
 
     // temporal attention (video_transformer.py:217-218): x + proj(attn(qkv(norm3 x)))
     BCHK(egv_layernorm_fwd(dt, d->x, sv + L.h3, d->ln_g[VL_NORM3], d->ln_b[VL_NORM3], (float*)(sv + L.stats3), M, D, d->eps, st));
-    BCHK(lin_fwd(dt, M, 3 * D, D, sv + L.h3, d->w[VW_TQKV], d->b[VW_TQKV], sv + L.qkv_t, 0, nullptr, nullptr, nullptr, nullptr, st));
+    BCHK(lin(VW_TQKV, 3 * D, D, sv + L.h3, sv + L.qkv_t, 0, nullptr, nullptr));
     BCHK(dvt.fwd(sv + L.qkv_t, sv + L.tctx, (float*)(sv + L.lse_t), aws, awb, st));
-    BCHK(lin_fwd(dt, M, D, D, sv + L.tctx, d->w[VW_TPROJ], d->b[VW_TPROJ], sv + L.tr, 0, nullptr, d->x, nullptr, nullptr, st));
+    BCHK(lin(VW_TPROJ, D, D, sv + L.tctx, sv + L.tr, 0, d->x, nullptr));
     // spatial attention (:219-222): residual from x, not from the time residual
     BCHK(egv_layernorm_fwd(dt, sv + L.tr, sv + L.h1, d->ln_g[VL_NORM1], d->ln_b[VL_NORM1], (float*)(sv + L.stats1), M, D, d->eps, st));
-    BCHK(lin_fwd(dt, M, 3 * D, D, sv + L.h1, d->w[VW_SQKV], d->b[VW_SQKV], sv + L.qkv_s, 0, nullptr, nullptr, nullptr, nullptr, st));
+    BCHK(lin(VW_SQKV, 3 * D, D, sv + L.h1, sv + L.qkv_s, 0, nullptr, nullptr));
     BCHK(dvs.fwd(sv + L.qkv_s, sv + L.sctx, (float*)(sv + L.lse_s), aws, awb, st));
     if (!fused) {
-        BCHK(lin_fwd(dt, M, D, D, sv + L.sctx, d->w[VW_SPROJ], d->b[VW_SPROJ], sv + L.sr, 0, nullptr, d->x, nullptr, nullptr, st));
+        BCHK(lin(VW_SPROJ, D, D, sv + L.sctx, sv + L.sr, 0, d->x, nullptr));
     } else {
         // image-to-text cross attention (:155-185): s = proj(ctx); q from norm_i2t_i(s), k|v from the text states; x + s + alpha*proj_i2t(o)
         const int BL = d->B * d->L;
-        BCHK(lin_fwd(dt, M, D, D, sv + L.sctx, d->w[VW_SPROJ], d->b[VW_SPROJ], sv + L.s, 0, nullptr, nullptr, nullptr, nullptr, st));
+        BCHK(lin(VW_SPROJ, D, D, sv + L.sctx, sv + L.s, 0, nullptr, nullptr));
         BCHK(lin_fwd(dt, BL, 2 * D, D, d->y, d->w[VW_KV_I2T], d->b[VW_KV_I2T], sv + L.kv, 0, nullptr, nullptr, nullptr, nullptr, st));
         BCHK(egv_layernorm_fwd(dt, sv + L.s, sv + L.hs, d->ln_g[VL_NORM_I2T], d->ln_b[VL_NORM_I2T], (float*)(sv + L.stats_i), M, D, d->eps, st));
-        BCHK(lin_fwd(dt, M, D, D, sv + L.hs, d->w[VW_Q_I2T], d->b[VW_Q_I2T], sv + L.q, 0, nullptr, nullptr, nullptr, nullptr, st));
+        BCHK(lin(VW_Q_I2T, D, D, sv + L.hs, sv + L.q, 0, nullptr, nullptr));
         BCHK(px.fwd(sv + L.q, D, sv + L.kv, at(sv + L.kv, (size_t)D * esz(dt)), 2 * D, sv + L.o, (float*)(sv + L.lse_x), aws, awb, st));
         BCHK(lin_fwd(dt, M, D, D, sv + L.o, d->w[VW_PROJ_I2T], d->b[VW_PROJ_I2T], sv + L.sr, 0, d->alpha, sv + L.s, d->x, sv + L.pg, st));
     }
     // MLP (:226): sr + fc2(gelu(fc1(norm2 sr)))
     BCHK(egv_layernorm_fwd(dt, sv + L.sr, sv + L.h2, d->ln_g[VL_NORM2], d->ln_b[VL_NORM2], (float*)(sv + L.stats2), M, D, d->eps, st));
-    BCHK(lin_fwd(dt, M, Hd, D, sv + L.h2, d->w[VW_FC1], d->b[VW_FC1], sv + L.act, EGV_ACT_GELU, nullptr, nullptr, nullptr, sv + L.pre, st));
-    BCHK(lin_fwd(dt, M, D, Hd, sv + L.act, d->w[VW_FC2], d->b[VW_FC2], d->out, 0, nullptr, sv + L.sr, nullptr, nullptr, st));
+    BCHK(lin(VW_FC1, Hd, D, sv + L.h2, sv + L.act, EGV_ACT_GELU, nullptr, sv + L.pre));
+    BCHK(lin(VW_FC2, D, Hd, sv + L.act, d->out, 0, sv + L.sr, nullptr));
     return 0;
 }
 
@@ -457,7 +493,19 @@ extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
         delta_x = (float*)ws.take((size_t)M * H * 4);
     }
     void* dotw = ws.take(4096);
+    Fp8 f8{vfp8_on(d), M, nullptr, nullptr, st};
+    if (f8.on) {
+        const int Kmax = Hd > 3 * D ? Hd : 3 * D;
+        f8.q = ws.take((size_t)M * Kmax);
+        f8.s = ws.take((size_t)egv_mx_scale_bytes(M, Kmax, 0));
+    }
     if (!ws.ok()) { egv_set_error("egv_vblock_bwd: workspace too small (%zu > %zu)", ws.off, ws.cap); return -1; }
+    // dx[M,K] = (dz[M,N] W[N,K]) * act'(aux) over the M video tokens: MX-fp8 on the quantised transposed weight when the desc
+    // carries it (the output gradient is quantised along N, the contraction), bf16 otherwise
+    auto dgrad = [&](int w, int N, int K, const void* dz, void* dx, const void* aux, int dact) -> int {
+        if (f8.on && d->wtq[w] && d->wtq_s[w]) return f8.lin(K, N, dz, d->wtq[w], d->wtq_s[w], nullptr, dx, 0, nullptr, nullptr, aux, dact);
+        return lin_dgrad(dt, M, N, K, dz, d->w[w], d->wt[w], dx, nullptr, aux, dact, st);
+    };
     // weight gradients over the M video tokens: collected and launched together at the end of the call (every operand -- saved
     // activations, scratch, dout -- stays untouched until then), or one launch each on the side stream as soon as ready
     // Where the weight gradients run:
@@ -484,9 +532,9 @@ extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
 
     // ---- MLP: out = sr + fc2(gelu(pre)), pre = fc1(h2)
     BCHK(wgrad(D, Hd, d->dout, sv + L.act, VW_FC2, nullptr, M));
-    BCHK(lin_dgrad(dt, M, D, Hd, d->dout, d->w[VW_FC2], d->wt[VW_FC2], dpre, nullptr, sv + L.pre, EGV_ACT_GELU, st));
+    BCHK(dgrad(VW_FC2, D, Hd, d->dout, dpre, sv + L.pre, EGV_ACT_GELU));
     BCHK(wgrad(Hd, D, dpre, sv + L.h2, VW_FC1, nullptr, M));
-    BCHK(lin_dgrad(dt, M, Hd, D, dpre, d->w[VW_FC1], d->wt[VW_FC1], dh2, nullptr, nullptr, 0, st));
+    BCHK(dgrad(VW_FC1, Hd, D, dpre, dh2, nullptr, 0));
     // d_sr = LN2'(dh2) + dout (skip path of the MLP residual)
     BCHK(egv_layernorm_bwd2(dt, dh2, sv + L.sr, (const float*)(sv + L.stats2), d->ln_g[VL_NORM2], d->dout, nullptr, d_sr, d->dln_g[VL_NORM2],
                             d->dln_b[VL_NORM2], M, D, lnw, st));
@@ -500,7 +548,7 @@ extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
         BCHK(px.bwd(sv + L.q, D, sv + L.kv, at(sv + L.kv, (size_t)D * es), 2 * D, sv + L.o, (float*)const_cast<char*>(sv + L.lse_x), d_o, dq, D, dkv,
                     at(dkv, (size_t)D * es), 2 * D, delta_x, aws, awb, st));
         BCHK(wgrad(D, D, dq, sv + L.hs, VW_Q_I2T, nullptr, M));
-        BCHK(lin_dgrad(dt, M, D, D, dq, d->w[VW_Q_I2T], d->wt[VW_Q_I2T], dhs, nullptr, nullptr, 0, st));
+        BCHK(dgrad(VW_Q_I2T, D, D, dq, dhs, nullptr, 0));
         BCHK(egv_layernorm_bwd2(dt, dhs, sv + L.s, (const float*)(sv + L.stats_i), d->ln_g[VL_NORM_I2T], d_sr, nullptr, d_s, d->dln_g[VL_NORM_I2T],
                                 d->dln_b[VL_NORM_I2T], M, D, lnw, st));
         BCHK(lin_wgrad(dt, BL, 2 * D, D, dkv, 2 * D, d->y, d->dw[VW_KV_I2T], d->db[VW_KV_I2T], nullptr, wgw, wgb, fk.begin()));
@@ -509,18 +557,18 @@ extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
     }
     // ---- spatial attention
     BCHK(wgrad(D, D, d_sproj_out, sv + L.sctx, VW_SPROJ, nullptr, M));
-    BCHK(lin_dgrad(dt, M, D, D, d_sproj_out, d->w[VW_SPROJ], d->wt[VW_SPROJ], d_sctx, nullptr, nullptr, 0, st));
+    BCHK(dgrad(VW_SPROJ, D, D, d_sproj_out, d_sctx, nullptr, 0));
     BCHK(dvs.bwd(sv + L.qkv_s, sv + L.sctx, (float*)const_cast<char*>(sv + L.lse_s), d_sctx, dqkv_s, delta_s, aws, awb, st));
     BCHK(wgrad(3 * D, D, dqkv_s, sv + L.h1, VW_SQKV, nullptr, M));
-    BCHK(lin_dgrad(dt, M, 3 * D, D, dqkv_s, d->w[VW_SQKV], d->wt[VW_SQKV], dh1, nullptr, nullptr, 0, st));
+    BCHK(dgrad(VW_SQKV, 3 * D, D, dqkv_s, dh1, nullptr, 0));
     BCHK(egv_layernorm_bwd2(dt, dh1, sv + L.tr, (const float*)(sv + L.stats1), d->ln_g[VL_NORM1], nullptr, nullptr, d_tr, d->dln_g[VL_NORM1],
                             d->dln_b[VL_NORM1], M, D, lnw, st));
     // ---- temporal attention
     BCHK(wgrad(D, D, d_tr, sv + L.tctx, VW_TPROJ, nullptr, M));
-    BCHK(lin_dgrad(dt, M, D, D, d_tr, d->w[VW_TPROJ], d->wt[VW_TPROJ], d_tctx, nullptr, nullptr, 0, st));
+    BCHK(dgrad(VW_TPROJ, D, D, d_tr, d_tctx, nullptr, 0));
     BCHK(dvt.bwd(sv + L.qkv_t, sv + L.tctx, (float*)const_cast<char*>(sv + L.lse_t), d_tctx, dqkv_t, delta_t, aws, awb, st));
     BCHK(wgrad(3 * D, D, dqkv_t, sv + L.h3, VW_TQKV, nullptr, M));
-    BCHK(lin_dgrad(dt, M, 3 * D, D, dqkv_t, d->w[VW_TQKV], d->wt[VW_TQKV], dh3, nullptr, nullptr, 0, st));
+    BCHK(dgrad(VW_TQKV, 3 * D, D, dqkv_t, dh3, nullptr, 0));
     // dx = LN3'(dh3) + d_sr + d_tr: x feeds norm3, the time residual and the space residual
     BCHK(egv_layernorm_bwd2(dt, dh3, d->x, (const float*)(sv + L.stats3), d->ln_g[VL_NORM3], d_sr, d_tr, d->dx, d->dln_g[VL_NORM3],
                             d->dln_b[VL_NORM3], M, D, lnw, st));

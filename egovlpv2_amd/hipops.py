@@ -136,7 +136,19 @@ _wprep = {}
 _wmerged = {}            # id(first weight of a group) -> (versions, merged W [sum R, C], merged W^T [C, sum R], merged bias or None, members, stream, event)
 
 
-def prepare_weights(weights, dtype: torch.dtype, groups=()):
+_wmx = {}    # id(fp32 weight) -> (version, codes [R,C], scales, codes of W^T [C,R], scales, weight, stream, event): MX-fp8 copies
+
+
+def mx_weight(w):
+    """(q, q_scales, qt, qt_scales) of a weight prepared by prepare_weights(..., fp8=[...]) for its current version, else None"""
+    e = _wmx.get(id(w))
+    if e is None or e[0] != w._version or e[5] is not w:
+        return None
+    _cross_stream((e[0], e[1], None, e[6], e[7]))
+    return e[1], e[2], e[3], e[4]
+
+
+def prepare_weights(weights, dtype: torch.dtype, groups=(), fp8=()):
     """One launch that makes the bf16 W and W^T compute copies of every listed fp32 [R, C] weight (R, C multiples of 64) and
     seeds the two caches above, so that the forward/backward of the step finds them ready.  Weights that do not qualify are
     left to the lazy per-tensor path.  A no-op when the copies of the current parameter versions already exist.
@@ -144,7 +156,10 @@ def prepare_weights(weights, dtype: torch.dtype, groups=()):
     groups: tuples (weights, biases) of Linears that read the SAME input (query / key / value of a RoBERTa layer, key / value of its
     text-to-image cross attention): their copies are laid out as ONE [sum R, C] matrix (row blocks) and ONE [C, sum R] transposed matrix
     (column blocks, written with a row pitch), and their biases are concatenated by a second small launch, so that the layer can run
-    them as one GEMM (merged_weights).  The per-weight entries of the caches are views of the merged buffers."""
+    them as one GEMM (merged_weights).  The per-weight entries of the caches are views of the merged buffers.
+
+    fp8: weights (a subset of `weights`, not in a group, R and C multiples of 128) that also get MX-fp8 copies of W and W^T (one more
+    launch over the bf16 copies: egv_quant_mx_batch, role 1), for the MX-fp8 forward / dgrad GEMMs of the video blocks (mx_weight)."""
     if dtype != torch.bfloat16:
         return
     ws = [w for w in weights if w.dim() == 2 and w.dtype == torch.float32 and w.is_contiguous() and w.is_cuda
@@ -156,7 +171,7 @@ def prepare_weights(weights, dtype: torch.dtype, groups=()):
             (c := _wcache.get(id(w))) is not None and c[0] == w._version and c[2] is w for w in ws):
         return
     import numpy as np
-    key = tuple(id(w) for w in ws)
+    key = tuple(id(w) for w in ws) + ('mx',) + tuple(id(w) for w in fp8)
     ent = _wprep.get(key)
     ptrs = [w.data_ptr() for w in ws]
     if ent is None or ent['ptrs'] != ptrs:
@@ -208,11 +223,37 @@ def prepare_weights(weights, dtype: torch.dtype, groups=()):
             seg_tab = seg_pin.to(dev, non_blocking=True)
         ent = _wprep[key] = {'ptrs': ptrs, 'outs': outs, 'table': pin.to(dev, non_blocking=True), 'prefix': pre.to(dev, non_blocking=True),
                              'ntiles': int(prefix[-1]), 'pins': (pin, pre, seg_pin), 'refs': ws, 'merged': merged, 'segs': seg_tab, 'nseg': len(segs),
-                             'bias_ptrs': [b_.data_ptr() for b_, _, _ in segs]}
+                             'bias_ptrs': [b_.data_ptr() for b_, _, _ in segs], 'mx': None}
+        want = {id(w) for w in fp8}
+        mxw = [(w, o, ot) for w, (o, ot) in zip(ws, outs) if id(w) in want and id(w) not in member and w.shape[0] % 128 == 0 and w.shape[1] % 128 == 0]
+        if mxw:
+            recs, mouts = [], []
+            for w, o, ot in mxw:
+                R, Cc = w.shape
+                q, qt = torch.empty(R, Cc, dtype=torch.uint8, device=dev), torch.empty(Cc, R, dtype=torch.uint8, device=dev)
+                sq = torch.full((lib.egv_mx_scale_bytes(R, Cc, 1),), 0x7f, dtype=torch.uint8, device=dev)
+                sqt = torch.full((lib.egv_mx_scale_bytes(Cc, R, 1),), 0x7f, dtype=torch.uint8, device=dev)
+                mouts.append((q, sq, qt, sqt))
+                recs.append((o.data_ptr(), q.data_ptr(), sq.data_ptr(), R, Cc, Cc, 1))
+                recs.append((ot.data_ptr(), qt.data_ptr(), sqt.data_ptr(), Cc, R, R, 1))
+            marr = np.zeros(len(recs), dtype=[('s', '<u8'), ('q', '<u8'), ('c', '<u8'), ('R', '<i4'), ('K', '<i4'), ('ld', '<i4'), ('role', '<i4')])
+            for k, name in enumerate(('s', 'q', 'c', 'R', 'K', 'ld', 'role')):
+                marr[name] = [r[k] for r in recs]
+            mpre = np.zeros(len(recs) + 1, dtype=np.int32)
+            mpre[1:] = np.cumsum([(r[3] * (r[4] // 32) + 255) // 256 for r in recs])
+            mpin, mppin = torch.from_numpy(marr.view(np.uint8).copy()).pin_memory(), torch.from_numpy(mpre).pin_memory()
+            ent['mx'] = {'w': [m[0] for m in mxw], 'outs': mouts, 'table': mpin.to(dev, non_blocking=True), 'prefix': mppin.to(dev, non_blocking=True),
+                         'n': len(recs), 'nblocks': int(mpre[-1]), 'pins': (mpin, mppin)}
     check(lib.egv_cast_weights_ld(_p(ent['table']), _p(ent['prefix']), len(ws), ent['ntiles'], _st()), 'egv_cast_weights_ld')
     if ent['nseg']:
         check(lib.egv_copy_segments(_p(ent['segs']), ent['nseg'], _st()), 'egv_copy_segments')
+    if ent['mx'] is not None:
+        m = ent['mx']
+        check(lib.egv_quant_mx_batch(_p(m['table']), _p(m['prefix']), m['n'], m['nblocks'], _st()), 'egv_quant_mx_batch')
     ev, st = _cast_event(), _st()
+    if ent['mx'] is not None:
+        for w, (q, sq, qt, sqt) in zip(ent['mx']['w'], ent['mx']['outs']):
+            _wmx[id(w)] = (w._version, q, sq, qt, sqt, w, st, ev)
     for w, (o, ot) in zip(ws, ent['outs']):
         _wcache[id(w)] = (w._version, o, w, st, ev)
         # a member of a merged group has no transposed copy of its own (its block of the merged W^T has the group's row pitch):
@@ -1077,7 +1118,7 @@ class VideoBlockFn(Function):
 
     @staticmethod
     def _desc(cfg, x, y, y_mask, params):
-        B, Fr, N, H, Hd, eps, L_, _track = cfg
+        B, Fr, N, H, Hd, eps, L_, _track, fp8 = cfg
         fused = L_ > 0
         d = L.VBlockDesc()
         d.dtype, d.B, d.F, d.N, d.H, d.D, d.Hd, d.L, d.eps = _dt(x), B, Fr, N, H, x.shape[1], Hd, L_, eps
@@ -1086,6 +1127,13 @@ class VideoBlockFn(Function):
         ws = [params[2 * i] for i in range(6)] + ([params[18 + 2 * i] for i in range(3)] if fused else [])
         bs = [params[2 * i + 1] for i in range(6)] + ([params[19 + 2 * i] for i in range(3)] if fused else [])
         _fill_weights(d, ws, x.dtype)
+        if fp8 and x.dtype == torch.bfloat16:
+            d.flags |= L.BLOCK_FP8
+            for i in ([0, 1, 2, 3, 4, 5] + ([7] if fused else [])):      # the Linears over the M video tokens without a gate
+                m = mx_weight(ws[i])
+                if m is None:
+                    raise RuntimeError('video_block(fp8=True): no MX-fp8 copy of weight %d -- call prepare_weights(..., fp8=[...]) first' % i)
+                d.wq[i], d.wq_s[i], d.wtq[i], d.wtq_s[i] = _p(m[0]), _p(m[1]), _p(m[2]), _p(m[3])
         for i in range(nw):
             d.b[i] = _p(bs[i])
         for i in range(3):
@@ -1145,7 +1193,7 @@ class VideoBlockFn(Function):
             # the grouped weight-gradient launch of this call keeps running on the companion stream after the call returns:
             # everything it reads or writes must outlive it in the caching allocator, and the calling stream is joined at the
             # end of the backward pass (_backward_done)
-            d.flags = L.BLOCK_NO_JOIN
+            d.flags |= L.BLOCK_NO_JOIN
             for t in (ws, save, dout, gp.flat, y):
                 if t is not None:
                     t.record_stream(side[0])
@@ -1155,8 +1203,9 @@ class VideoBlockFn(Function):
         return (None, dx, dy, None, *_acc_backward(ctx.key, gp, params, 18, side))
 
 
-def video_block(x, params, B, Fr, N, H, Hd, eps, y=None, y_mask=None, L=0):
-    return VideoBlockFn.apply((B, Fr, N, H, Hd, float(eps), L if y is not None else 0, _tracks_grad(params)), x, y, y_mask, *params)
+def video_block(x, params, B, Fr, N, H, Hd, eps, y=None, y_mask=None, L=0, fp8=False):
+    """fp8: the forward / dgrad GEMMs over the video tokens on MX-fp8 operands (bf16 mode only; BASELINE.json configs[4])"""
+    return VideoBlockFn.apply((B, Fr, N, H, Hd, float(eps), L if y is not None else 0, _tracks_grad(params), bool(fp8)), x, y, y_mask, *params)
 
 
 class TextLayerFn(Function):

@@ -116,7 +116,8 @@ class SelectClipsFn(torch.autograd.Function):
 class FrozenInTime(nn.Module):
     def __init__(self, video_params, text_params, projection_dim=4096, load_checkpoint=None, projection='minimal',
                  load_temporal_fix='bilinear', config=config, task_names='EgoNCE_ITM_MLM', norm_layer=None, embed_dim=768,
-                 compute_dtype=torch.bfloat16, path_config: PathConfig | None = None, init_seed: int = 0, text_fp32: bool = False):
+                 compute_dtype=torch.bfloat16, path_config: PathConfig | None = None, init_seed: int = 0, text_fp32: bool = False,
+                 video_fp8: bool = False):
         super().__init__()
         self.video_params = video_params
         self.text_params = text_params
@@ -147,6 +148,9 @@ class FrozenInTime(nn.Module):
         self.num_text_layer = self.cfg.depth
         self.compute_dtype = compute_dtype
         self.text_fp32 = bool(text_fp32) or os.environ.get('EGV_TEXT_FP32', '0') == '1'
+        # BASELINE.json configs[4] ("fp8 MFMA weight path"): the forward / data-gradient GEMMs of the video blocks on MX-fp8 (OCP
+        # MXFP8 E4M3) weights and activations; weight gradients, attention, LayerNorm, the text tower and the heads stay bf16
+        self.video_fp8 = (bool(video_fp8) or os.environ.get('EGV_VIDEO_FP8', '0') == '1') and compute_dtype == torch.bfloat16
         # bf16 mode: the text tower's residual stream (LayerNorm inputs / outputs, residual sums) stays fp32 between bf16 GEMMs, as under
         # torch.autocast (trainer/trainer_egoclip.py:143); EGV_TEXT_RES32=0 stores it in bf16 like the video tower's
         self.text_res32 = compute_dtype == torch.bfloat16 and os.environ.get('EGV_TEXT_RES32', '1') != '0'
@@ -312,7 +316,16 @@ class FrozenInTime(nn.Module):
                 for names in sets:
                     groups.append(([self.p(n + '.weight') for n in names], [self.p(n + '.bias') for n in names]))
             self.__dict__['_gemm_groups'] = groups if os.environ.get('EGV_MERGE_PROJ', '1') != '0' else []
-        ops.prepare_weights(lst, self.compute_dtype, groups=self.__dict__['_gemm_groups'])
+            c = self.cfg
+            mx = []
+            if self.video_fp8 and c.dim % 128 == 0 and c.dim >= 384:
+                for i in range(c.depth):
+                    b = f'video_model.blocks.{i}.'
+                    mx += [self.p(b + m + '.weight') for m in ('timeattn.qkv', 'timeattn.proj', 'attn.qkv', 'attn.proj', 'mlp.fc1', 'mlp.fc2')]
+                    if i >= c.depth - c.n_fuse:
+                        mx.append(self.p(b + 'attn.qkv_i2t.weight'))
+            self.__dict__['_mx_weights'] = mx
+        ops.prepare_weights(lst, self.compute_dtype, groups=self.__dict__['_gemm_groups'], fp8=self.__dict__['_mx_weights'])
 
     def p(self, name: str) -> torch.Tensor:
         if self._P is None:
@@ -371,7 +384,7 @@ class FrozenInTime(nn.Module):
         backward (csrc/egv_block.cpp)."""
         c = self.cfg
         return ops.video_block(x, self._block_params('video', i, y is not None), B, c.frames, c.n_patches, c.heads, c.dim * c.mlp_ratio,
-                               c.eps_video, y=y, y_mask=y_mask, L=L)
+                               c.eps_video, y=y, y_mask=y_mask, L=L, fp8=bool(self.__dict__.get('_mx_weights')))
 
     def _cls_rows(self, x, B, rows_per_sample):
         return x.reshape(B, rows_per_sample, -1)[:, 0].contiguous()

@@ -264,7 +264,9 @@ int egv_adamw_step(const void* table, const int* prefix, int ntensors, int nchun
  * weights 6..8 = qkv_text_i2t (2D x D), qkv_i2t, proj_i2t, LayerNorm 3 = norm_i2t_i, alpha = alpha_i2t (:155-185).
  * Weight order: timeattn.qkv, timeattn.proj, attn.qkv, attn.proj, mlp.fc1, mlp.fc2; LayerNorm order: norm3, norm1, norm2. */
 #define EGV_BLOCK_NO_JOIN 1
-#define EGV_BLOCK_RES_F32 2      /* egv_tlayer_*: hid / out / dout / dhid are fp32 (the text tower's fp32 residual stream), dtype = EGV_BF16 */
+#define EGV_BLOCK_RES_F32 2
+      /* egv_tlayer_*: hid / out / dout / dhid are fp32 (the text tower's fp32 residual stream), dtype = EGV_BF16 */
+#define EGV_BLOCK_FP8 4       /* egv_vblock_*: MX-fp8 forward / dgrad GEMMs where the desc carries quantised weights */
 typedef struct egv_vblock_desc {
     int dtype, B, F, N, H, D, Hd, L;
     float eps;
@@ -280,6 +282,11 @@ typedef struct egv_vblock_desc {
     float* dw[9]; float* db[9]; float* dln_g[4]; float* dln_b[4]; float* dalpha;
     void* stream; void* stream2;
     int flags;                                      /* EGV_BLOCK_* */
+    /* EGV_BLOCK_FP8 (bf16 blocks): MX-fp8 copies of the Linear weights (egv_quant_mx role 1) -- wq[i] / wq_s[i] = codes / scales of
+     * w[i] [N,K] (forward), wtq[i] / wtq_s[i] of wt[i] [K,N] (data gradient).  A Linear with both operands present runs its forward /
+     * dgrad over the M video tokens as egv_gemm_mx on activations quantised on the fly (role 0); NULL entries, the weight gradients,
+     * the gated i2t projection and the B*L-row text projections stay bf16. */
+    const void* wq[9]; const void* wq_s[9]; const void* wtq[9]; const void* wtq_s[9];
 } egv_vblock_desc;
 long long egv_vblock_save_bytes(const egv_vblock_desc* d);
 long long egv_vblock_ws_bytes(const egv_vblock_desc* d, int backward);

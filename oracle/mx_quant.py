@@ -57,3 +57,54 @@ def scale_layout(e8: torch.Tensor, role: int) -> torch.Tensor:
 def gemm_ref(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """fp64 product of the dequantised operands: what an exact block-scaled fp8 GEMM returns for a [M,K], b [N,K]"""
     return fake_quant(a).double() @ fake_quant(b).double().t()
+
+
+# ---- block-level oracle: the reference's Linear (video_transformer.py:53,56,120,152,166,183) under the MX-fp8 weight path --------
+class MxLinearFn(torch.autograd.Function):
+    """y = Q(x) Q(W)^T + b with both operands MX-quantised along the contraction dimension (dequantised-weight fp32 reference);
+    dx = Q(dy) Q'(W) with the output gradient and the weight quantised along N (the contraction of the data gradient);
+    dW = dy^T x and db = sum dy from the un-quantised (bf16-rounded) operands, as the product computes them."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1]).to(torch.bfloat16).float()
+        wb = w.to(torch.bfloat16).float()
+        ctx.save_for_backward(x2, wb)
+        ctx.shp, ctx.has_b = shp, b is not None
+        y = fake_quant(x2) @ fake_quant(wb).t()
+        if b is not None:
+            y = y + b
+        return y.reshape(*shp[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wb = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1]).to(torch.bfloat16).float()
+        dx = fake_quant(dy2) @ fake_quant(wb.t().contiguous()).t()
+        dw = dy2.t() @ x2
+        db = dy2.sum(0) if ctx.has_b else None
+        return dx.reshape(ctx.shp), dw, db
+
+
+import contextlib
+import re
+
+_VIDEO_LINEAR = re.compile(r'video_model\.blocks\.\d+\.(timeattn\.(qkv|proj)|attn\.(qkv|proj|qkv_i2t)|mlp\.fc[12])$')
+
+
+@contextlib.contextmanager
+def mx_video_linears(ref_model):
+    """inside the context the oracle (oracle/ref_model.py) runs the forward / data gradient of every video-block Linear over the video
+    tokens -- the ones the product runs on MX-fp8 operands -- through MxLinearFn"""
+    orig = ref_model._lin
+
+    def _lin(x, sd, prefix, bias=True):
+        if _VIDEO_LINEAR.match(prefix) and x.shape[-1] % 128 == 0:
+            return MxLinearFn.apply(x, sd[prefix + '.weight'], sd[prefix + '.bias'] if bias else None)
+        return orig(x, sd, prefix, bias)
+    ref_model._lin = _lin
+    try:
+        yield
+    finally:
+        ref_model._lin = orig
