@@ -117,6 +117,7 @@ def main():
     ap.add_argument('--arch', default='base16', choices=['base16', 'large14'],
                     help='base16: ViT-B/16 + RoBERTa-base (the measured configs); large14: the configs[4] geometry -- ViT-L/14 TimeSformer '
                          '(24 blocks, d = 1024, 16 heads, 256 patches per frame) + RoBERTa-large width, 12 fused layers -- in bf16 (no fp8 weights)')
+    ap.add_argument('--fp8', action='store_true', help='configs[4] "fp8 MFMA weight path": MX-fp8 forward / dgrad GEMMs in the video blocks (FrozenInTime(video_fp8=True))')
     ap.add_argument('--optimizer', action='store_true', help='also time the fused AdamW step + LR schedule (SURVEY.md §8f item 1)')
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--frames', type=int, default=16)
@@ -167,7 +168,7 @@ def main():
     dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
     model = FrozenInTime({'model': 'SpaceTimeTransformer', 'num_frames': cfg.frames, 'pretrained': True},
                          {'model': 'roberta-base', 'pretrained': True, 'input': 'text'}, path_config=cfg,
-                         task_names='EgoNCE_MLM_ITM', compute_dtype=dtype)
+                         task_names='EgoNCE_MLM_ITM', compute_dtype=dtype, video_fp8=a.fp8)
     model.load_state_dict(make_state_dict(cfg, 0), strict=True)          # same random-init weights on every rank
     model = model.to(dev)
     net = model
@@ -351,7 +352,7 @@ def main():
         out = {"metric": "video-text pairs/sec/node (EgoClip fwd+bwd, 16x224^2, 32 tok)", "value": round(value, 3),
                "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": a.dtype, "data": "synthetic",
+               "dtype": (a.dtype + "+mxfp8(video fwd/dgrad GEMMs)") if a.fp8 else a.dtype, "data": "synthetic",
                "config": {"workload": (("configs[2] full fusion EgoNCE+MLM+ITM" if a.arch == 'base16' else "full fusion EgoNCE+MLM+ITM") if a.workload == 'full' else "configs[1] dual encoder EgoNCE")
                           + (f", ViT-B/16 TimeSformer + RoBERTa-base" if a.arch == 'base16' else ", configs[4] geometry: ViT-L/14 TimeSformer + RoBERTa-large width, bf16 weights")
                           + f", B={a.batch}/GPU, {a.frames}x224^2, {a.text_len} tok",

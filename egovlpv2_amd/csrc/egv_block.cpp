@@ -338,6 +338,16 @@ int vgroup_cus(const egv_vblock_desc* d) {
     const int cap = device_cus() / 2;
     return g > cap ? cap : g;
 }
+// Deferred grouped weight gradients pay when the group fits beside the data-gradient chain: measured on the ViT-L/14 geometry
+// (256 output tiles per block, bf16) every CU split loses to one launch per gradient on the companion stream (190-256 vs 183 ms per
+// step), while with MX-fp8 data-gradient GEMMs -- a chain a third shorter -- the split wins (167 vs 213 ms).  EGV_WGRAD_DEFER_MAXTILES
+// overrides the bf16 limit.
+bool vdefer_ok(const egv_vblock_desc* d) {
+    static const int max_tiles = getenv("EGV_WGRAD_DEFER_MAXTILES") ? atoi(getenv("EGV_WGRAD_DEFER_MAXTILES")) : 192;
+    const int tD = d->D / 256, tH = d->Hd / 256;
+    const int ntile = 2 * tD * tH + 2 * tD * tD + 2 * 3 * tD * tD + (d->L > 0 ? 2 * tD * tD : 0);
+    return vfp8_on(d) || ntile <= max_tiles;
+}
 struct CuLimit {                                    // scoped egv_gemm_set_cu_limit
     bool on;
     explicit CuLimit(int n) : on(n > 0) { if (on) egv_gemm_set_cu_limit(n); }
@@ -444,7 +454,7 @@ extern "C" int egv_vblock_fwd(const egv_vblock_desc* d) {
 // then owes the join and must keep ws / save / dout alive until stream2 has drained), 0 if the call joins by itself anyway
 extern "C" int egv_vblock_bwd_defers(const egv_vblock_desc* d) {
     const long long M = (long long)d->B * (1 + (long long)d->F * d->N);
-    return (vgroup_ok(d) && d->stream2 && d->stream2 != d->stream && M >= 4096) ? 1 : 0;
+    return (vgroup_ok(d) && vdefer_ok(d) && d->stream2 && d->stream2 != d->stream && M >= 4096) ? 1 : 0;
 }
 
 extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
@@ -515,7 +525,7 @@ extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
     //  * no companion stream: one grouped launch on the calling stream (7/8 of the CUs: the chip-wide rate of this kernel peaks there);
     //  * companion stream, joined inside the call (DistributedDataParallel, gradient accumulation, hooks): one launch per gradient
     //    as soon as its operands exist, fp32 slabs + reduction launch (egv_gemm4.hip).
-    const bool side_group = vgroup_ok(d) && fk.forked() && (d->flags & EGV_BLOCK_NO_JOIN);
+    const bool side_group = vgroup_ok(d) && vdefer_ok(d) && fk.forked() && (d->flags & EGV_BLOCK_NO_JOIN);
     const bool group = vgroup_ok(d) && (side_group || !fk.forked());
     static const int main_limit = getenv("EGV_WGRAD_MAIN_LIMIT") ? atoi(getenv("EGV_WGRAD_MAIN_LIMIT")) : 0;
     CuLimit cu_limit(side_group ? (main_limit > 0 ? main_limit : device_cus() - vgroup_cus(d)) : 0);

@@ -1537,3 +1537,4 @@ def invalidate_weight_cache():
     _wcache.clear()
     _wtcache.clear()
     _wmerged.clear()
+    _wmx.clear()
