@@ -135,3 +135,36 @@ def test_oracle_dual_variant(name):
             if key.startswith(f'{ds}_grad_slice::'):
                 k = key.split('::', 1)[1]
                 assert rel_err(sd[k].grad.reshape(-1)[:64], g[key]) < 2e-4, key
+
+
+def test_mx_quant_oracle_known_answers():
+    """oracle/mx_quant.py against hand-derived vectors of the OCP MX v1.0 format (MXFP8, E4M3 elements, E8M0 scales): element codes
+    of exactly representable values, the scale rule at its boundaries (amax = 1.75 * 2^e keeps the lower scale, anything above takes
+    the next one), zero blocks, round-to-nearest-even ties, and the scale-byte order of both GEMM roles."""
+    import torch
+    from oracle import mx_quant as MX
+    x = torch.zeros(5, 32)
+    x[0, 0], x[0, 1], x[0, 2] = 448.0, 1.0, -0.5            # amax 448 = 1.75 * 2^8 -> scale 2^0
+    x[1, 0], x[1, 1] = 449.0, 1.0                           # above 448 -> scale 2^1: 449 / 2 = 224.5 -> 224 (ulp 16 at 2^7), 0.5 -> 0x30
+    x[2, 0] = 2.0 ** -20                                    # amax 2^-20 -> scale 2^-28, element 2^8 = 0x78
+    x[4, 0], x[4, 1], x[4, 2] = 1.0, 1.0625, 1.1875         # amax 1.1875 -> scale 2^-8: 256, 272 (tie -> 256, even mantissa), 304 (tie -> 320)
+    codes, e8 = MX.quantize(x)
+    assert e8[:, 0].tolist() == [127, 128, 127 - 28, 0, 127 - 8]
+    assert codes[0, :3].tolist() == [0x7e, 0x38, 0xb0]
+    assert codes[1, :2].tolist() == [0x76, 0x30]
+    assert codes[2, 0].item() == 0x78 and codes[3].abs().sum().item() == 0
+    assert codes[4, :3].tolist() == [0x78, 0x78, 0x7a]
+    d = MX.dequantize(codes, e8)
+    assert d[0, :3].tolist() == [448.0, 1.0, -0.5] and d[1, 0].item() == 448.0 and d[2, 0].item() == 2.0 ** -20
+    # scale-byte order: role 0 = 48-row blocks, byte = 16-row fragment; role 1 = 64-row blocks in the B-row permutation
+    e = torch.arange(200 * 4, dtype=torch.int32).reshape(200, 4).remainder(250).to(torch.uint8)
+    a = MX.scale_layout(e, 0).reshape(1, -1, 4, 16, 4)
+    assert a.shape[1] == 8                                  # ceil(200 / 192) * 4 blocks
+    for row, kb in ((0, 0), (17, 3), (47, 1), (48, 2), (199, 0)):
+        assert a[0, row // 48, kb, (row % 48) % 16, (row % 48) // 16].item() == e[row, kb].item()
+    assert a[0, 4, 0, 8, 0].item() == 0x7f                  # rows past R keep the fill value (row 200 would sit here)
+    b = MX.scale_layout(e[:192], 1).reshape(1, 3, 4, 16, 4)
+    for row, kb in ((0, 0), (5, 1), (37, 2), (63, 3), (130, 0)):
+        rb = row % 64
+        t, x32 = rb // 32, rb % 32
+        assert b[0, row // 64, kb, (x32 // 8) * 4 + (x32 % 4), t * 2 + (x32 // 4) % 2].item() == e[row, kb].item()
