@@ -24,6 +24,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: ~2.5 PF dense)
+N_CUS = 256                    # compute units of one MI355X
 
 
 def flops_per_pair(cfg, L, workload):
@@ -271,18 +272,19 @@ def main():
 
         def aggregate(recs):
             agg = {}
-            for fl, ms, kd, by in recs:
-                e = agg.setdefault(kd, [0.0, 0.0, 0, 0.0])
+            for fl, ms, kd, by, cu in recs:
+                e = agg.setdefault(kd, [0.0, 0.0, 0, 0.0, 0.0])
                 e[0] += fl
                 e[1] += ms
                 e[2] += 1
                 e[3] += by
+                e[4] += ms * (cu if cu > 0 else N_CUS)      # CU-milliseconds the launches were planned for
             return agg
         agg_in, agg_iso = aggregate(passes['in_step']), aggregate(passes['isolated'])
         if os.environ.get('EGV_BENCH_SHAPES'):           # per (kernel kind, FLOPs) breakdown on stderr: which shapes run slow in-step
             for tag, recs in passes.items():
                 by = {}
-                for fl, ms, kd, _b in recs:
+                for fl, ms, kd, _b, _c in recs:
                     e = by.setdefault((kd, fl), [0.0, 0])
                     e[0] += ms
                     e[1] += 1
@@ -291,7 +293,7 @@ def main():
                           f"avg_us={ms / n * 1e3:8.1f} TF={fl * n / (ms * 1e-3) / 1e12 if ms else 0:7.1f}", file=sys.stderr)
         gemm_kinds = [k for k in agg_in if k < 20]
         dom = max(gemm_kinds, key=lambda k: agg_in[k][1])
-        fl, ms, n, alg_bytes = agg_in[dom]
+        fl, ms, n, alg_bytes, cu_ms = agg_in[dom]
         ach = fl / (ms * 1e-3) / 1e12
         iso = agg_iso.get(dom)
         ach_iso = iso[0] / (iso[1] * 1e-3) / 1e12 if iso and iso[1] else None
@@ -334,6 +336,10 @@ def main():
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "frac_in_step": round(ach / PEAK_BF16_TFLOPS, 4),
                 "frac_isolated": round(ach_iso / PEAK_BF16_TFLOPS, 4) if ach_iso else None,
+                # the backward's persistent grids are planned for the CUs the grouped weight-gradient launch leaves them (DESIGN.md
+                # 3.2): FLOPs over the MFMA peak of the CUs each launch was planned for, time-weighted
+                "frac_of_granted_cus_in_step": round(fl / (cu_ms * 1e-3 / N_CUS) / 1e12 / PEAK_BF16_TFLOPS, 4) if cu_ms else None,
+                "mean_cus_granted_in_step": round(cu_ms / ms, 1) if ms else None,
                 "measured": "HIP events around every launch of the kernel, on its stream, in a repeat of the timed steps: in_step = as timed (two-stream); "
                             "isolated = single-stream (EGV_NO_OVERLAP=1); frac = in_step",
                 "traffic": traffic, "mfma_busy_frac_rocprof": mfma_busy,

@@ -155,6 +155,7 @@ PROTOTYPES = {
     'egv_prof_reset': (i32, []),
     'egv_prof_collect': (i32, [C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int), i32]),
     'egv_prof_collect2': (i32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int), i32]),
+    'egv_prof_collect3': (i32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int), i32]),
 }
 
 

@@ -34,7 +34,7 @@ extern "C" int egv_stream_create(int priority, void** stream) {
 
 // ---- per-launch HIP-event timing of the GEMM kernels, on the stream they are launched on ----
 namespace {
-struct Rec { hipEvent_t a, b; double flops, bytes; int kind; };
+struct Rec { hipEvent_t a, b; double flops, bytes; int kind, cus; };
 std::mutex g_mu;
 bool g_on = false;
 std::vector<Rec> g_recs;
@@ -46,21 +46,25 @@ hipEvent_t get_event() {
 }  // namespace
 
 bool egv_prof_on() { return g_on; }
+// CUs a persistent launch was planned for (its grid): set by the launcher right before egv_prof_end picks it up
+thread_local int egv_prof_cus_hint = 0;
 
 void* egv_prof_begin(void* stream) {
     if (!g_on) return nullptr;
     std::lock_guard<std::mutex> lk(g_mu);
-    Rec r; r.a = get_event(); r.b = get_event(); r.flops = 0; r.bytes = 0; r.kind = 0;
+    Rec r; r.a = get_event(); r.b = get_event(); r.flops = 0; r.bytes = 0; r.kind = 0; r.cus = 0;
     hipEventRecord(r.a, reinterpret_cast<hipStream_t>(stream));
     g_recs.push_back(r);
     return reinterpret_cast<void*>(g_recs.size());      // 1-based handle
 }
 
 void egv_prof_end(void* handle, void* stream, double flops, int kind, double bytes) {
+    const int cus = egv_prof_cus_hint;
+    egv_prof_cus_hint = 0;
     if (!handle) return;
     std::lock_guard<std::mutex> lk(g_mu);
     Rec& r = g_recs[reinterpret_cast<size_t>(handle) - 1];
-    r.flops = flops; r.kind = kind; r.bytes = bytes;
+    r.flops = flops; r.kind = kind; r.bytes = bytes; r.cus = cus;
     hipEventRecord(r.b, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -73,11 +77,14 @@ extern "C" int egv_prof_reset(void) {
     return 0;
 }
 
-extern "C" int egv_prof_collect2(double* flops, double* bytes, float* ms, int* kind, int max_records);
+extern "C" int egv_prof_collect3(double* flops, double* bytes, float* ms, int* kind, int* cus, int max_records);
+extern "C" int egv_prof_collect2(double* flops, double* bytes, float* ms, int* kind, int max_records) {
+    return egv_prof_collect3(flops, bytes, ms, kind, nullptr, max_records);
+}
 extern "C" int egv_prof_collect(double* flops, float* ms, int* kind, int max_records) {
     return egv_prof_collect2(flops, nullptr, ms, kind, max_records);
 }
-extern "C" int egv_prof_collect2(double* flops, double* bytes, float* ms, int* kind, int max_records) {
+extern "C" int egv_prof_collect3(double* flops, double* bytes, float* ms, int* kind, int* cus, int max_records) {
     std::lock_guard<std::mutex> lk(g_mu);
     int n = 0;
     for (auto& r : g_recs) {
@@ -87,6 +94,7 @@ extern "C" int egv_prof_collect2(double* flops, double* bytes, float* ms, int* k
         hipEventElapsedTime(&t, r.a, r.b);
         flops[n] = r.flops; ms[n] = t; kind[n] = r.kind;
         if (bytes) bytes[n] = r.bytes;
+        if (cus) cus[n] = r.cus;
         ++n;
     }
     return n;

@@ -585,6 +585,7 @@ using namespace egv;
 // backward call whose weight gradients run as a persistent launch on a granted share of the chip (egv_gemm5.hip): a grid
 // planned for CUs it cannot get would run its surplus workgroups as a second, nearly empty round.
 static thread_local int g_cu_limit = 0;
+extern thread_local int egv_prof_cus_hint;     // egv_api.cpp: the grid of a persistent launch, for the per-launch profile records
 void egv_gemm_set_cu_limit(int n) { g_cu_limit = n; }
 
 // returns 1 if the persistent ping-pong kernel took the call
@@ -653,6 +654,7 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);                               \
             attr = true;                                                                                                 \
         }                                                                                                                \
+        egv_prof_cus_hint = grid;                                                                                        \
         hipLaunchKernelGGL((gemm_pp_kernel<X, P, AC>), dim3(grid), dim3(512), PP_LDS, st, g, ntiles);                    \
         return 1;                                                                                                        \
     } while (0)
@@ -666,6 +668,7 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);                               \
             attr = true;                                                                                                 \
         }                                                                                                                \
+        egv_prof_cus_hint = grid;                                                                                        \
         hipLaunchKernelGGL((gemm_pp_kernel<X, P, false, false, 3>), dim3(grid), dim3(512), PP_LDS, st, g, ntiles);       \
         return 1;                                                                                                        \
     } while (0)
@@ -752,6 +755,7 @@ extern "C" int egv_gemm_mx(int M, int N, int K, const void* Aq, const void* Asca
                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_MX);                              \
             attr = true;                                                                                                   \
         }                                                                                                                  \
+        egv_prof_cus_hint = grid;                                                                                          \
         hipLaunchKernelGGL((gemm_pp_kernel<X, P, AC, false, 3, true>), dim3(grid), dim3(512), PP_LDS_MX, st, g, ntiles);   \
     } while (0)
     if (res1) MX_LAUNCH(1, false, false);

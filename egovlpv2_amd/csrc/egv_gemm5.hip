@@ -187,6 +187,7 @@ __global__ __launch_bounds__(512) void gemm_wgrad_group_kernel(const WgGroup g) 
 }
 
 }  // namespace egv
+extern thread_local int egv_prof_cus_hint;     // egv_api.cpp
 using namespace egv;
 
 void* egv_prof_begin(void* stream);
@@ -317,6 +318,7 @@ extern "C" int egv_gemm_wgrad_grouped(int dtype, int M, int nprob, const egv_wgr
     if (gp.nslab > 0) (void)hipMemsetAsync(g.cnt, 0, (size_t)2 * ntile * 4, st);
     int nwg = 0;
     for (int i = 0; i < gp.nphase; ++i) nwg = gp.tiles[i] * gp.splits[i] > nwg ? gp.tiles[i] * gp.splits[i] : nwg;
+    egv_prof_cus_hint = nwg;
     hipLaunchKernelGGL(gemm_wgrad_group_kernel, dim3(nwg), dim3(512), W4_LDS, st, g);
     egv_prof_end(ph, stream, flops, 15, bytes);                    // 15 = grouped ping-pong weight gradient
     EGV_LAUNCH_CHECK();

@@ -1528,8 +1528,9 @@ def prof_collect(max_records: int = 1 << 16):
     by = (C.c_double * max_records)()
     ms = (C.c_float * max_records)()
     kd = (C.c_int * max_records)()
-    n = lib.egv_prof_collect2(fl, by, ms, kd, max_records)
-    return [(fl[i], ms[i], kd[i], by[i]) for i in range(n)]
+    cu = (C.c_int * max_records)()
+    n = lib.egv_prof_collect3(fl, by, ms, kd, cu, max_records)
+    return [(fl[i], ms[i], kd[i], by[i], cu[i]) for i in range(n)]
 
 
 def invalidate_weight_cache():

@@ -628,8 +628,34 @@ class FrozenInTime(nn.Module):
             self._prepare_weights()
             self.task_names = 'EgoNCE'
             text_data = data['text']
-            text_embeds_l, join_txt = self._fork_text(lambda: self.compute_text(text_data),
-                                                      uses=(text_data['input_ids'], text_data['attention_mask']))
+            # The unfused RoBERTa layers run three times per step on 256 token rows each (EgoNCE tower, MLM prefix, ITM prefix): every
+            # launch is latency-bound, so two passes of M = 256 cost twice what one pass of M = 512 costs.  The EgoNCE tower's first
+            # depth - n_fuse layers and the MLM pass's text prefix share weights and both inputs exist now: they run as ONE pass over
+            # the concatenated batch (per-sample results unchanged: every kernel is batch-independent; dropout masks are a function
+            # of (seed, element) and stay independent per element); the ITM prefix cannot join -- its batch is drawn from the EgoNCE
+            # similarities.  EGV_TEXT_BATCH=0 restores the separate passes.
+            pair_prefix = ('MLM' in task_names and want_itm and c.depth > c.n_fuse and not os.environ.get('EGV_NO_PREFIX_SHARING')
+                           and not self.text_fp32 and os.environ.get('EGV_TEXT_BATCH', '1') != '0'
+                           and data['text_mlm_ids'].shape == text_data['input_ids'].shape)
+            txt_mlm_pair = None
+            if pair_prefix:
+                def text_pair():
+                    ids, am = text_data['input_ids'], text_data['attention_mask']
+                    B, L = ids.shape
+                    mask2 = self._key_mask(torch.cat([am, am]))
+                    hid = self._text_embeddings(torch.cat([ids, data['text_mlm_ids']]), self._text_dtype())
+                    for i in range(c.depth - c.n_fuse):
+                        hid = self._text_layer(hid, mask2, i, 2 * B, L)
+                    he, hm, mask = hid[:B * L], hid[B * L:], mask2[:B]
+                    for i in range(c.depth - c.n_fuse, c.depth):
+                        he = self._text_layer(he, mask, i, B, L, exact=True)
+                    return self._proj_mlp(self._text_operand(self._cls_rows(he, B, L), exact_ok=True), 'txt_proj'), hm, mask
+                (text_embeds_l, hm_pair, mask_pair), join_txt = self._fork_text(
+                    text_pair, uses=(text_data['input_ids'], text_data['attention_mask'], data['text_mlm_ids']))
+                txt_mlm_pair = ((hm_pair, mask_pair), join_txt)
+            else:
+                text_embeds_l, join_txt = self._fork_text(lambda: self.compute_text(text_data),
+                                                          uses=(text_data['input_ids'], text_data['attention_mask']))
             feats = self._video_features(data['video'])
             rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else getattr(args, 'rank', 0)
             bsz = data['video'].size(0)
@@ -726,7 +752,8 @@ class FrozenInTime(nn.Module):
         data_mlm = data
         if share_prefix:
             am = data['text']['attention_mask']
-            txt_mlm = self._fork_text(lambda: self._text_prefix(data['text_mlm_ids'], am), uses=(data['text_mlm_ids'], am))
+            txt_mlm = txt_mlm_pair if ('EgoNCE' in task_names and txt_mlm_pair is not None) else \
+                self._fork_text(lambda: self._text_prefix(data['text_mlm_ids'], am), uses=(data['text_mlm_ids'], am))
             v_pre = self._video_prefix(data['video'])                       # overlaps the MLM text prefix
             data_mlm = dict(data, _video_prefix=v_pre, _text_prefix=txt_mlm)
 

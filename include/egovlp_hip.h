@@ -339,6 +339,8 @@ int egv_prof_reset(void);
 int egv_prof_collect(double* flops, float* ms, int* kind, int max_records);
 /* the same plus the algorithmic bytes of each launch (operands, output and epilogue operands once) */
 int egv_prof_collect2(double* flops, double* bytes, float* ms, int* kind, int max_records);
+/* ... and the number of workgroups (= CUs) each persistent launch was planned for (0 for non-persistent kernels) */
+int egv_prof_collect3(double* flops, double* bytes, float* ms, int* kind, int* cus, int max_records);
 
 #ifdef __cplusplus
 }

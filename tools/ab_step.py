@@ -13,7 +13,7 @@ from egovlpv2_amd.model.loss import EgoNCE
 from egovlpv2_amd.trainer.trainer_egoclip import AllGather_multi
 
 settings = [''] + [a for a in sys.argv[1:] if '=' in a]
-R, K = 6, 5
+R, K = int(os.environ.get("AB_ROUNDS", "6")), 5
 dev = torch.device('cuda', 0)
 cfg = PathConfig(frames=16, drop_rate=0.1)
 model = FrozenInTime({'model': 'SpaceTimeTransformer', 'num_frames': cfg.frames, 'pretrained': True}, {'model': 'roberta-base', 'pretrained': True, 'input': 'text'},

@@ -11,6 +11,7 @@ import sqlite3, sys, json, re, collections
 
 GROUPS = [('gemm_pp_kernel', r'gemm_pp_kernel'), ('gemm_ring_kernel<256x128>', r'gemm_ring_kernel<egv::Cfg<4, 2, 4, 4>'),
           ('gemm_ring_kernel<128x128>', r'gemm_ring_kernel<egv::Cfg<4, 2, 2, 4>'), ('gemm_wgrad_ring_kernel', r'gemm_wgrad_ring_kernel'), ('gemm_wgrad_pp_kernel', r'gemm_wgrad_pp_kernel'),
+          ('gemm_wgrad_group_kernel', r'gemm_wgrad_group_kernel'), ('attn time fwd/dq/dkv (17 keys)', r'attn_(fwd|dq|dkv)_mfma_kernel<2, 1, 0, 0>'),
           ('attn_fwd_mfma (space, 196+1 keys)', r'attn_fwd_mfma_kernel<14, 4, 0, 13>'), ('attn_dq_mfma (space)', r'attn_dq_mfma_kernel<14, 4, 0, 0>'),
           ('attn_dkv_mfma (space)', r'attn_dkv_mfma_kernel<14, 4, 0, 0>'), ('attn_bwd_fused (space: dQ+dK+dV)', r'attn_bwd_fused_kernel'),
           ('layernorm_fwd', r'layernorm_fwd_kernel'), ('layernorm_bwd', r'layernorm_bwd(_bf16)?_kernel'), ('reduce_slabs', r'reduce_slabs_kernel')]
