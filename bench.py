@@ -300,7 +300,7 @@ def main():
         # HBM traffic and MFMA-busy counters of the dominant kernel are NOT measured in this run: they come from rocprofv3 --pmc
         # passes over this script (in-step, separate passes per counter group, gfx950 FETCH_SIZE correction) that were summarised by
         # tools/pmc_instep.py into a committed file; `source` says which
-        traffic = mfma_busy = launches_per_step = None
+        traffic = mfma_busy = launches_per_step = trace_avg_us = None
         pmc_file = None
         for cand in ('round3_pmc_instep.json', 'round2_pmc_instep.json'):
             if os.path.exists(os.path.join(REPO, 'profiles', cand)):
@@ -314,6 +314,7 @@ def main():
                 traffic['algorithmic_bytes_per_launch'] = round(alg_bytes / n)
                 traffic['source'] = f'profiles/{pmc_file} (committed rocprofv3 --pmc passes over this script; not re-measured in this run)'
                 mfma_busy = ent.get('mfma_busy_frac')
+                trace_avg_us = ent.get('avg_us')
             launches_per_step = pm.get('launches_per_step')
         except Exception:
             pass
@@ -344,6 +345,10 @@ def main():
                             "isolated = single-stream (EGV_NO_OVERLAP=1); frac = in_step",
                 "traffic": traffic, "mfma_busy_frac_rocprof": mfma_busy,
                 "kernel": kinds.get(dom, str(dom)), "launches": n, "avg_launch_ms": round(ms / n, 4),
+                # the same kernel's average duration in the committed rocprofv3 kernel trace of this command (two-stream step).  The HIP
+                # events of this run bracket dispatch latency as well (a few microseconds per launch), so avg_launch_ms reads higher
+                "avg_launch_ms_rocprof": round(trace_avg_us / 1e3, 4) if trace_avg_us else None,
+                "frac_in_step_rocprof": round(fl / n / (trace_avg_us * 1e-6) / 1e12 / PEAK_BF16_TFLOPS, 4) if trace_avg_us else None,
                 "all_gemm": tf_table(agg_in), "all_gemm_isolated": tf_table(agg_iso),
                 "gemm_ms_per_step": round(sum(agg_in[k][1] for k in gemm_kinds) / a.steps, 2),
                 "hbm_bound_classes": hbm,

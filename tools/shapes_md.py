@@ -5,7 +5,9 @@ import sys
 
 KIND = {0: 'gemm_kernel bf16 NT', 1: 'gemm_kernel bf16 NN', 4: 'gemm_kernel fp32', 5: 'gemm_kernel fp32 NN', 8: 'gemm_ring_kernel<256x128>',
         12: 'gemm_pp_kernel (persistent, fwd+dgrad)', 13: 'gemm_ring_kernel<128x128>', 14: 'gemm_wgrad_pp_kernel (one gradient per launch)',
-        15: 'gemm_wgrad_group_kernel (all gradients of a block call)', 16: 'gemm_pp_kernel MX-fp8'}
+        15: 'gemm_wgrad_group_kernel (all gradients of a block call)', 16: 'gemm_pp_kernel MX-fp8',
+        2: 'gemm_kernel bf16 TN', 10: 'gemm_wgrad_ring_kernel', 20: 'attention forward (not a GEMM: GFLOP = QK^T + PV)', 21: 'attention dQ', 22: 'attention dK/dV',
+        23: 'attention one-pass backward (space)', 30: 'layernorm forward (HBM-bound)', 31: 'layernorm backward (HBM-bound)', 32: 'quant_mx (HBM-bound)'}
 rows = {}
 for line in open(sys.argv[1]):
     m = re.match(r'shape\[(\w+)\] kind=(\d+) gflop=\s*([\d.]+) n/step=\s*([\d.]+) ms/step=\s*([\d.]+) avg_us=\s*([\d.]+) TF=\s*([\d.]+)', line)
