@@ -84,6 +84,7 @@ class WgradProblem(C.Structure):
 BLOCK_NO_JOIN = 1
 BLOCK_RES_F32 = 2
 BLOCK_FP8 = 4
+BLOCK_TAIL = 8
 
 
 # name -> (restype, argtypes); every symbol declared in include/egovlp_hip.h

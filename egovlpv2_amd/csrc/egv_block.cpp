@@ -582,7 +582,8 @@ extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
     // dx = LN3'(dh3) + d_sr + d_tr: x feeds norm3, the time residual and the space residual
     BCHK(egv_layernorm_bwd2(dt, dh3, d->x, (const float*)(sv + L.stats3), d->ln_g[VL_NORM3], d_sr, d_tr, d->dx, d->dln_g[VL_NORM3],
                             d->dln_b[VL_NORM3], M, D, lnw, st));
-    if (ngrp) BCHK(egv_gemm_wgrad_grouped(dt, M, ngrp, grp, side_group ? vgroup_cus(d) : (device_cus() * 7) / 8, wgw, wgb, fk.begin()));
+    const bool tail = side_group && (d->flags & EGV_BLOCK_TAIL);      // no data-gradient chain follows: the launch may have the chip
+    if (ngrp) BCHK(egv_gemm_wgrad_grouped(dt, M, ngrp, grp, (side_group && !tail) ? vgroup_cus(d) : (device_cus() * 7) / 8, wgw, wgb, fk.begin()));
     if (!side_group) fk.join();
     return 0;
 }

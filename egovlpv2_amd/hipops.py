@@ -1088,11 +1088,17 @@ def _acc_backward(key, pack, params, nshared, side=None):
 def begin_step(param_ids=None):
     """forget gradient bookkeeping of an aborted step (called at the top of FrozenInTime.forward).  param_ids: ids of the
     calling model's parameters -- only its blocks are forgotten; None: everything."""
+    _first_vblock[0] = True
     if param_ids is None:
         _acc.clear()
         return
     for k in [k for k in _acc if k[0][1] in param_ids]:
         del _acc[k]
+
+
+# the first video block call a step creates is the last one its backward pass runs (the engine runs nodes in reverse creation order):
+# nothing but the patch-embedding gradient follows it on the calling stream, so its grouped weight-gradient launch may take the chip
+_first_vblock = [False]
 
 
 def _tracks_grad(params):
@@ -1158,6 +1164,9 @@ class VideoBlockFn(Function):
         check(lib.egv_vblock_fwd(C.byref(d)), 'egv_vblock_fwd')
         ctx.cfg = cfg
         ctx.key = ('v', id(params[0]))
+        ctx.tail = bool(cfg[7] and _first_vblock[0] and os.environ.get('EGV_WGRAD_TAIL', '1') != '0')
+        if cfg[7]:
+            _first_vblock[0] = False
         _acc_forward(ctx.key, cfg[7], cfg[6] > 0)
         ctx.save_for_backward(x, y, y_mask, save, *params)
         return out
@@ -1193,7 +1202,7 @@ class VideoBlockFn(Function):
             # the grouped weight-gradient launch of this call keeps running on the companion stream after the call returns:
             # everything it reads or writes must outlive it in the caching allocator, and the calling stream is joined at the
             # end of the backward pass (_backward_done)
-            d.flags |= L.BLOCK_NO_JOIN
+            d.flags |= L.BLOCK_NO_JOIN | (L.BLOCK_TAIL if ctx.tail else 0)
             for t in (ws, save, dout, gp.flat, y):
                 if t is not None:
                     t.record_stream(side[0])

@@ -267,6 +267,8 @@ int egv_adamw_step(const void* table, const int* prefix, int ntensors, int nchun
 #define EGV_BLOCK_RES_F32 2
       /* egv_tlayer_*: hid / out / dout / dhid are fp32 (the text tower's fp32 residual stream), dtype = EGV_BF16 */
 #define EGV_BLOCK_FP8 4       /* egv_vblock_*: MX-fp8 forward / dgrad GEMMs where the desc carries quantised weights */
+#define EGV_BLOCK_TAIL 8      /* egv_vblock_bwd with EGV_BLOCK_NO_JOIN: nothing but the join follows this call on the calling stream (the last block of a
+                                 backward pass): its grouped weight-gradient launch gets 7/8 of the CUs instead of its share */
 typedef struct egv_vblock_desc {
     int dtype, B, F, N, H, D, Hd, L;
     float eps;
