@@ -45,6 +45,23 @@ def test_attn_desc_layout_matches_c(tmp_path):
     assert got == want
 
 
+def test_block_desc_layouts_match_c(tmp_path):
+    """the block descriptors (egv_vblock_desc / egv_tlayer_desc, ABI version 4: flags + MX-fp8 weight pointers, merged projections) and
+    the grouped weight-gradient problem record: sizeof and the offsets of the fields added last, C against the ctypes mirrors"""
+    from egovlpv2_amd._lib import VBlockDesc, TLayerDesc, WgradProblem
+    src = tmp_path / 'b.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "egovlp_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+                   'sizeof(egv_vblock_desc), offsetof(egv_vblock_desc, flags), offsetof(egv_vblock_desc, wq), offsetof(egv_vblock_desc, wtq_s),'
+                   'sizeof(egv_tlayer_desc), offsetof(egv_tlayer_desc, flags), offsetof(egv_tlayer_desc, w_qkv), offsetof(egv_tlayer_desc, b_ckv),'
+                   'sizeof(egv_wgrad_problem));return 0;}\n')
+    exe = tmp_path / 'b'
+    subprocess.check_call(['gcc', '-I', os.path.join(REPO, 'include'), str(src), '-o', str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [ctypes.sizeof(VBlockDesc), VBlockDesc.flags.offset, VBlockDesc.wq.offset, VBlockDesc.wtq_s.offset,
+            ctypes.sizeof(TLayerDesc), TLayerDesc.flags.offset, TLayerDesc.w_qkv.offset, TLayerDesc.b_ckv.offset, ctypes.sizeof(WgradProblem)]
+    assert got == want
+
+
 def test_state_dict_surface_matches_reference():
     from egovlpv2_amd.model.model import FrozenInTime
     from egovlpv2_amd.config import tiny_config
