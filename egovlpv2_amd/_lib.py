@@ -113,10 +113,11 @@ PROTOTYPES = {
     'egv_cast_weights': (i32, [vp, vp, i32, i32, vp]),
     'egv_cast_weights_ld': (i32, [vp, vp, i32, i32, vp]),
     'egv_copy_segments': (i32, [vp, i32, vp]),
+    'egv_layernorm_fwd_mx': (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     'egv_mx_scale_bytes': (i64, [i32, i32, i32]),
     'egv_quant_mx': (i32, [vp, i32, i32, i32, vp, vp, i32, vp]),
     'egv_quant_mx_batch': (i32, [vp, vp, i32, i32, vp]),
-    'egv_gemm_mx': (i32, [i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp]),
+    'egv_gemm_mx': (i32, [i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp]),
     'egv_stream_create': (i32, [i32, C.POINTER(vp)]),
     'egv_attn_split_workspace_bytes': (i64, [i32, i32, i32, i32, i32, i32]),
     'egv_attn_fwd': (i32, [i32, C.POINTER(AttnDesc), vp]),

@@ -292,7 +292,9 @@ size_t vfp8_ws_bytes(const egv_vblock_desc* d) {
     if (!vfp8_on(d)) return 0;
     const long long M = (long long)d->B * (1 + (long long)d->F * d->N);
     const int Kmax = d->Hd > 3 * d->D ? d->Hd : 3 * d->D;
-    return al((size_t)M * Kmax) + al((size_t)egv_mx_scale_bytes((int)M, Kmax, 0)) + 4096;
+    // + a second operand: the MX-fp8 form of the MLP's hidden activation / its gradient, written by the producing GEMM's epilogue
+    return al((size_t)M * Kmax) + al((size_t)egv_mx_scale_bytes((int)M, Kmax, 0)) + al((size_t)M * d->Hd) +
+           al((size_t)egv_mx_scale_bytes((int)M, d->Hd, 0)) + 8192;
 }
 struct Fp8 {                                     // quantise-then-GEMM for one block call
     bool on;
@@ -300,11 +302,23 @@ struct Fp8 {                                     // quantise-then-GEMM for one b
     void* q;
     void* s;
     void* st;
+    void* q2 = nullptr;                          // second operand buffer (codes / scales of an [M, Hd] tensor written by a GEMM epilogue)
+    void* s2 = nullptr;
     // y = epi(x W^T): x bf16 [M, K] -> MX codes, then the block-scaled GEMM on (wq, wq_s) [N, K]
     int lin(int N, int K, const void* x, const void* wq, const void* wq_s, const float* b, void* y, int act, const void* r1, void* pre,
             const void* aux, int dact) const {
         if (egv_quant_mx(x, M, K, K, q, s, 0, st)) return -1;
-        return egv_gemm_mx(M, N, K, q, s, wq, wq_s, y, N, b, act, r1, pre, aux, dact, N, st);
+        return egv_gemm_mx(M, N, K, q, s, wq, wq_s, y, N, b, act, r1, pre, aux, dact, N, nullptr, nullptr, st);
+    }
+    // the same, and the output also lands in (q2, s2) in MX-fp8 form (GELU + saved pre-activation, or GELU' epilogue)
+    int lin_qout(int N, int K, const void* x, bool x_is_quantised, const void* wq, const void* wq_s, const float* b, void* y, int act, void* pre,
+                 const void* aux, int dact) const {
+        if (!x_is_quantised && egv_quant_mx(x, M, K, K, q, s, 0, st)) return -1;
+        return egv_gemm_mx(M, N, K, q, s, wq, wq_s, y, N, b, act, nullptr, pre, aux, dact, N, q2, s2, st);
+    }
+    // a Linear whose A operand already sits in (q2, s2)
+    int lin_from_q2(int N, int K, const void* wq, const void* wq_s, const float* b, void* y, const void* r1) const {
+        return egv_gemm_mx(M, N, K, q2, s2, wq, wq_s, y, N, b, 0, r1, nullptr, nullptr, 0, N, nullptr, nullptr, st);
     }
 };
 
@@ -414,22 +428,37 @@ extern "C" int egv_vblock_fwd(const egv_vblock_desc* d) {
         const int Kmax = Hd > 3 * D ? Hd : 3 * D;
         f8.q = ws.take((size_t)M * Kmax);
         f8.s = ws.take((size_t)egv_mx_scale_bytes(M, Kmax, 0));
+        f8.q2 = ws.take((size_t)M * Hd);
+        f8.s2 = ws.take((size_t)egv_mx_scale_bytes(M, Hd, 0));
     }
     if (!ws.ok()) { egv_set_error("egv_vblock_fwd: workspace too small"); return -1; }
+    static const bool epi_q = !getenv("EGV_MX_EPI_QUANT") || atoi(getenv("EGV_MX_EPI_QUANT")) != 0;
+    const bool mlp_chain = epi_q && f8.on && d->wq[VW_FC1] && d->wq_s[VW_FC1] && d->wq[VW_FC2] && d->wq_s[VW_FC2];
     // one Linear over the M video tokens: MX-fp8 when the desc carries the quantised weight, bf16 otherwise
     auto lin = [&](int w, int N, int K, const void* x, void* y, int act, const void* r1, void* pre) -> int {
         if (f8.on && d->wq[w] && d->wq_s[w]) return f8.lin(N, K, x, d->wq[w], d->wq_s[w], d->b[w], y, act, r1, pre, nullptr, 0);
         return lin_fwd(dt, M, N, K, x, d->w[w], d->b[w], y, act, nullptr, r1, nullptr, pre, st);
     };
+    // LayerNorm followed by a Linear on its output: in the MX-fp8 mode the LayerNorm kernel writes the quantised operand itself
+    // (the same codes and scales egv_quant_mx would produce from h), so the Linear needs no quantiser launch
+    auto ln_lin = [&](int ln, const void* xin, void* h, float* stats, int w, int N, int K, void* y, int act, void* pre) -> int {
+        static const bool ln_mx = !getenv("EGV_LN_MX") || atoi(getenv("EGV_LN_MX")) != 0;
+        if (ln_mx && f8.on && d->wq[w] && d->wq_s[w] && K == D) {
+            if (egv_layernorm_fwd_mx(xin, h, d->ln_g[ln], d->ln_b[ln], stats, f8.q, f8.s, M, D, d->eps, st)) return -1;
+            if (w == VW_FC1 && mlp_chain)       // fc1's GELU epilogue also writes the MX-fp8 form of the activation: fc2's operand
+                return egv_gemm_mx(M, N, K, f8.q, f8.s, d->wq[w], d->wq_s[w], y, N, d->b[w], act, nullptr, pre, nullptr, 0, N, f8.q2, f8.s2, st);
+            return egv_gemm_mx(M, N, K, f8.q, f8.s, d->wq[w], d->wq_s[w], y, N, d->b[w], act, nullptr, pre, nullptr, 0, N, nullptr, nullptr, st);
+        }
+        if (egv_layernorm_fwd(dt, xin, h, d->ln_g[ln], d->ln_b[ln], stats, M, D, d->eps, st)) return -1;
+        return lin(w, N, K, h, y, act, nullptr, pre);
+    };
 
     // temporal attention (video_transformer.py:217-218): x + proj(attn(qkv(norm3 x)))
-    BCHK(egv_layernorm_fwd(dt, d->x, sv + L.h3, d->ln_g[VL_NORM3], d->ln_b[VL_NORM3], (float*)(sv + L.stats3), M, D, d->eps, st));
-    BCHK(lin(VW_TQKV, 3 * D, D, sv + L.h3, sv + L.qkv_t, 0, nullptr, nullptr));
+    BCHK(ln_lin(VL_NORM3, d->x, sv + L.h3, (float*)(sv + L.stats3), VW_TQKV, 3 * D, D, sv + L.qkv_t, 0, nullptr));
     BCHK(dvt.fwd(sv + L.qkv_t, sv + L.tctx, (float*)(sv + L.lse_t), aws, awb, st));
     BCHK(lin(VW_TPROJ, D, D, sv + L.tctx, sv + L.tr, 0, d->x, nullptr));
     // spatial attention (:219-222): residual from x, not from the time residual
-    BCHK(egv_layernorm_fwd(dt, sv + L.tr, sv + L.h1, d->ln_g[VL_NORM1], d->ln_b[VL_NORM1], (float*)(sv + L.stats1), M, D, d->eps, st));
-    BCHK(lin(VW_SQKV, 3 * D, D, sv + L.h1, sv + L.qkv_s, 0, nullptr, nullptr));
+    BCHK(ln_lin(VL_NORM1, sv + L.tr, sv + L.h1, (float*)(sv + L.stats1), VW_SQKV, 3 * D, D, sv + L.qkv_s, 0, nullptr));
     BCHK(dvs.fwd(sv + L.qkv_s, sv + L.sctx, (float*)(sv + L.lse_s), aws, awb, st));
     if (!fused) {
         BCHK(lin(VW_SPROJ, D, D, sv + L.sctx, sv + L.sr, 0, d->x, nullptr));
@@ -438,15 +467,14 @@ extern "C" int egv_vblock_fwd(const egv_vblock_desc* d) {
         const int BL = d->B * d->L;
         BCHK(lin(VW_SPROJ, D, D, sv + L.sctx, sv + L.s, 0, nullptr, nullptr));
         BCHK(lin_fwd(dt, BL, 2 * D, D, d->y, d->w[VW_KV_I2T], d->b[VW_KV_I2T], sv + L.kv, 0, nullptr, nullptr, nullptr, nullptr, st));
-        BCHK(egv_layernorm_fwd(dt, sv + L.s, sv + L.hs, d->ln_g[VL_NORM_I2T], d->ln_b[VL_NORM_I2T], (float*)(sv + L.stats_i), M, D, d->eps, st));
-        BCHK(lin(VW_Q_I2T, D, D, sv + L.hs, sv + L.q, 0, nullptr, nullptr));
+        BCHK(ln_lin(VL_NORM_I2T, sv + L.s, sv + L.hs, (float*)(sv + L.stats_i), VW_Q_I2T, D, D, sv + L.q, 0, nullptr));
         BCHK(px.fwd(sv + L.q, D, sv + L.kv, at(sv + L.kv, (size_t)D * esz(dt)), 2 * D, sv + L.o, (float*)(sv + L.lse_x), aws, awb, st));
         BCHK(lin_fwd(dt, M, D, D, sv + L.o, d->w[VW_PROJ_I2T], d->b[VW_PROJ_I2T], sv + L.sr, 0, d->alpha, sv + L.s, d->x, sv + L.pg, st));
     }
     // MLP (:226): sr + fc2(gelu(fc1(norm2 sr)))
-    BCHK(egv_layernorm_fwd(dt, sv + L.sr, sv + L.h2, d->ln_g[VL_NORM2], d->ln_b[VL_NORM2], (float*)(sv + L.stats2), M, D, d->eps, st));
-    BCHK(lin(VW_FC1, Hd, D, sv + L.h2, sv + L.act, EGV_ACT_GELU, nullptr, sv + L.pre));
-    BCHK(lin(VW_FC2, D, Hd, sv + L.act, d->out, 0, sv + L.sr, nullptr));
+    BCHK(ln_lin(VL_NORM2, sv + L.sr, sv + L.h2, (float*)(sv + L.stats2), VW_FC1, Hd, D, sv + L.act, EGV_ACT_GELU, sv + L.pre));
+    if (mlp_chain) BCHK(f8.lin_from_q2(D, Hd, d->wq[VW_FC2], d->wq_s[VW_FC2], d->b[VW_FC2], d->out, sv + L.sr));
+    else BCHK(lin(VW_FC2, D, Hd, sv + L.act, d->out, 0, sv + L.sr, nullptr));
     return 0;
 }
 
@@ -508,8 +536,12 @@ extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
         const int Kmax = Hd > 3 * D ? Hd : 3 * D;
         f8.q = ws.take((size_t)M * Kmax);
         f8.s = ws.take((size_t)egv_mx_scale_bytes(M, Kmax, 0));
+        f8.q2 = ws.take((size_t)M * Hd);
+        f8.s2 = ws.take((size_t)egv_mx_scale_bytes(M, Hd, 0));
     }
     if (!ws.ok()) { egv_set_error("egv_vblock_bwd: workspace too small (%zu > %zu)", ws.off, ws.cap); return -1; }
+    static const bool epi_q = !getenv("EGV_MX_EPI_QUANT") || atoi(getenv("EGV_MX_EPI_QUANT")) != 0;
+    const bool mlp_chain = epi_q && f8.on && d->wtq[VW_FC1] && d->wtq_s[VW_FC1] && d->wtq[VW_FC2] && d->wtq_s[VW_FC2];
     // dx[M,K] = (dz[M,N] W[N,K]) * act'(aux) over the M video tokens: MX-fp8 on the quantised transposed weight when the desc
     // carries it (the output gradient is quantised along N, the contraction), bf16 otherwise
     auto dgrad = [&](int w, int N, int K, const void* dz, void* dx, const void* aux, int dact) -> int {
@@ -542,9 +574,17 @@ extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
 
     // ---- MLP: out = sr + fc2(gelu(pre)), pre = fc1(h2)
     BCHK(wgrad(D, Hd, d->dout, sv + L.act, VW_FC2, nullptr, M));
-    BCHK(dgrad(VW_FC2, D, Hd, d->dout, dpre, sv + L.pre, EGV_ACT_GELU));
-    BCHK(wgrad(Hd, D, dpre, sv + L.h2, VW_FC1, nullptr, M));
-    BCHK(dgrad(VW_FC1, Hd, D, dpre, dh2, nullptr, 0));
+    if (mlp_chain) {
+        // fc2's data gradient writes dpre = (dout W2) * gelu'(pre) in bf16 (the weight gradient of fc1 reads it) AND in MX-fp8 form:
+        // the operand of fc1's data gradient, without a quantiser launch
+        BCHK(f8.lin_qout(Hd, D, d->dout, false, d->wtq[VW_FC2], d->wtq_s[VW_FC2], nullptr, dpre, 0, nullptr, sv + L.pre, EGV_ACT_GELU));
+        BCHK(wgrad(Hd, D, dpre, sv + L.h2, VW_FC1, nullptr, M));
+        BCHK(f8.lin_from_q2(D, Hd, d->wtq[VW_FC1], d->wtq_s[VW_FC1], nullptr, dh2, nullptr));
+    } else {
+        BCHK(dgrad(VW_FC2, D, Hd, d->dout, dpre, sv + L.pre, EGV_ACT_GELU));
+        BCHK(wgrad(Hd, D, dpre, sv + L.h2, VW_FC1, nullptr, M));
+        BCHK(dgrad(VW_FC1, Hd, D, dpre, dh2, nullptr, 0));
+    }
     // d_sr = LN2'(dh2) + dout (skip path of the MLP residual)
     BCHK(egv_layernorm_bwd2(dt, dh2, sv + L.sr, (const float*)(sv + L.stats2), d->ln_g[VL_NORM2], d->dout, nullptr, d_sr, d->dln_g[VL_NORM2],
                             d->dln_b[VL_NORM2], M, D, lnw, st));

@@ -15,6 +15,8 @@ struct GemmEpi {
     int dact;            // 0 none, 1 gelu'(aux = pre-activation), 2 relu'(aux = output), 3 tanh'(aux = output)
     int ldr;             // leading dim of res1/res2/pre/aux
     float scale;         // host scalar applied to the accumulator first
+    unsigned char* oq = nullptr;   // MX-fp8 form only: the output also as e4m3 codes [M][N] ...
+    unsigned char* os = nullptr;   // ... and role-0 scale bytes (egv_mx.hip)
 };
 
 struct GemmArgs {

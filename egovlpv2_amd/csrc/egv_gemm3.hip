@@ -59,27 +59,27 @@ __device__ __forceinline__ PPTile pp_tile(int t, int tiles_n, int bm) {
 // decides the count of the phase's s_waitcnt.
 enum { PP_PLAIN = 0, PP_LAST = 1, PP_FIRST_CHAIN = 2, PP_FIRST_COLD = 3, PP_SECOND_CHAIN = 4, PP_SECOND_COLD = 5 };
 
-// extra vector-memory operations issued in phase p of a K-tile of kind `kind` (NSQ stores per quadrant of a deferred epilogue,
+// extra vector-memory operations issued in phase p of a K-tile of kind `kind` (NSP stores per pair of quadrants of a deferred epilogue,
 // 1 bias DMA per tile); with a BULK epilogue (residual / GELU' operand kinds) the tile's NST stores are issued between the
 // last K-tile and the next tile's first one
 // (MX-fp8 form: + the K-tile's scale DMA, issued in phase 3 right BEFORE that phase's unit)
-__host__ __device__ constexpr int pp_extra(int kind, int p, int NSQ, bool bulk, bool mx = false) {
+__host__ __device__ constexpr int pp_extra(int kind, int p, int NSP, bool bulk, bool mx = false) {
     const int s = (mx && p == 3) ? 1 : 0;
     if (kind == PP_LAST) return s + (p == 1 ? 1 : 0);
-    if (kind == PP_FIRST_CHAIN && !bulk) return s + ((p & 1) ? 0 : 2 * NSQ);
+    if (kind == PP_FIRST_CHAIN && !bulk) return s + ((p & 1) ? 0 : NSP);
     return s;
 }
 __host__ __device__ constexpr int pp_prev_kind(int kind) {
     return kind == PP_FIRST_CHAIN ? PP_LAST : kind == PP_SECOND_CHAIN ? PP_FIRST_CHAIN : kind == PP_SECOND_COLD ? PP_FIRST_COLD : PP_PLAIN;
 }
 // operations younger than the unit staged 4 phases ago, at the wait of phase p: the DMAs of the last 4 phases + the extras
-__host__ __device__ constexpr int pp_nwait(int kind, int p, int NSQ, bool bulk, bool mx = false) {
+__host__ __device__ constexpr int pp_nwait(int kind, int p, int NSP, bool bulk, bool mx = false) {
     int n = 8;
-    for (int q = 0; q <= p; ++q) n += pp_extra(kind, q, NSQ, bulk, mx);
+    for (int q = 0; q <= p; ++q) n += pp_extra(kind, q, NSP, bulk, mx);
     if (kind != PP_FIRST_COLD)                      // before a cold first K-tile there is only the prologue (nothing younger)
-        for (int q = p + 1; q < 4; ++q) n += pp_extra(pp_prev_kind(kind), q, NSQ, bulk, mx);
+        for (int q = p + 1; q < 4; ++q) n += pp_extra(pp_prev_kind(kind), q, NSP, bulk, mx);
     else if (mx && p < 3) n += 1;                   // ... except the prologue's scale DMA of K-tile 1, issued where a phase 3 would have
-    if (kind == PP_FIRST_CHAIN && bulk) n += 4 * NSQ;  // the previous tile's bulk epilogue (all of its stores) sits between the tiles
+    if (kind == PP_FIRST_CHAIN && bulk) n += 2 * NSP;  // the previous tile's bulk epilogue (all of its stores) sits between the tiles
     return n;
 }
 
@@ -95,13 +95,20 @@ __host__ __device__ constexpr int pp_nwait(int kind, int p, int NSQ, bool bulk, 
 //         registers 4-7 of lane group fg: exactly the two 16-byte chunks a lane reads for the two bf16 K-halves), half as many
 //         MFMAs of twice the length, twice the flops per staged byte; block scales arrive by one 256-byte LDS-DMA per wave and
 //         K-tile (4-deep ring) and are read as one dword per lane and sub-tile
-template <int X1K, bool PREK, bool ACTK, bool STAMPS = false, int IM = 4, bool MX = false>
+//   QOUT: (MX only) the output is ALSO written in MX-fp8 form -- codes e.oq[M][N] and role-0 scale bytes e.os, quantised from the
+//         bf16-rounded values exactly as egv_quant_mx would quantise C: it is the A operand of the next Linear (fc1 -> fc2 forward,
+//         fc2 -> fc1 data gradient), whose quantiser launch disappears.  A 32-column block of a row is the 8 columns of the four
+//         lanes fr, fr + 16, fr + 32, fr + 48
+template <int X1K, bool PREK, bool ACTK, bool STAMPS = false, int IM = 4, bool MX = false, bool QOUT = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntiles) {
+    static_assert(!QOUT || MX, "quantised output only in the MX-fp8 form");
     static_assert(IM == 4 || IM == 3, "A sub-tile of 4 or 3 fragments");
     static_assert(!MX || IM == 3, "MX-fp8 form: 192-row tiles only (48-row scale blocks; the 256-row form does not fit 256 registers)");
     constexpr unsigned int ES = MX ? 1u : 2u;                      // bytes per operand element
     constexpr int BM = IM * 64, WM = IM * 32, SM = IM * 16;        // tile rows, rows per wave row, rows per A sub-tile and wave row
-    constexpr int NSQ = PREK ? 2 * IM : IM;
+    // stores per pair of quadrants (one pair_epilogue call): 2 (4 with the saved pre-activation) per 16-row fragment, + 2 code stores
+    // and 1 scale store when the output is also emitted in MX-fp8 form
+    constexpr int NSP = (PREK ? 4 : 2) * IM + (QOUT ? 3 * IM : 0);
     constexpr bool BULK = X1K != 0;                                // residual / GELU' operand: epilogue in one piece at the tile's end
     constexpr unsigned int OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -243,6 +250,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
     const __amdgpu_buffer_rsrc_t rs_x = mk((X1K == 1 || X1K == 3) ? e.res1 : e.aux, (long long)g.M * e.ldr * 2);
     const __amdgpu_buffer_rsrc_t rs_x2 = mk(X1K == 3 ? e.res2 : nullptr, (long long)g.M * e.ldr * 2);
     const __amdgpu_buffer_rsrc_t rs_bias = mk(e.bias, (long long)g.N * 4);
+    const __amdgpu_buffer_rsrc_t rs_q = mk(QOUT ? e.oq : nullptr, (long long)g.M * g.N);
+    const __amdgpu_buffer_rsrc_t rs_s = mk(QOUT ? e.os : nullptr, (long long)(g.N >> 7) * (((g.M + 191) / 192) * 4) * 256);
     const float gate = e.gate ? *e.gate : 1.0f;
 
     // quadrant q (= the phase that computes it): (s, t) = (0,0) (0,1) (1,1) (1,0)
@@ -383,6 +392,50 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                 }
                 o[t] = u32x4_t{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
             }
+            if constexpr (QOUT) {
+                const int l = opaque_lane();
+                const int fr_ = l & 15, fg_ = l >> 4;
+                const int row = tl.m0 + wr * WM + s * SM + i * 16 + fr_;
+                const int col = tl.n0 + wc * 64 + fg_ * 8;                     // + t * 32
+                int e8[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float r[8], amax = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        r[2 * k] = __uint_as_float(o[t][k] << 16);
+                        r[2 * k + 1] = __uint_as_float(o[t][k] & 0xffff0000u);
+                        amax = fmaxf(amax, fmaxf(fabsf(r[2 * k]), fabsf(r[2 * k + 1])));
+                    }
+                    amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+                    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+                    const unsigned int bits = __float_as_uint(amax);
+                    int e = (int)(bits >> 23) - 8 + ((bits & 0x7fffffu) > 0x600000u ? 1 : 0);
+                    e = e < 0 ? 0 : (e > 254 ? 254 : e);
+                    e8[t] = e;
+                    u32x2_t c2;
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        float a4[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) a4[k] = fminf(fmaxf(__builtin_amdgcn_ldexpf(r[h2 * 4 + k], 127 - e), -448.f), 448.f);
+                        int pk = __builtin_amdgcn_cvt_pk_fp8_f32(a4[0], a4[1], 0, false);
+                        pk = __builtin_amdgcn_cvt_pk_fp8_f32(a4[2], a4[3], pk, true);
+                        c2[h2] = (unsigned int)pk;
+                    }
+                    const unsigned int qoff = (row < g.M && col < g.N) ? (unsigned int)(row * g.N + col + t * 32) : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b64(c2, rs_q, qoff, 0, 0);
+                }
+                {   // scale bytes: lanes fg = 0 / 1 write the block of t = 0 / 1 (one store instruction)
+                    const int kb = ((tl.n0 + wc * 64) >> 5) + fg_;
+                    const int blk = row / 48, rb = row - blk * 48, nblk = ((g.M + 191) / 192) * 4;
+                    const bool on = fg_ < 2 && row < g.M && tl.n0 + wc * 64 < g.N;
+                    const unsigned int so = (unsigned int)((((kb >> 2) * nblk + blk) * 4 + (kb & 3)) * 64 + (rb & 15) * 4 + (rb >> 4));
+                    // (a buffer store with an out-of-range offset for the lanes that have nothing to write: the number of vector-memory
+                    // instructions per epilogue must not depend on the data -- the counted waits rely on it)
+                    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(fg_ == 0 ? e8[0] : e8[1]), rs_s, on ? so : OOB, 0, 0);
+                }
+            }
             pair_swap(o[0], o[1], f, sec);
             __builtin_amdgcn_raw_buffer_store_b128(f, rs_c, p_off(tl, s, i, 0, true), 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(sec, rs_c, p_off(tl, s, i, 1, true), 0, 0);
@@ -460,7 +513,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                 sc_b = sc_read((BUFIDX) & 3, 4 + wc);                                                                      \
             }                                                                                                              \
             stage_unit(2);                                                                                                 \
-            pp_wait_vmcnt<pp_nwait(KIND, 0, NSQ, BULK, MX)>();                                                          \
+            pp_wait_vmcnt<pp_nwait(KIND, 0, NSP, BULK, MX)>();                                                           \
             __builtin_amdgcn_s_barrier();                                                                                  \
             PP_MFMA(0, bf0, 0, FIRSTK);                                                                                 \
             __builtin_amdgcn_s_barrier();                                                                                  \
@@ -475,7 +528,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
             }                                                                                                              \
             stage_unit(3);                                                                                                 \
             advance_cursor();                                                                                              \
-            pp_wait_vmcnt<pp_nwait(KIND, 1, NSQ, BULK, MX)>();                                                          \
+            pp_wait_vmcnt<pp_nwait(KIND, 1, NSP, BULK, MX)>();                                                           \
             __builtin_amdgcn_s_barrier();                                                                                  \
             PP_MFMA(0, bf1, 1, FIRSTK);                                                                                 \
             __builtin_amdgcn_s_barrier();                                                                                  \
@@ -491,7 +544,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
             }                                                                                                              \
             if constexpr (MX) sc_a1 = sc_read((BUFIDX) & 3, wr * 2 + 1);                                                   \
             stage_unit(0);                                                                                                 \
-            pp_wait_vmcnt<pp_nwait(KIND, 2, NSQ, BULK, MX)>();                                                          \
+            pp_wait_vmcnt<pp_nwait(KIND, 2, NSP, BULK, MX)>();                                                           \
             __builtin_amdgcn_s_barrier();                                                                                  \
             PP_MFMA(1, bf1, 1, FIRSTK);                                                                                 \
             __builtin_amdgcn_s_barrier();                                                                                  \
@@ -500,7 +553,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
         {                                                                                                                  \
             stage_scales();                                                                                                \
             stage_unit(1);                                                                                                 \
-            pp_wait_vmcnt<pp_nwait(KIND, 3, NSQ, BULK, MX)>();                                                          \
+            pp_wait_vmcnt<pp_nwait(KIND, 3, NSP, BULK, MX)>();                                                           \
             __builtin_amdgcn_s_barrier();                                                                                  \
             PP_MFMA(1, bf0, 0, FIRSTK);                                                                                 \
             __builtin_amdgcn_s_barrier();                                                                                  \
@@ -707,7 +760,8 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
 void* egv_prof_begin(void* stream);
 void egv_prof_end(void* handle, void* stream, double flops, int kind, double bytes);
 extern "C" int egv_gemm_mx(int M, int N, int K, const void* Aq, const void* Ascales, const void* Bq, const void* Bscales, void* C, int ldc,
-                           const float* bias, int act, const void* res1, void* pre, const void* aux, int dact, int ldr, void* stream) {
+                           const float* bias, int act, const void* res1, void* pre, const void* aux, int dact, int ldr, void* out_q,
+                           void* out_scales, void* stream) {
     EGV_CHECK(M > 0 && N > 0 && K > 0 && Aq && Ascales && Bq && Bscales && C, "egv_gemm_mx: null / empty operand");
     EGV_CHECK((K % 128) == 0 && K >= 384 && (N % 64) == 0, "egv_gemm_mx: K %% 128 == 0, K >= 384, N %% 64 == 0 required (N=%d K=%d)", N, K);
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
@@ -718,6 +772,9 @@ extern "C" int egv_gemm_mx(int M, int N, int K, const void* Aq, const void* Asca
               "egv_gemm_mx: operand beyond 32-bit byte offsets");
     EGV_CHECK(!(res1 && (dact || act || pre)) && !(dact && (act || pre)) && !(pre && !act), "egv_gemm_mx: epilogue combination not built");
     EGV_CHECK(!dact || aux, "egv_gemm_mx: dact without aux");
+    EGV_CHECK((out_q == nullptr) == (out_scales == nullptr), "egv_gemm_mx: out_q and out_scales come together");
+    EGV_CHECK(!out_q || (((pre && act) || dact) && (N % 128) == 0 && ldc == N && al16(out_q)),
+              "egv_gemm_mx: the quantised output is built for the GELU (saved pre-activation) and the GELU' epilogues, N %% 128 == 0, ldc == N");
     GemmArgs g{};
     g.A = Aq; g.B = Bq; g.C = C;
     g.M = M; g.N = N; g.K = K;
@@ -728,6 +785,8 @@ extern "C" int egv_gemm_mx(int M, int N, int K, const void* Aq, const void* Asca
     g.sa = reinterpret_cast<const unsigned char*>(Ascales);
     g.sb = reinterpret_cast<const unsigned char*>(Bscales);
     g.mx = 1;
+    g.e.oq = reinterpret_cast<unsigned char*>(out_q);
+    g.e.os = reinterpret_cast<unsigned char*>(out_scales);
     g.tiles_n = (N + 255) / 256;
     g.tiles_m = (M + 191) / 192;
     const int ntiles = g.tiles_m * g.tiles_n;
@@ -747,26 +806,30 @@ extern "C" int egv_gemm_mx(int M, int N, int K, const void* Aq, const void* Asca
     if (grid > ncu) grid = ncu;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     void* ph = egv_prof_begin(stream);
-#define MX_LAUNCH(X, P, AC)                                                                                                \
+#define MX_LAUNCH_Q(X, P, AC, QO)                                                                                          \
     do {                                                                                                                   \
         static bool attr = false;                                                                                          \
         if (!attr) {                                                                                                       \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<X, P, AC, false, 3, true>),             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<X, P, AC, false, 3, true, QO>),         \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_MX);                              \
             attr = true;                                                                                                   \
         }                                                                                                                  \
         egv_prof_cus_hint = grid;                                                                                          \
-        hipLaunchKernelGGL((gemm_pp_kernel<X, P, AC, false, 3, true>), dim3(grid), dim3(512), PP_LDS_MX, st, g, ntiles);   \
+        hipLaunchKernelGGL((gemm_pp_kernel<X, P, AC, false, 3, true, QO>), dim3(grid), dim3(512), PP_LDS_MX, st, g, ntiles); \
     } while (0)
-    if (res1) MX_LAUNCH(1, false, false);
+#define MX_LAUNCH(X, P, AC) MX_LAUNCH_Q(X, P, AC, false)
+    if (out_q && dact) MX_LAUNCH_Q(2, false, false, true);
+    else if (out_q) MX_LAUNCH_Q(0, true, true, true);
+    else if (res1) MX_LAUNCH(1, false, false);
     else if (dact) MX_LAUNCH(2, false, false);
     else if (pre) MX_LAUNCH(0, true, true);
     else if (act) MX_LAUNCH(0, false, true);
     else MX_LAUNCH(0, false, false);
 #undef MX_LAUNCH
+#undef MX_LAUNCH_Q
     // algorithmic bytes: fp8 operands + scales once, the bf16 output and every bf16 epilogue operand once
     const double abytes = (double)M * K * (1.0 + 1.0 / 32) + (double)N * K * (1.0 + 1.0 / 32) +
-                          2.0 * M * N * (1 + (res1 != nullptr) + (pre != nullptr) + (aux != nullptr));
+                          2.0 * M * N * (1 + (res1 != nullptr) + (pre != nullptr) + (aux != nullptr)) + (out_q ? (double)M * N * (1.0 + 1.0 / 32) : 0.0);
     egv_prof_end(ph, stream, 2.0 * M * N * K, 16, abytes);
     EGV_LAUNCH_CHECK();
     return 0;

@@ -10,10 +10,14 @@ constexpr int LN_MAXV = 4;   // up to 4 vectors of 4 elements per lane -> D <= 1
 
 // y2 (optional): a bf16 copy of the output -- the fp32 residual stream of the text tower keeps y in fp32 and feeds the next Linear
 // (a bf16 MFMA GEMM) from the copy
-template <typename T>
+// MXQ (bf16 only, D % 128 == 0): also emit the MX-fp8 form of the output (egv_mx.hip: e4m3 codes q[M][D] and the E8M0 scale bytes in
+// the role-0 lane order) -- the A operand of the Linear that follows, quantised from the bf16-rounded values exactly as egv_quant_mx
+// would quantise y: a 32-element block is the 4 x 8 elements of 8 neighbouring lanes
+template <typename T, bool MXQ = false>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            float* __restrict__ stats, int M, int D, float eps, bf16_t* __restrict__ y2 = nullptr) {
+                                                            float* __restrict__ stats, int M, int D, float eps, bf16_t* __restrict__ y2 = nullptr,
+                                                            unsigned char* __restrict__ mxq = nullptr, unsigned char* __restrict__ mxs = nullptr) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + wave_id();
     if (row >= M) return;
@@ -59,6 +63,28 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
             for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * gamma[c + e] + beta[c + e];
             st4(yr + c, o);
             if (y2) st4(y2 + (size_t)row * D + c, o);
+            if constexpr (MXQ) {
+                float r[4], amax = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { r[e] = bf2f(f2bf(o[e])); amax = fmaxf(amax, fabsf(r[e])); }
+                amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+                amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+                amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+                const unsigned int bits = __float_as_uint(amax);
+                int e8 = (int)(bits >> 23) - 8 + ((bits & 0x7fffffu) > 0x600000u ? 1 : 0);
+                e8 = e8 < 0 ? 0 : (e8 > 254 ? 254 : e8);
+                const int sh = 127 - e8;
+                float a4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a4[e] = fminf(fmaxf(__builtin_amdgcn_ldexpf(r[e], sh), -448.f), 448.f);
+                int pk = __builtin_amdgcn_cvt_pk_fp8_f32(a4[0], a4[1], 0, false);
+                pk = __builtin_amdgcn_cvt_pk_fp8_f32(a4[2], a4[3], pk, true);
+                *reinterpret_cast<int*>(mxq + (size_t)row * D + c) = pk;
+                if ((lane & 7) == 0) {
+                    const int kb = c >> 5, blk = row / 48, rb = row - blk * 48, nblk = ((M + 191) / 192) * 4;
+                    mxs[(((size_t)(kb >> 2) * nblk + blk) * 4 + (kb & 3)) * 64 + (rb & 15) * 4 + (rb >> 4)] = (unsigned char)e8;
+                }
+            }
         }
     }
 }
@@ -499,6 +525,17 @@ extern "C" int egv_layernorm_fwd(int dtype, const void* x, void* y, const float*
         hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, gamma, beta, stats, M, D, eps);
     else
         hipLaunchKernelGGL(layernorm_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (float*)y, gamma, beta, stats, M, D, eps);
+    EGV_LAUNCH_CHECK();
+    return 0;
+}
+
+// bf16 LayerNorm that also writes the MX-fp8 form of its output (role 0: the A operand of the next Linear; BASELINE.json configs[4])
+extern "C" int egv_layernorm_fwd_mx(const void* x, void* y, const float* gamma, const float* beta, float* stats, void* q, void* scales,
+                                    int M, int D, float eps, void* stream) {
+    EGV_CHECK(D % 128 == 0 && D <= LN_MAXV * 256 && M > 0 && q && scales, "egv_layernorm_fwd_mx: M=%d D=%d unsupported", M, D);
+    LnProf prof(stream, 30, 5.0 * M * D);
+    hipLaunchKernelGGL((layernorm_fwd_kernel<bf16_t, true>), dim3((M + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       (const bf16_t*)x, (bf16_t*)y, gamma, beta, stats, M, D, eps, (bf16_t*)nullptr, (unsigned char*)q, (unsigned char*)scales);
     EGV_LAUNCH_CHECK();
     return 0;
 }

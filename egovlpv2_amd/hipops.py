@@ -334,12 +334,29 @@ def quant_mx(x, role):
     return q, sc
 
 
-def gemm_mx(aq, asc, bq, bsc, M, N, K, *, bias=None, act=0, res1=None, pre=None, aux=None, dact=0):
-    """bf16 C[M,N] = epi(A B^T) on MX-fp8 operands (egv_gemm_mx); aq [M,K] / bq [N,K] codes, asc / bsc their scale bytes"""
+def layernorm_mx(x, gamma, beta, eps):
+    """bf16 LayerNorm that also returns the MX-fp8 form (role 0) of its output: (y, codes, scale bytes) -- egv_layernorm_fwd_mx"""
+    M, D = x.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    y = torch.empty_like(x)
+    q = torch.empty(M, D, dtype=torch.uint8, device=x.device)
+    sc = torch.full((lib.egv_mx_scale_bytes(M, D, 0),), 0x7f, dtype=torch.uint8, device=x.device)
+    stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+    check(lib.egv_layernorm_fwd_mx(_p(x), _p(y), _p(gamma), _p(beta), _p(stats), _p(q), _p(sc), M, D, float(eps), _st()), 'egv_layernorm_fwd_mx')
+    return y, q, sc
+
+
+def gemm_mx(aq, asc, bq, bsc, M, N, K, *, bias=None, act=0, res1=None, pre=None, aux=None, dact=0, quant_out=False):
+    """bf16 C[M,N] = epi(A B^T) on MX-fp8 operands (egv_gemm_mx); aq [M,K] / bq [N,K] codes, asc / bsc their scale bytes.
+    quant_out: also return C in MX-fp8 form (codes, role-0 scale bytes) written by the GEMM's epilogue"""
     out = torch.empty(M, N, dtype=torch.bfloat16, device=aq.device)
+    oq = osc = None
+    if quant_out:
+        oq = torch.empty(M, N, dtype=torch.uint8, device=aq.device)
+        osc = torch.full((lib.egv_mx_scale_bytes(M, N, 0),), 0x7f, dtype=torch.uint8, device=aq.device)
     check(lib.egv_gemm_mx(M, N, K, _p(aq), _p(asc), _p(bq), _p(bsc), _p(out), N, _p(bias), act, _p(res1), _p(pre), _p(aux), dact, N,
-                          _st()), 'egv_gemm_mx')
-    return out
+                          _p(oq), _p(osc), _st()), 'egv_gemm_mx')
+    return (out, oq, osc) if quant_out else out
 
 
 def wgrad(dy, x, M, N, K, gate=None, scale=1.0, ldy=None, bias=False):

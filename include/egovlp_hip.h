@@ -233,11 +233,18 @@ int egv_copy_segments(const void* table, int nseg, void* stream);
  * prefix[t] = workgroups before tensor t (a tensor takes ceil(R * K / 32 / 256)).
  * egv_gemm_mx: C[M,N] (bf16) = epi( A B^T ) with both operands quantised along K; epilogue as egv_gemm (bias, act, saved
  * pre-activation `pre`, residual res1, activation-derivative operand aux/dact).  K % 128 == 0, K >= 384, N % 64 == 0. */
+/* bf16 LayerNorm (as egv_layernorm_fwd) that also writes the MX-fp8 form of its output y (role 0): bit-identical to
+   egv_quant_mx(y) in a separate pass; D % 128 == 0 */
+int egv_layernorm_fwd_mx(const void* x, void* y, const float* gamma, const float* beta, float* stats, void* q, void* scales,
+                         int M, int D, float eps, void* stream);
 long long egv_mx_scale_bytes(int R, int K, int role);
 int egv_quant_mx(const void* x, int R, int K, int ld, void* q, void* scales, int role, void* stream);
 int egv_quant_mx_batch(const void* table, const int* prefix, int ntensors, int nblocks, void* stream);
 int egv_gemm_mx(int M, int N, int K, const void* Aq, const void* Ascales, const void* Bq, const void* Bscales, void* C, int ldc,
-                const float* bias, int act, const void* res1, void* pre, const void* aux, int dact, int ldr, void* stream);
+                const float* bias, int act, const void* res1, void* pre, const void* aux, int dact, int ldr,
+                void* out_q, void* out_scales,   /* optional (both or neither; GELU+pre and GELU' epilogues, N % 128 == 0): C also in MX-fp8
+                                                    form, role 0 -- the A operand of the next Linear, bit-identical to egv_quant_mx(C) */
+                void* stream);
 
 /* ---- fused multi-tensor AdamW (set_optim_schedule.py:108 -> transformers 4.30 AdamW: eps on sqrt(v) without bias
  * correction of the denominator, step_size = lr*sqrt(1-b2^t)/(1-b1^t), weight decay p -= lr*wd*p AFTER the update).

@@ -835,3 +835,39 @@ def test_mx_gemm_epilogues_vs_reference(ops):
     uu = u.float().requires_grad_(True)
     torch.nn.functional.gelu(uu).sum().backward()
     assert _rel(out.float().cpu(), (lin - bias) * uu.grad) < 4e-3
+
+
+@pytest.mark.parametrize('M,D', [(4113, 1024), (394, 512), (1000, 768)])
+def test_layernorm_with_fused_mx_output(ops, M, D):
+    """egv_layernorm_fwd_mx: the bf16 output equals egv_layernorm_fwd's, and its MX-fp8 codes / scale bytes equal what the standalone
+    quantiser makes of that output (bit for bit: the block executor may use either)"""
+    x = _rnd((M, D), torch.bfloat16, 1.5, 3).cuda()
+    g, b = _rnd((D,), torch.float32, 1.0, 4).cuda(), _rnd((D,), torch.float32, 0.3, 5).cuda()
+    y, q, sc = ops.layernorm_mx(x, g, b, 1e-5)
+    y0 = ops.layernorm(x, g, b, 1e-5)
+    assert torch.equal(y, y0)
+    q0, sc0 = ops.quant_mx(y0, 0)
+    assert torch.equal(q, q0) and torch.equal(sc, sc0)
+
+
+@pytest.mark.parametrize('M,N,K', [(1030, 1024, 512), (4113, 4096, 1024), (394, 2048, 512)])
+def test_mx_gemm_quantised_output_is_the_quantiser_s(ops, M, N, K):
+    """egv_gemm_mx(out_q, out_scales): the MX-fp8 form of the output written by the GEMM's epilogue (fc1's GELU with saved
+    pre-activation, fc2's GELU' data gradient) equals egv_quant_mx of the bf16 output, bit for bit, and the bf16 outputs do not change"""
+    a, b = _mx_inputs(M, K, 3, spread=False), (_mx_inputs(N, K, 4, spread=False).float() * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N).cuda()
+    aq, asc = ops.quant_mx(a.cuda(), 0)
+    bq, bsc = ops.quant_mx(b.cuda(), 1)
+    pre0 = torch.empty(M, N, dtype=torch.bfloat16, device='cuda')
+    pre1 = torch.empty_like(pre0)
+    out0 = ops.gemm_mx(aq, asc, bq, bsc, M, N, K, bias=bias, act=1, pre=pre0)
+    out1, oq, osc = ops.gemm_mx(aq, asc, bq, bsc, M, N, K, bias=bias, act=1, pre=pre1, quant_out=True)
+    assert torch.equal(out0, out1) and torch.equal(pre0, pre1)
+    q0, s0 = ops.quant_mx(out0, 0)
+    assert torch.equal(oq, q0) and torch.equal(osc, s0)
+    u = torch.randn(M, N).to(torch.bfloat16).cuda()
+    out0 = ops.gemm_mx(aq, asc, bq, bsc, M, N, K, aux=u, dact=1)
+    out1, oq, osc = ops.gemm_mx(aq, asc, bq, bsc, M, N, K, aux=u, dact=1, quant_out=True)
+    assert torch.equal(out0, out1)
+    q0, s0 = ops.quant_mx(out0, 0)
+    assert torch.equal(oq, q0) and torch.equal(osc, s0)

@@ -37,7 +37,7 @@ for name, N, K in shapes:
     xq, xs = ops.quant_mx(x, 0)
     wq, ws = ops.quant_mx(w, 1)
     t_mx = timed(lambda: lib.egv_gemm_mx(M, N, K, xq.data_ptr(), xs.data_ptr(), wq.data_ptr(), ws.data_ptr(), out.data_ptr(), N, bias.data_ptr(),
-                                         0, None, None, None, 0, N, None))
+                                         0, None, None, None, 0, N, None, None, None))
     t_q = timed(lambda: lib.egv_quant_mx(x.data_ptr(), M, K, K, xq.data_ptr(), xs.data_ptr(), 0, None))
     fl = 2.0 * M * N * K
     print(f"| {name} | {N} | {K} | {t_bf:.1f} | {fl / t_bf / 1e6:.0f} | {t_mx:.1f} | {fl / t_mx / 1e6:.0f} | {t_bf / t_mx:.2f} | {t_q:.1f} |")
