@@ -681,20 +681,37 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
         ncu_dev = ncu;
     }
     const int ncu_all = ncu;
-    if (g_cu_limit > 0 && g_cu_limit < ncu_all) ncu = g_cu_limit >= 8 ? (g_cu_limit / 8) * 8 : 8;
+    // A CU limit (the backward's grids beside a grouped weight-gradient launch) is a plan, not a fence: up to `slack` CUs beyond it are
+    // taken when that removes a whole round of the walk (1176 tiles of the fc1 / fc2 class: 8 rounds on 160 CUs, 7 on 168) -- a few
+    // workgroups then start late, behind the weight-gradient workgroups that hold their CUs, instead of every workgroup walking one
+    // tile more (measured on configs[2]: limit 160 -> 168, 78.1 -> 76.7 ms per step)
+    static const int slack = getenv("EGV_PP_LIMIT_SLACK") ? atoi(getenv("EGV_PP_LIMIT_SLACK")) : 16;
+    int ncu_soft = 0;
+    if (g_cu_limit > 0 && g_cu_limit < ncu_all) {
+        ncu = g_cu_limit >= 8 ? (g_cu_limit / 8) * 8 : 8;
+        ncu_soft = ncu + slack < ncu_all ? ncu + slack : ncu_all;
+    }
     // tile height: 192-row tiles where they shorten the walk (rounds x tile work, + 6 % for the smaller tile's lower operand
     // reuse); only the plain and the residual epilogue kinds are built for them
     static const bool allow192 = !getenv("EGV_PP_BM192") || atoi(getenv("EGV_PP_BM192")) != 0;
     const bool kind192 = !e.dact && (!e.pre || e.res2) && !e.act && !stamps;
     const int t256 = ((g.M + 255) / 256) * g.tiles_n, t192 = ((g.M + 191) / 192) * g.tiles_n;
     static const double pen192 = getenv("EGV_PP_192_PENALTY") ? atof(getenv("EGV_PP_192_PENALTY")) : 1.06;
-    const double c256 = (double)((t256 + ncu - 1) / ncu), c192 = (double)((t192 + ncu - 1) / ncu) * 0.75 * pen192;
+    auto rounds_of = [&](int t) {
+        const int r = (t + ncu - 1) / ncu;
+        return ncu_soft > ncu && (t + ncu_soft - 1) / ncu_soft < r ? (t + ncu_soft - 1) / ncu_soft : r;
+    };
+    const double c256 = (double)rounds_of(t256), c192 = (double)rounds_of(t192) * 0.75 * pen192;
     const bool use192 = allow192 && kind192 && t256 >= ncu && c192 < c256;
     g.tiles_m = use192 ? (g.M + 191) / 192 : (g.M + 255) / 256;
     const int ntiles = g.tiles_m * g.tiles_n;
     // the smallest grid (multiple of 8: the XCD-aware walk) that keeps the number of rounds: the walk takes as long, and the CUs it
     // does not take serve the companion streams
-    const int rounds = (ntiles + ncu - 1) / ncu;
+    int rounds = (ntiles + ncu - 1) / ncu;
+    if (ncu_soft > ncu && (ntiles + ncu_soft - 1) / ncu_soft < rounds) {
+        rounds = (ntiles + ncu_soft - 1) / ncu_soft;
+        ncu = ncu_soft;
+    }
     static const bool trim = !getenv("EGV_PP_TRIM") || atoi(getenv("EGV_PP_TRIM")) != 0;
     int grid = trim ? (((ntiles + rounds - 1) / rounds + 7) / 8) * 8 : ncu;
     if (grid > ncu) grid = ncu;
