@@ -813,7 +813,7 @@ class FrozenInTime(nn.Module):
         if itm_state is not None and 'EgoNCE' in task_names and late_tail:
             make_tail()          # after both text prefixes were created, before the fused stacks: see late_tail above
 
-        if 'MLM' in task_names:                                                                  # :404-422
+        def run_mlm():                                                                           # :404-422
             # infer(task_names='MLM') with the head, the cross entropy and the loss arithmetic on the text stream: in backward the
             # head and the last fused text layer -- which the first MLM video block's backward has to wait for -- then run beside
             # the ITM pass's backward instead of after it (2.2 ms of calling-stream idle time per step)
@@ -839,9 +839,9 @@ class FrozenInTime(nn.Module):
             Bm, Lm = data['text_mlm_ids'].shape
             ret.update({'cross_attn_mlm_logits': logits.reshape(Bm, Lm, -1)[..., :c.vocab]})
             loss_dict.update({'loss_mlm': loss_mlm})
-            loss_terms.append((1.0, loss_mlm))
+            terms['mlm'] = (1.0, loss_mlm)
 
-        if 'ITM' in task_names:                                                                  # :426-483
+        def run_itm():                                                                           # :426-483
             rank, bsz, w_host, ev, all_video, all_text_ids, all_text_masks, ev_in = itm_pre
             drawn = itm_state if itm_state is not None else itm_draw()
             itm_labels, neg_log, vid_idx, vid_list, labels_dev, data_itm = (drawn[k] for k in ('itm_labels', 'neg_log', 'vid_idx', 'vid_list',
@@ -864,15 +864,29 @@ class FrozenInTime(nn.Module):
                 data_itm['_video_prefix'] = SelectClipsFn.apply(plan, c.seq, v_pre, v_rem)
             else:
                 data_itm['video'] = all_video.index_select(0, vid_idx)
-            ret = self.infer(data_itm, task_names='ITM', ret=ret)
-            itm_logits = ret['cross_attn_itm_logits']
+            r_itm = self.infer(data_itm, task_names='ITM', ret=ret)
+            itm_logits = r_itm['cross_attn_itm_logits']
             ce_sum = ops.cross_entropy_sum(ops.CastFn.apply(itm_logits, torch.float32).contiguous(), labels_dev.contiguous(), 2, -100)
             tot = gather(torch.stack([ce_sum, torch.full_like(ce_sum, float(bsz))]).reshape(1, 2))
             loss_itm = tot[:, 0].sum() / tot[:, 1].sum()
             loss_dict.update({'loss_itm': loss_itm})
-            loss_terms.append((2.0, loss_itm))
+            terms['itm'] = (2.0, loss_itm)
             ret['_itm_labels'] = itm_labels
             ret['_itm_neg_log'] = neg_log
+
+        # Which fused pass is CREATED last runs FIRST in backward (reverse creation order).  EGV_ITM_FIRST=1 creates the ITM pass before
+        # the MLM pass (default: the reference's order).  The losses are added in the reference's order either way.
+        terms = {}
+        if 'MLM' in task_names:
+            loss_dict['loss_mlm'] = None
+        if 'ITM' in task_names:
+            loss_dict['loss_itm'] = None
+        for name, fn in ((('ITM', run_itm), ('MLM', run_mlm)) if os.environ.get('EGV_ITM_FIRST', '0') == '1' else (('MLM', run_mlm), ('ITM', run_itm))):
+            if name in task_names:
+                fn()
+        for key in ('mlm', 'itm'):
+            if key in terms:
+                loss_terms.append(terms[key])
 
         if 'EgoNCE' in task_names and late_tail and 'out' not in tail_state:
             make_tail()
