@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401  -- must be imported first: the HIP runtime torch bundles has to be the one in the process
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libegovlp_hip.so')
+# EGV_LIB_PATH: an alternative build of the SAME library (kernel experiments of tools/); the product path never sets it
+LIB_PATH = os.environ.get('EGV_LIB_PATH') or os.path.join(_HERE, 'libegovlp_hip.so')
 
 ABI_VERSION = 4
 EGV_F32, EGV_BF16 = 0, 1

@@ -89,4 +89,5 @@ int egv_attn_dq_mfma(const egv::AttnArgs& a, int B, hipStream_t st);
 int egv_attn_dkv_mfma(const egv::AttnArgs& a, int B, hipStream_t st);
 int egv_attn_bwd_fused_mfma(const egv::AttnArgs& a, int B, hipStream_t st);
 bool egv_attn_bwd_pair_cls_ok(const egv::AttnArgs& a);
+int egv_attn_time_bwd(const egv::AttnArgs& a, int B, hipStream_t st);   // egv_attn_time.hip: one-launch backward of the <= 16-row groups (time attention)
 void egv_attn_bwd_cls_reduce_launch(const egv::AttnArgs& a, int B, int self_term, hipStream_t st);

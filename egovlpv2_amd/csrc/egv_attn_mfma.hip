@@ -1040,6 +1040,13 @@ int egv_attn_dkv_mfma(const AttnArgs& ain, int B, hipStream_t st) {
 // other side (space attention: 196 patches + CLS) -- for the 17-row time attention a one-wave fused kernel measured no faster
 // than the pair (both are bound by the global round trips of one wave, and the pair runs at twice the occupancy).
 int egv_attn_bwd_fused_mfma(const AttnArgs& a, int B, hipStream_t st) {
+    // groups of at most one 16-row tile (the 17-row time attention): the one-wave-per-group kernel of egv_attn_time.hip, which
+    // leaves the CLS row's gradients as per-group partials; the (CLS, CLS) term is added by the reduction
+    static const bool time_fused = !getenv("EGV_ATTN_TIME_FUSED") || atoi(getenv("EGV_ATTN_TIME_FUSED")) != 0;
+    if (time_fused && a.q.n <= 16 && a.ws && a.extra && egv_attn_time_bwd(a, B, st)) {
+        hipLaunchKernelGGL(attn_cls_reduce_kernel, dim3(B, a.H), dim3(256), 0, st, a, 1);
+        return 1;
+    }
     const int ntot = a.q.n + a.extra;
     const int own = (a.k.n + 15) / 16 + a.extra;
     if (!aligned_ok(a) || (a.lddq % 4) || (a.dqoff % 4) || (a.lddk % 4) || (a.lddv % 4) || (a.dkoff % 4) || (a.dvoff % 4)) return 0;

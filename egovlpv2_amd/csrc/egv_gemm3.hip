@@ -108,7 +108,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
     constexpr int BM = IM * 64, WM = IM * 32, SM = IM * 16;        // tile rows, rows per wave row, rows per A sub-tile and wave row
     // stores per pair of quadrants (one pair_epilogue call): 2 (4 with the saved pre-activation) per 16-row fragment, + 2 code stores
     // and 1 scale store when the output is also emitted in MX-fp8 form
-    constexpr int NSP = (PREK ? 4 : 2) * IM + (QOUT ? 3 * IM : 0);
+#ifndef EGV_PP_EXP
+#define EGV_PP_EXP 0
+#endif
+    // EGV_PP_EXP (tools/pp_exp.sh, never in the product build): 1 = the epilogue stores are dropped; 2 = dropped and replaced by the same
+    // number of stores trickled one per wave into phases 1 and 3 of the tile's plain K-tiles (counted waits left conservative)
+    constexpr int NSP = EGV_PP_EXP ? 0 : (PREK ? 4 : 2) * IM + (QOUT ? 3 * IM : 0);
     constexpr bool BULK = X1K != 0;                                // residual / GELU' operand: epilogue in one piece at the tile's end
     constexpr unsigned int OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -341,8 +346,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                                     pack_bf16x2(a1[0] + bias8[t][4], a1[1] + bias8[t][5]), pack_bf16x2(a1[2] + bias8[t][6], a1[3] + bias8[t][7])};
                 }
                 pair_swap(pr[0], pr[1], f, sec);
+#if EGV_PP_EXP
+                asm volatile("" :: "v"(f), "v"(sec));
+#else
                 __builtin_amdgcn_raw_buffer_store_b128(f, rs_pre, p_off(tl, s, i, 0, false), 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(sec, rs_pre, p_off(tl, s, i, 1, false), 0, 0);
+#endif
             }
             u32x4_t o[2];
 #pragma unroll
@@ -437,8 +446,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                 }
             }
             pair_swap(o[0], o[1], f, sec);
+#if EGV_PP_EXP
+            asm volatile("" :: "v"(f), "v"(sec));
+#else
             __builtin_amdgcn_raw_buffer_store_b128(f, rs_c, p_off(tl, s, i, 0, true), 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(sec, rs_c, p_off(tl, s, i, 1, true), 0, 0);
+#endif
         }
     };
 
@@ -487,6 +500,22 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
         }                                                                                                                  \
         __builtin_amdgcn_s_setprio(0);                                                                                     \
     } while (0)
+#if EGV_PP_EXP == 2
+#define PP_EXP_TRICKLE(KIND, H)                                                                                            \
+    do {                                                                                                                   \
+        if ((KIND) == PP_PLAIN && ts > 0) {                                                                                \
+            const int slot = exp_kt * 2 + (H);                                                                             \
+            const int per = PREK ? 2 : 1;                                                                                  \
+            if (slot < 4 * IM / 1) {                                                                                       \
+                for (int r = 0; r < per; ++r)                                                                              \
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, bf1[0][0]), r ? rs_pre : rs_c,     \
+                        p_off(prev, (slot / (2 * IM)) & 1, (slot >> 1) % IM, slot & 1, r == 0), 0, 0);                     \
+            }                                                                                                              \
+        }                                                                                                                  \
+    } while (0)
+#else
+#define PP_EXP_TRICKLE(KIND, H) do { } while (0)
+#endif
 #define PP_KTILE(KIND, BUFIDX)                                                                                             \
     do {                                                                                                                   \
         constexpr bool FIRSTK = (KIND) == PP_FIRST_CHAIN || (KIND) == PP_FIRST_COLD;                                       \
@@ -521,6 +550,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
         /* ---------------- phase 1: read B sub 1 (U2); stage U3 of kt+1; quadrant 1 = (0,1) */                            \
         {                                                                                                                  \
             if (LASTK) load_bias(cur);                                                                                    \
+            PP_EXP_TRICKLE(KIND, 0);                                                                                       \
             const unsigned char* pb = buf + 2 * PP_UNIT + b_base;                                                          \
             _Pragma("unroll") for (int jp = 0; jp < 2; ++jp) {                                                             \
                 bf1[jp][0] = *reinterpret_cast<const bf16x8_t*>(pb + jp * 2048 + swz0);                                    \
@@ -551,6 +581,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
         }                                                                                                                  \
         /* ---------------- phase 3: no reads; stage U1 of kt+2; quadrant 3 = (1,0) */                                     \
         {                                                                                                                  \
+            PP_EXP_TRICKLE(KIND, 1);                                                                                       \
             stage_scales();                                                                                                \
             stage_unit(1);                                                                                                 \
             pp_wait_vmcnt<pp_nwait(KIND, 3, NSP, BULK, MX)>();                                                           \
@@ -562,6 +593,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
 
     PPTile prev = cur, nxt = cur;
     bool have_next = false;
+    [[maybe_unused]] int exp_kt = 0;
     for (int ts = 0; ts < my_tiles; ++ts) {
         have_next = ts + 1 < my_tiles;
         nxt = pp_tile(first + (have_next ? ts + 1 : ts) * G, g.tiles_n, BM);
@@ -585,7 +617,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
             PP_STAMP(1);
             PP_KTILE(PP_SECOND_CHAIN, kb + 1);
         }
-        for (int kt = 2; kt < KT - 1; ++kt) { PP_STAMP(kt); PP_KTILE(PP_PLAIN, kb + kt); }
+        for (int kt = 2; kt < KT - 1; ++kt) { PP_STAMP(kt); exp_kt = kt - 2; PP_KTILE(PP_PLAIN, kb + kt); }
         PP_STAMP(KT - 1);
         PP_KTILE(PP_LAST, kb + KT - 1);
         PP_STAMP(KT);

@@ -253,6 +253,12 @@ static int group_plan(int M, int nprob, const egv_wgrad_problem* pr, int cus, Gr
     gp.G = cus;
     const int KT = (M + 63) / 64;
     plan_phases(gp.ntile, cus, KT, 0, gp.tiles, gp.splits, gp.nphase);
+    {   // the recursion stops at WG_MAXPH phases: a plan that does not cover every tile (few CUs, many tiles) is no plan --
+        // the caller then takes the one-gradient-per-launch form instead of leaving dW tiles unwritten
+        int covered = 0;
+        for (int i = 0; i < gp.nphase; ++i) covered += gp.tiles[i];
+        if (covered != gp.ntile || gp.nphase < 1 || gp.nphase > WG_MAXPH) return 0;
+    }
     gp.nslab = 0;
     for (int i = 0; i < gp.nphase; ++i) {
         int ns = gp.splits[i];

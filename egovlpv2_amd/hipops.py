@@ -1106,6 +1106,18 @@ def begin_step(param_ids=None):
     """forget gradient bookkeeping of an aborted step (called at the top of FrozenInTime.forward).  param_ids: ids of the
     calling model's parameters -- only its blocks are forgotten; None: everything."""
     _first_vblock[0] = True
+    # A backward pass that raised (out of memory, anomaly mode, an interrupt) never ran the engine's final callbacks: the
+    # callback latch would stay set -- no later pass would queue `_backward_done`, and with it the join of the companion
+    # streams -- and the weight-gradient launches it left behind would still be unjoined.  Recover here, once per step.
+    _acc_cb[0] = False
+    if _deferred['sides']:
+        cur = torch.cuda.current_stream() if torch.cuda.is_available() else None
+        for side, main in _deferred['sides'].values():
+            main.wait_stream(side)
+            if cur is not None and cur.cuda_stream != main.cuda_stream:
+                cur.wait_stream(side)
+        _deferred['sides'].clear()
+    _deferred['handed'] = []
     if param_ids is None:
         _acc.clear()
         return

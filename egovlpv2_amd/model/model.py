@@ -470,6 +470,7 @@ class FrozenInTime(nn.Module):
     # ------------------------------------------------------------------ reference API
     def compute_text(self, text_data):
         """model.py:491-505: RoBERTa last_hidden_state[:, 0] -> txt_proj."""
+        self._prepare_weights()
         ids, am = text_data['input_ids'], text_data['attention_mask']
         B, L = ids.shape
         hid = self._text_embeddings(ids, self._text_dtype())
@@ -480,6 +481,7 @@ class FrozenInTime(nn.Module):
 
     def compute_text_tokens(self, text_data):
         """model.py:507-522: all token states -> txt_proj."""
+        self._prepare_weights()
         ids, am = text_data['input_ids'], text_data['attention_mask']
         B, L = ids.shape
         hid = self._text_embeddings(ids, self._text_dtype())
@@ -489,6 +491,7 @@ class FrozenInTime(nn.Module):
         return self._proj_mlp(self._text_operand(hid, exact_ok=True), 'txt_proj').reshape(B, L, -1)
 
     def _video_features(self, video_data):
+        self._prepare_weights()          # (a no-op when the step's copies exist: direct compute_video / Feature_Extraction calls find them too)
         B = video_data.shape[0]
         x = self._patch_tokens(video_data, 'video_model.cls_token')
         for i in range(self.cfg.depth):
@@ -602,8 +605,14 @@ class FrozenInTime(nn.Module):
         ops.begin_step(ids)
         # under DistributedDataParallel the reducer copies every gradient the moment autograd produces it: the block backward
         # calls must then join their weight-gradient stream before they return (hipops.set_defer_wgrad_join)
-        ddp = getattr(torch.nn.parallel.DistributedDataParallel, '_active_ddp_module', None)
-        ops.set_defer_wgrad_join(ddp is None)
+        DDP = torch.nn.parallel.DistributedDataParallel
+        if hasattr(DDP, '_active_ddp_module'):
+            defer = DDP._active_ddp_module is None
+        else:
+            # this torch does not tell whether a DDP forward is active: defer only where no reducer can be listening (no process
+            # group at all, or the flat gradient sync of trainer/grad_sync.py, which is ordered behind the launch itself)
+            defer = not (dist.is_available() and dist.is_initialized()) or ops._pack_hook[0] is not None
+        ops.set_defer_wgrad_join(defer)
 
     def forward(self, data, n_embeds, v_embeds, allgather, n_gpu, args, config, loss_egonce, gpu, return_embeds=True,
                 task_names='EgoNCE_ITM_MLM'):
