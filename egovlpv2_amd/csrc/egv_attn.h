@@ -89,5 +89,10 @@ int egv_attn_dq_mfma(const egv::AttnArgs& a, int B, hipStream_t st);
 int egv_attn_dkv_mfma(const egv::AttnArgs& a, int B, hipStream_t st);
 int egv_attn_bwd_fused_mfma(const egv::AttnArgs& a, int B, hipStream_t st);
 bool egv_attn_bwd_pair_cls_ok(const egv::AttnArgs& a);
+bool egv_attn_space_fwd_ok(const egv::AttnArgs& a, int B);
+int egv_attn_space_fwd(const egv::AttnArgs& a, int B, hipStream_t st);  // egv_attn_space.hip: 1 group rows, 2 also the CLS row (a.ws set), 0 not covered
+int egv_attn_space_bwd(const egv::AttnArgs& a, int B, hipStream_t st);  // one-launch backward of those groups (+ the CLS row's partials with a.ws)
+bool egv_attn_time_fwd_ok(const egv::AttnArgs& a, int B);
+int egv_attn_time_fwd(const egv::AttnArgs& a, int B, hipStream_t st);   // egv_attn_time.hip: forward of those groups incl. the CLS query (partials + combination)
 int egv_attn_time_bwd(const egv::AttnArgs& a, int B, hipStream_t st);   // egv_attn_time.hip: one-launch backward of the <= 16-row groups (time attention)
 void egv_attn_bwd_cls_reduce_launch(const egv::AttnArgs& a, int B, int self_term, hipStream_t st);

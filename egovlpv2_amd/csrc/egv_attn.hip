@@ -674,7 +674,7 @@ extern "C" long long egv_attn_fwd_extra_workspace_bytes(int B, int G, int H) { r
 extern "C" int egv_attn_fwd_covers_extra(int dtype, const egv_attn_desc* d) {
     if (dtype != EGV_BF16 || !d || !d->ws) return 0;
     AttnArgs a = to_args(d);
-    return egv_attn_fwd_cls_ok(a) ? 1 : 0;
+    return (egv_attn_fwd_cls_ok(a) || egv_attn_time_fwd_ok(a, d->B) || egv_attn_space_fwd_ok(a, d->B)) ? 1 : 0;
 }
 
 static int egv_attn_fwd_impl(int dtype, const egv_attn_desc* d, void* stream) {
@@ -682,6 +682,18 @@ static int egv_attn_fwd_impl(int dtype, const egv_attn_desc* d, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     AttnArgs a = to_args(d);
     if (dtype == EGV_BF16 && a.nsplit == 1) {
+        if (d->ws && d->ws_bytes >= egv_attn_fwd_extra_workspace_bytes(d->B, d->G, d->H) && egv_attn_time_fwd(a, d->B, st)) {
+            EGV_LAUNCH_CHECK();                  // <= 16-row groups (time attention): group rows and the CLS query in one launch + its combination
+            return 0;
+        }
+        {   // long groups (space attention): row-major LDS images, the CLS row as row n of them (egv_attn_space.hip)
+            AttnArgs a2 = a;
+            if (!(d->ws && d->ws_bytes >= egv_attn_fwd_extra_workspace_bytes(d->B, d->G, d->H))) a2.ws = nullptr;
+            if (egv_attn_space_fwd(a2, d->B, st)) {
+                EGV_LAUNCH_CHECK();
+                return 0;
+            }
+        }
         if (d->ws && egv_attn_fwd_cls_ok(a))
             EGV_CHECK(d->ws_bytes >= egv_attn_fwd_extra_workspace_bytes(d->B, d->G, d->H), "egv_attn_fwd: workspace too small for the extra row's partial states");
         const int r = egv_attn_fwd_mfma(a, d->B, st);

@@ -1047,6 +1047,11 @@ int egv_attn_bwd_fused_mfma(const AttnArgs& a, int B, hipStream_t st) {
         hipLaunchKernelGGL(attn_cls_reduce_kernel, dim3(B, a.H), dim3(256), 0, st, a, 1);
         return 1;
     }
+    // long groups (space attention): two-phase kernel on row-major LDS images (egv_attn_space.hip)
+    if (a.delta && a.lse && egv_attn_space_bwd(a, B, st)) {
+        if (a.ws && a.extra) hipLaunchKernelGGL(attn_cls_reduce_kernel, dim3(B, a.H), dim3(256), 0, st, a, 0);
+        return 1;
+    }
     const int ntot = a.q.n + a.extra;
     const int own = (a.k.n + 15) / 16 + a.extra;
     if (!aligned_ok(a) || (a.lddq % 4) || (a.dqoff % 4) || (a.lddk % 4) || (a.lddv % 4) || (a.dkoff % 4) || (a.dvoff % 4)) return 0;

@@ -18,6 +18,7 @@
 // The CLS row's gradients leave as fp32 partials ws[group][head][3][64] (dQ, dK, dV; the layout of attn_bwd_fused_kernel) and are
 // summed over the groups, with the (CLS, CLS) term added, by attn_cls_reduce_kernel(self_term = 1).
 #include "egv_attn.h"
+#include <cstdlib>
 
 namespace egv {
 
@@ -58,6 +59,22 @@ __device__ __forceinline__ bf16x8_t t_afrag(const unsigned char* img, const unsi
     const short c = fg == 0 ? *reinterpret_cast<const short*>(cls + (dt * 16 + fr) * 2) : (short)0;
     const t_s16x8_t v = {lo[0], lo[1], lo[2], lo[3], c, 0, 0, 0};
     return __builtin_bit_cast(bf16x8_t, v);
+}
+// o[dt] (C layout: row fr, head dims dt*16 + fg*4 .. +3) -> bf16 row pieces of 16 bytes through a (free) LDS image, so that a store
+// instruction writes 16 rows x 64 contiguous bytes (as the loads read them) instead of 16 rows x 32
+__device__ __forceinline__ void t_store_rows(unsigned char* img, __amdgpu_buffer_rsrc_t r, unsigned int off, const f32x4_t (&o)[4], float s,
+                                             int fr, int fg) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const u32x2_t pk = {pack_bf16x2(o[dt][0] * s, o[dt][1] * s), pack_bf16x2(o[dt][2] * s, o[dt][3] * s)};
+        *reinterpret_cast<u32x2_t*>(img + fr * TP + dt * 32 + fg * 8) = pk;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const u32x4_t lo = *reinterpret_cast<const u32x4_t*>(img + fr * TP + fg * 16), hi = *reinterpret_cast<const u32x4_t*>(img + fr * TP + 64 + fg * 16);
+    __builtin_amdgcn_raw_buffer_store_b128(lo, r, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(hi, r, off + (off == T_OOB ? 0u : 64u), 0, 0);
 }
 __device__ __forceinline__ f32x4_t t_mfma(bf16x8_t a, bf16x8_t b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 }  // namespace
@@ -137,10 +154,6 @@ __global__ __launch_bounds__(256) void attn_time_bwd_kernel(const AttnArgs a, in
     const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
     const long long pw_off = ((long long)pg * a.H + h) * 3 * HD;
     const __amdgpu_buffer_rsrc_t rDQ = mk(a.dQ, dqkv_bytes), rDK = mk(a.dK, dqkv_bytes), rDV = mk(a.dV, dqkv_bytes);
-    auto st4bf = [&](__amdgpu_buffer_rsrc_t r, unsigned int off, const f32x4_t& v, float s) {
-        const u32x2_t pk = {pack_bf16x2(v[0] * s, v[1] * s), pack_bf16x2(v[2] * s, v[3] * s)};
-        __builtin_amdgcn_raw_buffer_store_b64(pk, r, off, 0, 0);
-    };
 
     // ================= lane = query: S^T[key][query] -> dQ^T = K^T dS^T =================
     {
@@ -165,13 +178,15 @@ __global__ __launch_bounds__(256) void attn_time_bwd_kernel(const AttnArgs a, in
             ds_cp[0] = fg == 0 ? p * (d_cp[0] - dl) : 0.f;
         }
         const bf16x8_t bP = t_pack8(ds_pp, ds_cp), bC = t_pack8(ds_pc, zero);
+        f32x4_t dq[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             const bf16x8_t ak = t_afrag(sK, cK, dt, fr, fg);
-            const f32x4_t dq = t_mfma(ak, bP, zero), dqc = t_mfma(ak, bC, zero);
-            st4bf(rDQ, valid ? (unsigned int)(row * a.lddq + a.dqoff + h * HD + dt * 16 + fg * 4) * 2u : T_OOB, dq, a.scale);
+            dq[dt] = t_mfma(ak, bP, zero);
+            const f32x4_t dqc = t_mfma(ak, bC, zero);
             if (c0) *reinterpret_cast<f32x4_t*>(a.ws + pw_off + dt * 16 + fg * 4) = dqc * a.scale;
         }
+        t_store_rows(sK, rDQ, valid ? (unsigned int)(row * a.lddq + a.dqoff + h * HD + fg * 8) * 2u : T_OOB, dq, a.scale, fr, fg);   // (the K image is free now)
     }
     // ================= lane = key: S[query][key] -> dV^T = dO^T P, dK^T = Q^T dS =================
     {
@@ -198,19 +213,171 @@ __global__ __launch_bounds__(256) void attn_time_bwd_kernel(const AttnArgs a, in
             ds_cp[0] = fg == 0 ? p * (d_cp[0] - dlc) : 0.f;
         }
         const bf16x8_t bvP = t_pack8(p_pp, p_cp), bvC = t_pack8(p_pc, zero), bkP = t_pack8(ds_pp, ds_cp), bkC = t_pack8(ds_pc, zero);
+        f32x4_t dv[4], dk[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             const bf16x8_t ag = t_afrag(sG, cG, dt, fr, fg), aq = t_afrag(sQ, cQ, dt, fr, fg);
-            const f32x4_t dv = t_mfma(ag, bvP, zero), dvc = t_mfma(ag, bvC, zero);
-            const f32x4_t dk = t_mfma(aq, bkP, zero), dkc = t_mfma(aq, bkC, zero);
-            st4bf(rDV, valid ? (unsigned int)(row * a.lddv + a.dvoff + h * HD + dt * 16 + fg * 4) * 2u : T_OOB, dv, 1.0f);
-            st4bf(rDK, valid ? (unsigned int)(row * a.lddk + a.dkoff + h * HD + dt * 16 + fg * 4) * 2u : T_OOB, dk, a.scale);
+            dv[dt] = t_mfma(ag, bvP, zero);
+            dk[dt] = t_mfma(aq, bkP, zero);
+            const f32x4_t dvc = t_mfma(ag, bvC, zero), dkc = t_mfma(aq, bkC, zero);
             if (c0) {
                 *reinterpret_cast<f32x4_t*>(a.ws + pw_off + HD + dt * 16 + fg * 4) = dkc * a.scale;
                 *reinterpret_cast<f32x4_t*>(a.ws + pw_off + 2 * HD + dt * 16 + fg * 4) = dvc;
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // every lane's transposing reads of the two images are done
+        __builtin_amdgcn_wave_barrier();
+        t_store_rows(sG, rDV, valid ? (unsigned int)(row * a.lddv + a.dvoff + h * HD + fg * 8) * 2u : T_OOB, dv, 1.0f, fr, fg);
+        t_store_rows(sQ, rDK, valid ? (unsigned int)(row * a.lddk + a.dkoff + h * HD + fg * 8) * 2u : T_OOB, dk, a.scale, fr, fg);
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Forward of the same groups: O and lse of the <= 16 patch queries over [CLS key ; the group's keys] AND the CLS query's partial
+// softmax state over the group's keys (m, l, o[64] per (group, sample, head): the layout attn_fwd_mfma_kernel leaves for the space
+// attention; the CLS key itself is counted in group 0) -- the one-query launch over all S keys (attn1_fwd_kernel) is not needed.
+// Scores in the lane = query layout (S^T = K Q^T); the probabilities are the B operand of O^T = V^T P^T as they stand.
+__global__ __launch_bounds__(256) void attn_time_fwd_kernel(const AttnArgs a, int nprob, int nb, unsigned int qkv_bytes, unsigned int o_bytes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, w = wave_id();
+    const int fr = lane & 15, fg = lane >> 4;
+    const int prob = blockIdx.x * 4 + w;
+    if (prob >= nprob) return;
+    unsigned char* sV = smem + w * (T_IMG + 128);
+    unsigned char* cV = sV + T_IMG;
+
+    const int h = prob % a.H, pg = prob / a.H, b = pg / a.G, g = pg % a.G;
+    const int n = a.q.n;
+    const bool valid = fr < n;
+    const int row = (int)(b * a.q.bs + a.q.base + g * a.q.gs) + fr * (int)a.q.is;
+    const int cls = (int)(b * a.extra_bs + a.extra_row);
+    const float sc2 = a.scale * T_LOG2E;
+    constexpr float T_LN2 = 0.6931471805599453f;
+
+    auto mk = [&](const void* p, unsigned int bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000); };
+    const __amdgpu_buffer_rsrc_t rQ = mk(a.Q, qkv_bytes), rK = mk(a.K, qkv_bytes), rV = mk(a.V, qkv_bytes), rO = mk(a.O, o_bytes);
+    auto ld = [&](__amdgpu_buffer_rsrc_t r, unsigned int off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); };
+    const unsigned int oq = valid ? (unsigned int)(row * a.ldq + a.qoff + h * HD + fg * 8) * 2u : T_OOB;
+    const unsigned int ok_ = valid ? (unsigned int)(row * a.ldk + a.koff + h * HD + fg * 8) * 2u : T_OOB;
+    const unsigned int ov_ = valid ? (unsigned int)(row * a.ldv + a.voff + h * HD + fg * 8) * 2u : T_OOB;
+    const bool c0 = fr == 0;
+    const unsigned int cq = c0 ? (unsigned int)(cls * a.ldq + a.qoff + h * HD + fg * 8) * 2u : T_OOB;
+    const unsigned int ck = c0 ? (unsigned int)(cls * a.ldk + a.koff + h * HD + fg * 8) * 2u : T_OOB;
+    const unsigned int cv = c0 ? (unsigned int)(cls * a.ldv + a.voff + h * HD + fg * 8) * 2u : T_OOB;
+    const u32x4_t q0 = ld(rQ, oq), q1 = ld(rQ, oq + 64), k0 = ld(rK, ok_), k1 = ld(rK, ok_ + 64), v0 = ld(rV, ov_), v1 = ld(rV, ov_ + 64);
+    const u32x4_t qc0 = ld(rQ, cq), qc1 = ld(rQ, cq + 64), kc0 = ld(rK, ck), kc1 = ld(rK, ck + 64), vc0 = ld(rV, cv), vc1 = ld(rV, cv + 64);
+
+    *reinterpret_cast<u32x4_t*>(sV + fr * TP + fg * 16) = v0;
+    *reinterpret_cast<u32x4_t*>(sV + fr * TP + 64 + fg * 16) = v1;
+    if (c0) {
+        *reinterpret_cast<u32x4_t*>(cV + fg * 16) = vc0;
+        *reinterpret_cast<u32x4_t*>(cV + 64 + fg * 16) = vc1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t s_pp = t_mfma(t_bf(k1), t_bf(q1), t_mfma(t_bf(k0), t_bf(q0), zero));       // patch keys x patch queries
+    f32x4_t s_cp = t_mfma(t_bf(kc1), t_bf(q1), t_mfma(t_bf(kc0), t_bf(q0), zero));     // CLS key (row 0) x patch queries
+    f32x4_t s_pc = t_mfma(t_bf(k1), t_bf(qc1), t_mfma(t_bf(k0), t_bf(qc0), zero));     // patch keys x CLS query (column 0: lanes fr == 0)
+    const float s_cc = readlane_f(t_grp_sum(t_dot16(qc0, qc1, kc0, kc1)), 0);          // CLS query . CLS key
+    // patch queries: softmax over [CLS key ; live patch keys] (raw scores; the positive scale commutes with max)
+    float m = fg == 0 ? s_cp[0] : -INFINITY, mc = (g == 0) ? s_cc : -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bool kv = fg * 4 + r < n;
+        s_pp[r] = kv ? s_pp[r] : -INFINITY;
+        s_pc[r] = kv ? s_pc[r] : -INFINITY;
+        m = fmaxf(m, s_pp[r]);
+        mc = fmaxf(mc, s_pc[r]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64)) * sc2;
+    mc = fmaxf(mc, __shfl_xor(mc, 16, 64));
+    mc = fmaxf(mc, __shfl_xor(mc, 32, 64)) * sc2;                 // (meaningful in lanes fr == 0)
+    f32x4_t p_pp, p_pc, p_cp = zero, p_cc = zero;
+    float l = 0.f, lc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        p_pp[r] = exp2_fast_t(fmaf(s_pp[r], sc2, -m));
+        l += p_pp[r];
+        p_pc[r] = exp2_fast_t(fmaf(s_pc[r], sc2, -mc));
+        lc += p_pc[r];
+    }
+    if (fg == 0) {
+        p_cp[0] = exp2_fast_t(fmaf(s_cp[0], sc2, -m));
+        l += p_cp[0];
+        if (g == 0) { p_cc[0] = exp2_fast_t(fmaf(s_cc, sc2, -mc)); lc += p_cc[0]; }
+    }
+    l = t_grp_sum(l);
+    lc = t_grp_sum(lc);
+    const bf16x8_t bP = t_pack8(p_pp, p_cp), bC = t_pack8(p_pc, p_cc);
+    const float inv = 1.0f / l;
+    float* dst = a.ws + (((long long)g * nb + b) * a.H + h) * 66;
+    f32x4_t o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8_t av = t_afrag(sV, cV, dt, fr, fg);
+        o[dt] = t_mfma(av, bP, zero);
+        const f32x4_t oc = t_mfma(av, bC, zero);
+        if (c0) *reinterpret_cast<f32x4_t*>(dst + 2 + dt * 16 + fg * 4) = oc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // every lane's transposing reads of the V image are done
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] *= inv;                      // (per-lane factor: the row's 1 / l)
+    t_store_rows(sV, rO, valid ? (unsigned int)(row * a.ldo + a.ooff + h * HD + fg * 8) * 2u : T_OOB, o, 1.0f, fr, fg);
+    if (a.lse && valid && fg == 0) a.lse[(long long)row * a.H + h] = m * T_LN2 + __logf(l);
+    if (lane == 0) { dst[0] = mc * T_LN2; dst[1] = lc; }
+}
+
+// the CLS query's G partial states (m, l, o[64]) -> its output row and lse.  One workgroup per (sample, head); the four waves take
+// the groups round-robin with eight loads in flight (G = 196 for the time attention: a single wave's serial loop is 2 x 196 dependent
+// round trips), combined in wave order: the result does not depend on scheduling.
+constexpr int CW = 16;                          // waves of the combine workgroup
+__global__ __launch_bounds__(64 * CW) void attn_cls_combine_kernel(const AttnArgs a, int nb) {
+    __shared__ float red[CW][66];
+    const int b = blockIdx.x, h = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long gstride = (long long)nb * a.H * 66;
+    const float* base = a.ws + ((long long)b * a.H + h) * 66;
+    float M = -INFINITY;
+    for (int g = threadIdx.x; g < a.G; g += 64 * CW) M = fmaxf(M, base[g * gstride]);
+    M = wave_max(M);
+    red[w][0] = M;
+    __syncthreads();
+    M = red[0][0];
+#pragma unroll
+    for (int i = 1; i < CW; ++i) M = fmaxf(M, red[i][0]);
+    __syncthreads();
+    float L = 0.f, o = 0.f;
+    for (int g0 = w; g0 < a.G; g0 += CW * 8) {
+        float mm[8], ll[8], oo[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int g = g0 + CW * u;
+            const float* src = base + (g < a.G ? g : 0) * gstride;
+            mm[u] = g < a.G ? src[0] : -INFINITY; ll[u] = src[1]; oo[u] = src[2 + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float c = __expf(mm[u] - M);                       // (groups past the end: exp(-inf) = 0)
+            L += ll[u] * c;
+            o += oo[u] * c;
+        }
+    }
+    red[w][1] = L;
+    red[w][2 + lane] = o;
+    __syncthreads();
+    if (w != 0) return;
+    L = red[0][1];
+    o = red[0][2 + lane];
+#pragma unroll
+    for (int i = 1; i < CW; ++i) { L += red[i][1]; o += red[i][2 + lane]; }
+    const long long row = (long long)b * a.extra_bs + a.extra_row;
+    reinterpret_cast<bf16_t*>(a.O)[row * a.ldo + a.ooff + h * HD + lane].v = f2bf(o / L);
+    if (a.lse && lane == 0) a.lse[row * a.H + h] = M + __logf(L);
 }
 
 }  // namespace egv
@@ -233,4 +400,33 @@ int egv_attn_time_bwd(const AttnArgs& a, int B, hipStream_t st) {
     hipLaunchKernelGGL(attn_time_bwd_kernel, dim3((nprob + 3) / 4), dim3(256), lds, st, a, nprob, (unsigned int)qkv_b, (unsigned int)o_b,
                        (unsigned int)dq_b);
     return 1;
+}
+
+static bool time_fwd_shape_ok(const AttnArgs& a) {
+    const bool same = a.q.bs == a.k.bs && a.q.base == a.k.base && a.q.gs == a.k.gs && a.q.is == a.k.is && a.q.n == a.k.n;
+    auto ok8 = [](int x) { return (x % 8) == 0; };
+    return same && a.q.n <= 16 && a.q.n >= 1 && a.extra && a.extra_row == 0 && a.ws && !a.mask && a.drop_p <= 0.f && a.nsplit == 1 && a.O &&
+           ok8(a.ldq) && ok8(a.ldk) && ok8(a.ldv) && ok8(a.ldo) && ok8(a.qoff) && ok8(a.koff) && ok8(a.voff) && ok8(a.ooff) && a.ldq == a.ldk &&
+           a.ldq == a.ldv;
+}
+bool egv_attn_time_fwd_ok(const AttnArgs& a, int B) {
+    static const bool on = !getenv("EGV_ATTN_TIME_FUSED") || atoi(getenv("EGV_ATTN_TIME_FUSED")) != 0;
+    if (!on || !time_fwd_shape_ok(a)) return false;
+    const long long rows = (long long)B * a.extra_bs;
+    return rows * a.ldq * 2 < (1LL << 31) && rows * a.ldo * 2 < (1LL << 31);
+}
+// 1 if enqueued: O / lse of the group rows, the CLS query's partial states in a.ws AND their combination (O / lse of the CLS row)
+int egv_attn_time_fwd(const AttnArgs& a, int B, hipStream_t st) {
+    if (!egv_attn_time_fwd_ok(a, B)) return 0;
+    const long long rows = (long long)B * a.extra_bs;
+    const int nprob = B * a.G * a.H;
+    const size_t lds = 4 * (size_t)(T_IMG + 128);
+    hipLaunchKernelGGL(attn_time_fwd_kernel, dim3((nprob + 3) / 4), dim3(256), lds, st, a, nprob, B, (unsigned int)(rows * a.ldq * 2),
+                       (unsigned int)(rows * a.ldo * 2));
+    hipLaunchKernelGGL(attn_cls_combine_kernel, dim3(B, a.H), dim3(64 * CW), 0, st, a, B);
+    return 1;
+}
+
+void egv_attn_cls_combine_launch(const AttnArgs& a, int B, hipStream_t st) {
+    hipLaunchKernelGGL(attn_cls_combine_kernel, dim3(B, a.H), dim3(64 * CW), 0, st, a, B);
 }

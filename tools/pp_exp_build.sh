@@ -11,6 +11,6 @@ for v in "$@"; do
 done
 wait
 for v in "$@"; do
-  hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/exp_libs/libegovlp_hip_exp$v.so build/egv_gemm.o build/egv_gemm2.o build/egv_gemm3_exp$v.o build/egv_gemm4.o build/egv_gemm5.o build/egv_mx.o build/egv_norm.o build/egv_attn.o build/egv_attn_mfma.o build/egv_attn_time.o build/egv_misc.o build/egv_optim.o build/egv_api.o build/egv_block.o
+  hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/exp_libs/libegovlp_hip_exp$v.so build/egv_gemm.o build/egv_gemm2.o build/egv_gemm3_exp$v.o build/egv_gemm4.o build/egv_gemm5.o build/egv_mx.o build/egv_norm.o build/egv_attn.o build/egv_attn_mfma.o build/egv_attn_time.o build/egv_attn_space.o build/egv_misc.o build/egv_optim.o build/egv_api.o build/egv_block.o
 done
 echo done
