@@ -3,8 +3,8 @@
 // "(b h f) n d").  One workgroup of four waves per (sample, frame, head); built like the time-attention kernels of
 // egv_attn_time.hip, for a key side of up to NT 16-row tiles:
 //   * the other side of a phase sits in LDS as ROW-MAJOR images (144-byte pitch: conflict-free 16-byte row reads) copied as stored,
-//     16 bytes per lane -- no register transposes; rows >= n + 1 are zeros; the CLS row is row n of every image, so it needs no
-//     tile, launch or code path of its own: as a key it is one more column, as a query one more row of the last query tile (whose
+//     16 bytes per lane -- no register transposes; rows >= n + 1 are zeros; the CLS row is row 0 of every image, so it needs no
+//     tile, launch or code path of its own: as a key it is one more column, as a query one more row of the first query tile (whose
 //     result leaves as a per-group partial instead of an output row; the (CLS, CLS) pair is counted in group 0 only);
 //   * A operands of the first products are 16-byte row reads, the transposed A operands of the second products (V^T, K^T, dO^T,
 //     Q^T) come from the same images with ds_read_b64_tr_b16; the C layout of a first product is the B operand of the second
@@ -97,8 +97,9 @@ __device__ __forceinline__ SGeom s_geom(const AttnArgs& a) {
     q.cls = (int)(q.b * a.extra_bs + a.extra_row);
     return q;
 }
-// token-matrix row of index i of the group's row list [patch rows 0 .. n-1 ; CLS row], -1 past it
-__device__ __forceinline__ int s_row_of(const SGeom& q, int i) { return i < q.n ? q.row0 + i * q.is : (i == q.n ? q.cls : -1); }
+// token-matrix row of index i of the group's row list [CLS row ; patch rows 0 .. n-1], -1 past it (the CLS row first: the order in
+// which attn_fwd_mfma_kernel sums the keys -- outputs stay bit-identical to that kernel's)
+__device__ __forceinline__ int s_row_of(const SGeom& q, int i) { return i == 0 ? q.cls : (i <= q.n ? q.row0 + (i - 1) * q.is : -1); }
 
 // copy rows [0, NT*16) of the group's row list (one head's 64 columns of `base`) into an image
 template <int NT>
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(64 * SNW) void attn_space_fwd_kernel(const AttnArgs
     const int fr = lane & 15, fg = lane >> 4;
     unsigned char* scr = smem + 2 * IMG + w * 16 * SP;
     const SGeom q = s_geom(a);
-    const int nk = q.n + 1;                                        // keys incl. the CLS key (index n)
+    const int nk = q.n + 1;                                        // keys incl. the CLS key (index 0)
     const float sc2 = a.scale * S_LOG2E;
     auto mk = [&](const void* p, unsigned int bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000); };
     const __amdgpu_buffer_rsrc_t rQ = mk(a.Q, qkv_bytes), rK = mk(a.K, qkv_bytes), rV = mk(a.V, qkv_bytes), rO = mk(a.O, o_bytes);
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(64 * SNW) void attn_space_fwd_kernel(const AttnArgs
         const unsigned int on = qoff(qt + SNW);
         const u32x4_t nq0 = __builtin_amdgcn_raw_buffer_load_b128(rQ, on, 0, 0), nq1 = __builtin_amdgcn_raw_buffer_load_b128(rQ, on == S_OOB ? S_OOB : on + 64u, 0, 0);
         const int qi = qt * 16 + fr;
-        const bool is_cls = qi == q.n;                              // this lane's query is the CLS query
+        const bool is_cls = qi == 0;                                // this lane's query is the CLS query
         f32x4_t s[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -166,11 +167,11 @@ __global__ __launch_bounds__(64 * SNW) void attn_space_fwd_kernel(const AttnArgs
         float m = -INFINITY;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            if (t * 16 + 16 > q.n) {                               // uniform: tiles that hold the CLS key or padding
+            if (t == 0 || t * 16 + 16 > nk) {                      // uniform: tiles that hold the CLS key or padding
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = t * 16 + fg * 4 + r;
-                    const bool dead = key >= nk || (key == q.n && is_cls && q.g != 0);   // the (CLS, CLS) pair belongs to group 0
+                    const bool dead = key >= nk || (key == 0 && is_cls && q.g != 0);   // the (CLS, CLS) pair belongs to group 0
                     s[t][r] = dead ? -INFINITY : s[t][r];
                 }
             }
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(64 * SNW) void attn_space_fwd_kernel(const AttnArgs
             for (int dt = 0; dt < 4; ++dt) o[dt] = s_mfma(s_trfrag(sV, 2 * kk, 2 * kk + 1 < NT, dt, fr, fg), pf, o[dt]);
         }
         const int row = s_row_of(q, qi);
-        const bool patch = qi < q.n;
+        const bool patch = qi >= 1 && qi <= q.n;
         if (is_cls && a.ws) {                                       // the CLS query's partial state over this group's keys
             float* dst = a.ws + (((long long)q.g * nb + q.b) * a.H + q.h) * 66;
 #pragma unroll
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(64 * SNW, (NT <= 14 ? 4 : 2)) void attn_space_bwd_k
     const int fr = lane & 15, fg = lane >> 4;
     unsigned char* scr = smem + 2 * IMG + 2 * NT * 16 * 4 + w * 16 * SP;
     const SGeom q = s_geom(a);
-    const int nk = q.n + 1;                                        // rows of the list: patches + the CLS row (index n)
+    const int nk = q.n + 1;                                        // rows of the list: the CLS row (index 0) + patches
     const int nlt = (nk + 15) >> 4;                                // live tiles
     const float sc2 = a.scale * S_LOG2E;
     auto mk = [&](const void* p, unsigned int bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000); };
@@ -243,7 +244,6 @@ __global__ __launch_bounds__(64 * SNW, (NT <= 14 ? 4 : 2)) void attn_space_bwd_k
     };
     const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
     float* pw = a.ws ? a.ws + ((long long)(q.b * a.G + q.g) * a.H + q.h) * 3 * HD : nullptr;
-    const int ct = q.n >> 4, cr = q.n & 15;                        // the CLS row's tile and row inside it
 
     // ================= phase A: keys in LDS, every wave's query tiles -> dQ (lane = query) =================
     u32x4_t q0, q1, g0, g1, o0, o1;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64 * SNW, (NT <= 14 ? 4 : 2)) void attn_space_bwd_k
         ld2(rO, foff(qt + SNW, a.ldo, a.ooff), no0, no1);
         const int qi = qt * 16 + fr;
         const int row = s_row_of(q, qi);
-        const bool patch = qi < q.n, is_cls = qi == q.n;
+        const bool patch = qi >= 1 && qi <= q.n, is_cls = qi == 0;
         const float lse2 = row >= 0 ? a.lse[(long long)row * a.H + q.h] * S_LOG2E : INFINITY;    // past the list: exp2(s - inf) = 0
         const float dl = s_grp_sum(s_dot16(g0, g1, o0, o1));
         if (fg == 0) { sL[qi] = lse2; sD[qi] = dl; }
@@ -281,11 +281,11 @@ __global__ __launch_bounds__(64 * SNW, (NT <= 14 ? 4 : 2)) void attn_space_bwd_k
                         const f32x4_t dp = s_mfma(v1, s_bf(g1), s_mfma(v0, s_bf(g0), zero));
 #pragma unroll
                         for (int r = 0; r < 4; ++r) ds[u][r] = s_exp2(fmaf(sc[r], sc2, -lse2)) * (dp[r] - dl);
-                        if (t * 16 + 16 > q.n) {                    // uniform: the tile holds the CLS key or padding
+                        if (t == 0 || t * 16 + 16 > nk) {           // uniform: the tile holds the CLS key or padding
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const int key = t * 16 + fg * 4 + r;
-                                const bool dead = key >= nk || (key == q.n && is_cls && q.g != 0);   // (CLS, CLS): group 0 only
+                                const bool dead = key >= nk || (key == 0 && is_cls && q.g != 0);   // (CLS, CLS): group 0 only
                                 ds[u][r] = dead ? 0.f : ds[u][r];
                             }
                         }
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64 * SNW, (NT <= 14 ? 4 : 2)) void attn_space_bwd_k
         ld2(rV, foff(kt + SNW, a.ldv, a.voff), nv0, nv1);
         const int ki = kt * 16 + fr;
         const int row = s_row_of(q, ki);
-        const bool patch = ki < q.n, is_cls = ki == q.n;
+        const bool patch = ki >= 1 && ki <= q.n, is_cls = ki == 0;
         f32x4_t dv[4] = {zero, zero, zero, zero}, dk[4] = {zero, zero, zero, zero};
 #pragma unroll
         for (int kk = 0; kk < NP; ++kk) {
@@ -338,13 +338,7 @@ __global__ __launch_bounds__(64 * SNW, (NT <= 14 ? 4 : 2)) void attn_space_bwd_k
                         pp[u][r] = p;
                         ds[u][r] = p * (dp[r] - d4[r]);
                     }
-                    if (t == ct && q.g != 0) {                     // uniform: the tile with the CLS query; (CLS, CLS) is group 0's
-                        if (is_cls && fg * 4 <= cr && cr < fg * 4 + 4) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                if (fg * 4 + r == cr) { pp[u][r] = 0.f; ds[u][r] = 0.f; }
-                        }
-                    }
+                    if (t == 0 && q.g != 0 && is_cls && fg == 0) { pp[u][0] = 0.f; ds[u][0] = 0.f; }   // (CLS query, CLS key) is group 0's
                 }
             }
             const bf16x8_t bp = s_pack8(pp[0], pp[1]), bd = s_pack8(ds[0], ds[1]);
