@@ -389,6 +389,10 @@ extern "C" long long egv_vblock_ws_bytes(const egv_vblock_desc* d, int backward)
     const size_t S = 1 + (size_t)d->F * d->N, M = (size_t)d->B * S, D = d->D, Hd = d->Hd, H = d->H;
     Divided dv{d->dtype, d->B, d->F, d->N, d->H, d->D, (int)S, (int)M, true};
     long long attn = dv.ws_bytes();
+    {   // the time attention's groups (one per patch position) need the larger CLS-partial workspace
+        Divided dvt{d->dtype, d->B, d->F, d->N, d->H, d->D, (int)S, (int)M, false};
+        if (dvt.ws_bytes() > attn) attn = dvt.ws_bytes();
+    }
     if (d->L > 0) {
         Plain p{d->dtype, d->B, d->H, d->D, (int)S, d->L, 0.125f, 0.f, 0u, nullptr};
         if (p.ws_bytes() > attn) attn = p.ws_bytes();
@@ -419,7 +423,7 @@ extern "C" int egv_vblock_fwd(const egv_vblock_desc* d) {
     void* st = d->stream;
     Bump ws(d->ws, d->ws_bytes);
     Divided dvt{dt, d->B, d->F, d->N, d->H, D, S, M, false}, dvs{dt, d->B, d->F, d->N, d->H, D, S, M, true};
-    long long awb = dvs.ws_bytes();
+    long long awb = dvs.ws_bytes() > dvt.ws_bytes() ? dvs.ws_bytes() : dvt.ws_bytes();
     Plain px{dt, d->B, d->H, D, S, d->L, 0.125f, 0.f, 0u, d->y_mask};
     if (fused && px.ws_bytes() > awb) awb = px.ws_bytes();
     void* aws = ws.take((size_t)awb);
@@ -497,7 +501,7 @@ extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
     Fork fk(d->stream, d->stream2, M);
     Bump ws(d->ws, d->ws_bytes);
     Divided dvt{dt, d->B, d->F, d->N, d->H, D, S, M, false}, dvs{dt, d->B, d->F, d->N, d->H, D, S, M, true};
-    long long awb = dvs.ws_bytes();
+    long long awb = dvs.ws_bytes() > dvt.ws_bytes() ? dvs.ws_bytes() : dvt.ws_bytes();
     Plain px{dt, d->B, d->H, D, S, d->L, 0.125f, 0.f, 0u, d->y_mask};
     if (fused && px.ws_bytes() > awb) awb = px.ws_bytes();
     void* aws = ws.take((size_t)awb);
