@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get('EGV_LIB_PATH') or os.path.join(_HERE, 'libegovlp_hip.
 
 ABI_VERSION = 4
 EGV_F32, EGV_BF16 = 0, 1
-ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH, ACT_GELU_D = 0, 1, 2, 3, 4
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_longlong, C.c_float
 

@@ -120,6 +120,15 @@ __device__ __forceinline__ float dgelu_fast_f(float x) {
     return (x < 0.f ? q : 1.0f - q) + x * 0.39894228040143267794f * e;
 }
 
+// GELU and its derivative from ONE evaluation of the tail / density (the pair the EGV_ACT_GELU_D epilogues store)
+__device__ __forceinline__ void gelu_pair_fast_f(float x, float& g, float& d) {
+    float e;
+    const float q = phi_tail_q(x, e);
+    const float cdf = x < 0.f ? q : 1.0f - q;
+    g = x * cdf;
+    d = cdf + x * 0.39894228040143267794f * e;
+}
+
 // bijective XCD-aware remap of a linear workgroup id (cdna_hip_programming.md §5 template):
 // consecutive logical tiles land on the same XCD (= same L2) instead of round-robin over the 8 XCDs.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

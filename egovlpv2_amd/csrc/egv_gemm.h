@@ -39,7 +39,7 @@ struct GemmArgs {
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == 1) return gelu_f(v);
+    if (act == 1 || act == 4) return gelu_f(v);
     if (act == 2) return fmaxf(v, 0.0f);
     if (act == 3) return tanhf(v);
     return v;
@@ -48,6 +48,7 @@ __device__ __forceinline__ float apply_dact(float aux, int dact) {
     if (dact == 1) return dgelu_f(aux);
     if (dact == 2) return aux > 0.0f ? 1.0f : 0.0f;
     if (dact == 3) return 1.0f - aux * aux;
+    if (dact == 4) return aux;                   // EGV_ACT_GELU_D: aux already holds gelu'(x)
     return 1.0f;
 }
 
@@ -71,14 +72,22 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& g, OutT* C, int m
             if (full || n + r < g.N) v[r] += e.bias[n + r];
     }
     if (PRE) {
-        if (full && rvec) st4(PRE + ro, v);
+        float pv[4] = {v[0], v[1], v[2], v[3]};
+        if (e.act == 4) {                        // EGV_ACT_GELU_D: the saved tensor is gelu'(x)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (sizeof(T) == 2) { float gg; gelu_pair_fast_f(v[r], gg, pv[r]); }
+                else pv[r] = dgelu_f(v[r]);
+            }
+        }
+        if (full && rvec) st4(PRE + ro, pv);
         else
             for (int r = 0; r < 4; ++r)
-                if (n + r < g.N) Elem<T>::st(PRE + ro + r, v[r]);
+                if (n + r < g.N) Elem<T>::st(PRE + ro + r, pv[r]);
     }
     if (e.act) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (sizeof(T) == 2 && e.act == 1) ? gelu_fast_f(v[r]) : apply_act(v[r], e.act);   // bf16 mode: the same GELU form in every kernel
+        for (int r = 0; r < 4; ++r) v[r] = (sizeof(T) == 2 && (e.act == 1 || e.act == 4)) ? gelu_fast_f(v[r]) : apply_act(v[r], e.act);   // bf16 mode: the same GELU form in every kernel
     }
     if (e.gate) {
 #pragma unroll

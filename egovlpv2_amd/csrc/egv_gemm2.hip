@@ -155,11 +155,18 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmArgs g) {
                 const size_t ro = (size_t)m * e.ldr + ncol;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = v[k] * e.scale + bias8[k];
-                if (PRE) {
+                if (PRE && e.act == 4) {                           // EGV_ACT_GELU_D: save gelu'(x), return gelu(x)
+                    float dv[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) gelu_pair_fast_f(v[k], v[k], dv[k]);
+                    u32x4_t o = {pack2f(dv[0], dv[1]), pack2f(dv[2], dv[3]), pack2f(dv[4], dv[5]), pack2f(dv[6], dv[7])};
+                    *reinterpret_cast<u32x4_t*>(PRE + ro) = o;
+                } else if (PRE) {
                     u32x4_t o = {pack2f(v[0], v[1]), pack2f(v[2], v[3]), pack2f(v[4], v[5]), pack2f(v[6], v[7])};
                     *reinterpret_cast<u32x4_t*>(PRE + ro) = o;
                 }
-                if (e.act == 1) {                                  // GELU: bf16-mode fast form (egv_common.h)
+                if (PRE && e.act == 4) {
+                } else if (e.act == 1 || e.act == 4) {             // GELU: bf16-mode fast form (egv_common.h)
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] = gelu_fast_f(v[k]);
                 } else if (e.act) {

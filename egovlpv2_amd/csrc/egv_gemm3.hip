@@ -342,8 +342,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const f32x4_t a0 = acc[s * IM + i][t * 2 + 0], a1 = acc[s * IM + i][t * 2 + 1];
-                    pr[t] = u32x4_t{pack_bf16x2(a0[0] + bias8[t][0], a0[1] + bias8[t][1]), pack_bf16x2(a0[2] + bias8[t][2], a0[3] + bias8[t][3]),
-                                    pack_bf16x2(a1[0] + bias8[t][4], a1[1] + bias8[t][5]), pack_bf16x2(a1[2] + bias8[t][6], a1[3] + bias8[t][7])};
+                    float pv[8] = {a0[0] + bias8[t][0], a0[1] + bias8[t][1], a0[2] + bias8[t][2], a0[3] + bias8[t][3],
+                                   a1[0] + bias8[t][4], a1[1] + bias8[t][5], a1[2] + bias8[t][6], a1[3] + bias8[t][7]};
+                    if (e.act == 4) {                             // EGV_ACT_GELU_D: the saved tensor is gelu'(x) (one more FMA beside the GELU below)
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { float gg; gelu_pair_fast_f(pv[k], gg, pv[k]); }
+                    }
+                    pr[t] = u32x4_t{pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]), pack_bf16x2(pv[4], pv[5]), pack_bf16x2(pv[6], pv[7])};
                 }
                 pair_swap(pr[0], pr[1], f, sec);
 #if EGV_PP_EXP
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                     v[4 + k] = acc[s * IM + i][t * 2 + 1][k] + bias8[t][4 + k];
                 }
                 if (ACTK) {
-                    if (e.act == 1) {
+                    if (e.act == 1 || e.act == 4) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) v[k] = gelu_fast_f(v[k]);
                     } else if (e.act) {

@@ -35,6 +35,9 @@ extern "C" {
 #define EGV_ACT_GELU 1 /* exact erf GELU: nn.GELU video_transformer.py:43, ACT2FN["gelu"] roberta.py:402 */
 #define EGV_ACT_RELU 2 /* txt_proj / vid_proj, model.py:105-115 */
 #define EGV_ACT_TANH 3 /* heads.Pooler, heads.py:15-25 */
+#define EGV_ACT_GELU_D 4 /* GELU whose saved tensor is the DERIVATIVE gelu'(x) instead of x: as act (with pre) the forward GEMM stores
+                           gelu'(acc + bias) in pre; as dact the data-gradient GEMM multiplies by aux as it stands.  Same bytes, but
+                           the backward epilogue (video_transformer.py:43 under autograd) has no erf / exp left to compute */
 
 int egv_abi_version(void);
 const char* egv_last_error(void);

@@ -135,6 +135,36 @@ def test_mlp(ops, dtype):
         assert _rel(a.grad, bb.grad) < _tol(dtype, True) * 1.5
 
 
+@pytest.mark.parametrize('M,N,K', [(777, 520, 128), (4000, 1032, 256), (25096, 3072, 768)])
+def test_gelu_saved_derivative_epilogues_bf16(ops, M, N, K):
+    """EGV_ACT_GELU_D (the video MLP in the bf16 mode): the forward GEMM returns gelu(xW^T + b) and saves gelu'(xW^T + b) where
+    EGV_ACT_GELU saves the pre-activation; the data-gradient GEMM with dact = EGV_ACT_GELU_D multiplies by the saved tensor.  On all
+    three GEMM kernels (generic, DMA ring, persistent): same output as the EGV_ACT_GELU call, saved tensor and gradient vs fp64."""
+    from egovlpv2_amd import _lib as L
+    x = _rnd((M, K), torch.bfloat16, 1.0, 1).cuda()
+    w = _rnd((N, K), torch.float32, 0.06, 2).cuda().to(torch.bfloat16)
+    b = _rnd((N,), torch.float32, 0.3, 3).cuda()
+    y, pre = torch.empty(M, N, device='cuda', dtype=torch.bfloat16), torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+    y2, dsave = torch.empty_like(y), torch.empty_like(y)
+    kw = dict(M=M, N=N, K=K, lda=K, ldb=K, ldc=N)
+    ops.gemm(x, w, y, bias=b, act=L.ACT_GELU, pre=pre, **kw)
+    ops.gemm(x, w, y2, bias=b, act=L.ACT_GELU_D, pre=dsave, **kw)
+    assert _rel(y2, y.double().cpu()) < 2e-3                          # (the compiler contracts x * Phi(x) differently beside the derivative: not bit-equal)
+    rows = torch.cat([torch.arange(0, min(M, 300)), torch.arange(max(0, M - 300), M)]).unique()
+    z = x[rows.cuda()].double().cpu() @ w.double().cpu().t() + b.double().cpu()
+    dref = 0.5 * (1 + torch.erf(z / 2 ** 0.5)) + z * torch.exp(-0.5 * z * z) / (2 * torch.pi) ** 0.5
+    assert _rel(dsave[rows.cuda()], dref) < 4e-3
+    # data gradient: dx = (dy W2) * saved, against the EGV_ACT_GELU form on the saved pre-activation and against fp64
+    dy = _rnd((M, K), torch.bfloat16, 1.0, 4).cuda()
+    dz1, dz2 = torch.empty(M, N, device='cuda', dtype=torch.bfloat16), torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+    kd = dict(M=M, N=N, K=K, lda=K, ldb=K, ldc=N)
+    ops.gemm(dy, w, dz1, aux=pre, dact=L.ACT_GELU, **kd)
+    ops.gemm(dy, w, dz2, aux=dsave, dact=L.ACT_GELU_D, **kd)
+    g64 = (dy[rows.cuda()].double().cpu() @ w.double().cpu().t()) * dref
+    assert _rel(dz2[rows.cuda()], g64) < 6e-3
+    assert _rel(dz1[rows.cuda()], g64) < 6e-3
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('D', [768, 1024])
 def test_layernorm(ops, dtype, D):
