@@ -125,6 +125,7 @@ def main():
     ap.add_argument('--text-len', type=int, default=32)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--drop-rate', type=float, default=0.1, help='RoBERTa dropout in the train step (pretrained roberta-base config: 0.1)')
+    ap.add_argument('--seed-offset', type=int, default=0, help='added to the per-rank data / RNG seeds (1234 + rank, 1 + rank): a 1-rank run with offset r sees the batch of rank r of a multi-rank run (test aid)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gemm-events', action='store_true')
     ap.add_argument('--force-ddp', action='store_true', help='run the data-parallel path (process group, gradient sync) even at world size 1 (test aid)')
@@ -181,15 +182,16 @@ def main():
     elif use_dist:
         from egovlpv2_amd.trainer.grad_sync import FlatGradSync
         gsync = FlatGradSync(model)               # all-reduce of the flat per-block gradient buffers as they complete
-    data, noun, verb = make_batch(cfg, a.batch, a.text_len, 1234 + rank)
+    data, noun, verb = make_batch(cfg, a.batch, a.text_len, 1234 + rank + a.seed_offset)
+    n_mlm_labels = int(((data['text_mlm_labels'] >= 0) & (data['text_mlm_labels'] < cfg.vocab)).sum())
     data = {'video': data['video'].to(dev), 'text': {k: v.to(dev) for k, v in data['text'].items()},
             'text_mlm_ids': data['text_mlm_ids'].to(dev), 'text_mlm_labels': data['text_mlm_labels'].to(dev)}
     noun, verb = noun.to(dev), verb.to(dev)
     args = types.SimpleNamespace(world_size=world, rank=rank)
     loss_fn = EgoNCE()
     conf = {'loss': {'type': 'EgoNCE'}}
-    np.random.seed(1 + rank)
-    torch.manual_seed(1 + rank)
+    np.random.seed(1 + rank + a.seed_offset)
+    torch.manual_seed(1 + rank + a.seed_offset)
 
     optimizer = scheduler = None
     if a.optimizer:
@@ -258,10 +260,16 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     losses = {k: round(float(v.detach()), 5) for k, v in ld.items()}
+    mlm_counts = torch.tensor([n_mlm_labels], dtype=torch.int64, device=dev)
+    if use_dist:
+        gathered = [torch.zeros_like(mlm_counts) for _ in range(world)]
+        dist.all_gather(gathered, mlm_counts)
+        mlm_counts = torch.cat(gathered)
+    losses['mlm_labels_per_rank'] = [int(x) for x in mlm_counts.tolist()]     # weights of the per-rank MLM means in the global mean
 
     roof = None
     if use_events and rank == 0:
-        kinds = {0: 'gemm_kernel<bf16,NT> (generic 128x128)', 1: 'gemm_kernel<bf16,NN> (generic)', 2: 'gemm_kernel<bf16,TN> (generic)',
+        kinds = {-1: 'launch declined by a one-pass attention entry point (no kernel ran: the caller took another path)', 0: 'gemm_kernel<bf16,NT> (generic 128x128)', 1: 'gemm_kernel<bf16,NN> (generic)', 2: 'gemm_kernel<bf16,TN> (generic)',
                  4: 'gemm_kernel<f32,NT>', 5: 'gemm_kernel<f32,NN>', 6: 'gemm_kernel<f32,TN>',
                  8: 'gemm_ring_kernel<256x128> (NT fwd+dgrad, DMA ring)', 10: 'gemm_wgrad_ring_kernel (TN wgrad, 256x128 DMA ring)',
                  12: 'gemm_pp_kernel (NT fwd+dgrad, persistent ping-pong 256x256)', 13: 'gemm_ring_kernel<128x128> (NT, text-side grids)',

@@ -13,7 +13,9 @@ import torch  # noqa: F401  -- must be imported first: the HIP runtime torch bun
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # EGV_LIB_PATH: an alternative build of the SAME library (kernel experiments of tools/); the product path never sets it
-LIB_PATH = os.environ.get('EGV_LIB_PATH') or os.path.join(_HERE, 'libegovlp_hip.so')
+from . import switches as _sw  # noqa: E402
+
+LIB_PATH = _sw.value('EGV_LIB_PATH') or os.path.join(_HERE, 'libegovlp_hip.so')
 
 ABI_VERSION = 4
 EGV_F32, EGV_BF16 = 0, 1
@@ -92,6 +94,7 @@ BLOCK_TAIL = 8
 PROTOTYPES = {
     'egv_abi_version': (i32, []),
     'egv_last_error': (C.c_char_p, []),
+    'egv_config_dump': (C.c_char_p, []),
     'egv_gemm': (i32, [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     'egv_gemm_wgrad_workspace_bytes': (i64, [i32, i32, i32]),
     'egv_gemm_wgrad': (i32, [i32, i32, i32, i32, vp, i32, vp, i32, vp, vp, f32, vp, vp, i64, vp]),
@@ -100,6 +103,7 @@ PROTOTYPES = {
     'egv_layernorm_fwd': (i32, [i32, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     'egv_layernorm_bwd_workspace_bytes': (i64, [i32, i32]),
     'egv_layernorm_bwd': (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
+    'egv_layernorm_bwd2': (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     'egv_colsum_workspace_bytes': (i64, [i32, i32]),
     'egv_colsum': (i32, [i32, vp, i32, i32, i32, vp, f32, vp, vp, vp]),
     'egv_dot': (i32, [i32, vp, vp, i64, vp, f32, vp, vp]),

@@ -19,6 +19,75 @@ void egv_set_error(const char* fmt, ...) {
 
 extern "C" int egv_abi_version(void) { return 4; }
 
+// ---- switches --------------------------------------------------------------------------------------------------------------
+// Every run-time switch of the library in ONE table (name, default, what it does).  The defaults are the configuration that is
+// benchmarked and tested; an environment variable of the same name overrides one switch (A/B aid).  egv_cfg_* is the only place
+// that reads the environment: a name that is not in the table, or a call site that states another default than the table, is a
+// programming error and aborts.  egv_config_dump() lists name, default and current value (tests/test_abi_and_host.py pins the
+// defaults; INTEGRATION.md explains the switches).
+#include <cstdlib>
+#include <cstring>
+#include <string>
+namespace {
+struct Switch { const char* name; double def; const char* doc; };
+const Switch g_switches[] = {
+    {"EGV_ATTN_TIME_FUSED", 1, "one-launch forward / backward of the <= 16-row attention groups (time attention), egv_attn_time.hip"},
+    {"EGV_ATTN_SPACE_NEW", 1, "space attention on row-major LDS images, egv_attn_space.hip (0: the kernels of egv_attn_mfma.hip)"},
+    {"EGV_ATTN_FUSED_CLS", 1, "the group launches also serve the CLS row (per-group partials + one small sum)"},
+    {"EGV_ATTN_FUSED_BWD", 1, "one-launch attention backward where a kernel covers the shape (0: dQ + dK/dV kernel pair)"},
+    {"EGV_WGRAD_PP", 1, "ping-pong 256x256 weight-gradient kernel (0: 256x128 ring kernel)"},
+    {"EGV_WGRAD_ITEMS", 224, "(tile, split) items of a one-gradient-per-launch weight gradient: 7/8 of the CUs"},
+    {"EGV_GEMM_PP", 1, "persistent ping-pong GEMM for large grids (0: DMA-ring kernels only)"},
+    {"EGV_PP_STAMPS", 0, "instrumentation build only: per-K-tile cycle stamps of the persistent GEMM"},
+    {"EGV_PP_CUS", 0, "cap of the persistent GEMM's grid (0: all CUs)"},
+    {"EGV_PP_LIMIT_SLACK", 16, "CUs a persistent grid may take beyond its CU limit when that removes a round of its tile walk"},
+    {"EGV_PP_BM192", 1, "192-row tiles where they shorten the walk"},
+    {"EGV_PP_192_PENALTY", 1.06, "cost factor of a 192-row tile relative to 3/4 of a 256-row tile"},
+    {"EGV_PP_TRIM", 1, "grid trimmed to the smallest size that keeps the round count"},
+    {"EGV_PP_RES_MINK", 1536, "shortest K for which a residual-epilogue GEMM takes the persistent kernel on 256-row tiles"},
+    {"EGV_LN_BLOCKS", 512, "workgroup cap of the LayerNorm backward"},
+    {"EGV_LN_PACKED", 1, "packed four-rows-per-wave LayerNorm backward (bf16, D = 768 / 1024)"},
+    {"EGV_GELU_DERIV", 0, "video MLP saves gelu'(x) instead of x in the bf16 mode (EGV_ACT_GELU_D; measured slower, off)"},
+    {"EGV_WGRAD_GROUP", 1, "all weight gradients of a video block call as one persistent grouped launch"},
+    {"EGV_WGRAD_CUS", 0, "CU grant of the grouped weight-gradient launch (0: 2/3 CU per output tile)"},
+    {"EGV_WGRAD_DEFER_MAXTILES", 192, "largest group whose launch is left running beside the next block call"},
+    {"EGV_WGRAD_MAIN_LIMIT", 0, "CU limit of the calling stream's grids beside a grouped launch (0: the CUs the grant leaves)"},
+    {"EGV_TEXT_WGRAD_GROUP", 1, "weight gradients over the text rows of a RoBERTa layer as one grouped launch"},
+    {"EGV_MX_EPI_QUANT", 1, "MX-fp8 path: GELU / GELU' epilogues also emit the quantised form of their output"},
+    {"EGV_LN_MX", 1, "MX-fp8 path: LayerNorm forward also writes the quantised form of its output"},
+};
+const Switch* find_switch(const char* name) {
+    for (const Switch& s : g_switches)
+        if (!std::strcmp(s.name, name)) return &s;
+    return nullptr;
+}
+std::string g_dump;
+}  // namespace
+
+double egv_cfg_f64(const char* name, double def) {
+    const Switch* s = find_switch(name);
+    if (!s || s->def != def) {
+        std::fprintf(stderr, "egovlp_hip: switch %s (default %g) is not in the switch table of egv_api.cpp with that default\n", name, def);
+        std::abort();
+    }
+    const char* v = std::getenv(name);
+    return (v && *v) ? std::atof(v) : def;
+}
+int egv_cfg_int(const char* name, int def) { return (int)egv_cfg_f64(name, (double)def); }
+bool egv_cfg_on(const char* name, bool def) { return egv_cfg_f64(name, def ? 1.0 : 0.0) != 0.0; }
+
+// "NAME default current doc\n" per switch (tab separated)
+extern "C" const char* egv_config_dump(void) {
+    g_dump.clear();
+    char line[512];
+    for (const Switch& s : g_switches) {
+        const char* v = std::getenv(s.name);
+        std::snprintf(line, sizeof(line), "%s\t%g\t%g\t%s\n", s.name, s.def, (v && *v) ? std::atof(v) : s.def, s.doc);
+        g_dump += line;
+    }
+    return g_dump.c_str();
+}
+
 extern "C" int egv_stream_create(int priority, void** stream) {
     if (!stream) { egv_set_error("egv_stream_create: null output pointer"); return -1; }
     int least = 0, greatest = 0;

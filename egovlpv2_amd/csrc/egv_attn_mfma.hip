@@ -1042,7 +1042,7 @@ int egv_attn_dkv_mfma(const AttnArgs& ain, int B, hipStream_t st) {
 int egv_attn_bwd_fused_mfma(const AttnArgs& a, int B, hipStream_t st) {
     // groups of at most one 16-row tile (the 17-row time attention): the one-wave-per-group kernel of egv_attn_time.hip, which
     // leaves the CLS row's gradients as per-group partials; the (CLS, CLS) term is added by the reduction
-    static const bool time_fused = !getenv("EGV_ATTN_TIME_FUSED") || atoi(getenv("EGV_ATTN_TIME_FUSED")) != 0;
+    static const bool time_fused = egv_cfg_on("EGV_ATTN_TIME_FUSED", true);
     if (time_fused && a.q.n <= 16 && a.ws && a.extra && egv_attn_time_bwd(a, B, st)) {
         hipLaunchKernelGGL(attn_cls_reduce_kernel, dim3(B, a.H), dim3(256), 0, st, a, 1);
         return 1;

@@ -409,7 +409,7 @@ using namespace egv;
 void egv_attn_cls_combine_launch(const AttnArgs& a, int B, hipStream_t st);       // egv_attn_time.hip
 
 static bool space_on() {
-    static const bool on = !getenv("EGV_ATTN_SPACE_NEW") || atoi(getenv("EGV_ATTN_SPACE_NEW")) != 0;
+    static const bool on = egv_cfg_on("EGV_ATTN_SPACE_NEW", true);
     return on;
 }
 // the kernels' argument block from an AttnArgs; false if the launch is not one they cover

@@ -410,7 +410,7 @@ static bool time_fwd_shape_ok(const AttnArgs& a) {
            a.ldq == a.ldv;
 }
 bool egv_attn_time_fwd_ok(const AttnArgs& a, int B) {
-    static const bool on = !getenv("EGV_ATTN_TIME_FUSED") || atoi(getenv("EGV_ATTN_TIME_FUSED")) != 0;
+    static const bool on = egv_cfg_on("EGV_ATTN_TIME_FUSED", true);
     if (!on || !time_fwd_shape_ok(a)) return false;
     const long long rows = (long long)B * a.extra_bs;
     return rows * a.ldq * 2 < (1LL << 31) && rows * a.ldo * 2 < (1LL << 31);

@@ -17,6 +17,8 @@
 #include "../../include/egovlp_hip.h"
 
 void egv_set_error(const char* fmt, ...);
+int egv_cfg_int(const char* name, int def);          // run-time switches: the one table in egv_api.cpp
+bool egv_cfg_on(const char* name, bool def);
 void egv_gemm_set_cu_limit(int n);                  // egv_gemm3.hip: CUs the persistent forward / dgrad grids of this thread plan for
 extern "C" int egv_layernorm_bwd2(int dtype, const void* dy, const void* x, const float* stats, const float* gamma,
                                   const void* add, const void* add2, void* dx, float* dgamma, float* dbeta, int M, int D,
@@ -111,7 +113,7 @@ void rowset(long long& bs, long long& base, long long& gs, long long& is, int& n
 // exp for 77 M elements per block).  Measured on configs[2] (alternating A/B): 74.2 -> 74.9 ms per step -- the fc2 data-gradient
 // epilogue is not bound by its VALU work, and the forward epilogue pays for the second value -- so it stays OFF.
 int mlp_act(int dt) {
-    static const bool on = getenv("EGV_GELU_DERIV") && atoi(getenv("EGV_GELU_DERIV")) != 0;
+    static const bool on = egv_cfg_on("EGV_GELU_DERIV", false);
     return (on && dt == EGV_BF16) ? EGV_ACT_GELU_D : EGV_ACT_GELU;
 }
 
@@ -157,7 +159,7 @@ struct Divided {
         egv_attn_desc d;
         fill(d, qkv, O, lse);
         groups(d);
-        static const bool fused_cls = !getenv("EGV_ATTN_FUSED_CLS") || atoi(getenv("EGV_ATTN_FUSED_CLS")) != 0;
+        static const bool fused_cls = egv_cfg_on("EGV_ATTN_FUSED_CLS", true);
         if (fused_cls && wsb >= egv_attn_fwd_extra_workspace_bytes(B, d.G, H)) { d.ws = (float*)ws; d.ws_bytes = wsb; }
         const bool covers = d.ws && egv_attn_fwd_covers_extra(dt, &d);
         if (!covers) { d.ws = nullptr; d.ws_bytes = 0; }
@@ -182,8 +184,8 @@ struct Divided {
         const int ns = nsplit_for(S);
         // groups: dQ, dK, dV in one pass where the shape allows it (bf16 space attention); with the workspace that kernel also
         // produces the CLS row's gradients (per-group partials + one small sum) and nothing else is launched
-        static const bool fused = !getenv("EGV_ATTN_FUSED_BWD") || atoi(getenv("EGV_ATTN_FUSED_BWD")) != 0;
-        static const bool fused_cls = !getenv("EGV_ATTN_FUSED_CLS") || atoi(getenv("EGV_ATTN_FUSED_CLS")) != 0;
+        static const bool fused = egv_cfg_on("EGV_ATTN_FUSED_BWD", true);
+        static const bool fused_cls = egv_cfg_on("EGV_ATTN_FUSED_CLS", true);
         fill(d, qkv, const_cast<void*>(O), lse); grads(d); groups(d);
         if (fused_cls && wsb >= egv_attn_bwd_fused_workspace_bytes(B, d.G, H)) { d.ws = (float*)ws; d.ws_bytes = wsb; }
         int fr = fused ? egv_attn_bwd_fused(dt, &d, st) : 1;
@@ -332,7 +334,7 @@ struct Fp8 {                                     // quantise-then-GEMM for one b
 };
 
 bool vgroup_ok(const egv_vblock_desc* d) {
-    static const bool on = !getenv("EGV_WGRAD_GROUP") || atoi(getenv("EGV_WGRAD_GROUP")) != 0;
+    static const bool on = egv_cfg_on("EGV_WGRAD_GROUP", true);
     const long long M = (long long)d->B * (1 + (long long)d->F * d->N);
     return on && d->dtype == EGV_BF16 && (d->D % 256) == 0 && (d->Hd % 256) == 0 && M >= 4096;
 }
@@ -353,7 +355,7 @@ int device_cus() {
 // (measured on configs[2]: 96 of 256 CUs for the 144 tiles of an unfused block; 88 / 104 are 2 / 5 ms per step worse).
 // EGV_WGRAD_CUS overrides.
 int vgroup_cus(const egv_vblock_desc* d) {
-    static const int forced = getenv("EGV_WGRAD_CUS") ? atoi(getenv("EGV_WGRAD_CUS")) : 0;
+    static const int forced = egv_cfg_int("EGV_WGRAD_CUS", 0);
     if (forced > 0) return forced;
     const int tD = d->D / 256, tH = d->Hd / 256;
     const int ntile = 2 * tD * tH + 2 * tD * tD + 2 * 3 * tD * tD + (d->L > 0 ? 2 * tD * tD : 0);
@@ -366,7 +368,7 @@ int vgroup_cus(const egv_vblock_desc* d) {
 // step), while with MX-fp8 data-gradient GEMMs -- a chain a third shorter -- the split wins (167 vs 213 ms).  EGV_WGRAD_DEFER_MAXTILES
 // overrides the bf16 limit.
 bool vdefer_ok(const egv_vblock_desc* d) {
-    static const int max_tiles = getenv("EGV_WGRAD_DEFER_MAXTILES") ? atoi(getenv("EGV_WGRAD_DEFER_MAXTILES")) : 192;
+    static const int max_tiles = egv_cfg_int("EGV_WGRAD_DEFER_MAXTILES", 192);
     const int tD = d->D / 256, tH = d->Hd / 256;
     const int ntile = 2 * tD * tH + 2 * tD * tD + 2 * 3 * tD * tD + (d->L > 0 ? 2 * tD * tD : 0);
     return vfp8_on(d) || ntile <= max_tiles;
@@ -445,7 +447,7 @@ extern "C" int egv_vblock_fwd(const egv_vblock_desc* d) {
         f8.s2 = ws.take((size_t)egv_mx_scale_bytes(M, Hd, 0));
     }
     if (!ws.ok()) { egv_set_error("egv_vblock_fwd: workspace too small"); return -1; }
-    static const bool epi_q = !getenv("EGV_MX_EPI_QUANT") || atoi(getenv("EGV_MX_EPI_QUANT")) != 0;
+    static const bool epi_q = egv_cfg_on("EGV_MX_EPI_QUANT", true);
     const bool mlp_chain = epi_q && f8.on && d->wq[VW_FC1] && d->wq_s[VW_FC1] && d->wq[VW_FC2] && d->wq_s[VW_FC2];
     // one Linear over the M video tokens: MX-fp8 when the desc carries the quantised weight, bf16 otherwise
     auto lin = [&](int w, int N, int K, const void* x, void* y, int act, const void* r1, void* pre) -> int {
@@ -455,7 +457,7 @@ extern "C" int egv_vblock_fwd(const egv_vblock_desc* d) {
     // LayerNorm followed by a Linear on its output: in the MX-fp8 mode the LayerNorm kernel writes the quantised operand itself
     // (the same codes and scales egv_quant_mx would produce from h), so the Linear needs no quantiser launch
     auto ln_lin = [&](int ln, const void* xin, void* h, float* stats, int w, int N, int K, void* y, int act, void* pre) -> int {
-        static const bool ln_mx = !getenv("EGV_LN_MX") || atoi(getenv("EGV_LN_MX")) != 0;
+        static const bool ln_mx = egv_cfg_on("EGV_LN_MX", true);
         if (ln_mx && f8.on && d->wq[w] && d->wq_s[w] && K == D) {
             if (egv_layernorm_fwd_mx(xin, h, d->ln_g[ln], d->ln_b[ln], stats, f8.q, f8.s, M, D, d->eps, st)) return -1;
             if (w == VW_FC1 && mlp_chain)       // fc1's GELU epilogue also writes the MX-fp8 form of the activation: fc2's operand
@@ -553,7 +555,7 @@ extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
         f8.s2 = ws.take((size_t)egv_mx_scale_bytes(M, Hd, 0));
     }
     if (!ws.ok()) { egv_set_error("egv_vblock_bwd: workspace too small (%zu > %zu)", ws.off, ws.cap); return -1; }
-    static const bool epi_q = !getenv("EGV_MX_EPI_QUANT") || atoi(getenv("EGV_MX_EPI_QUANT")) != 0;
+    static const bool epi_q = egv_cfg_on("EGV_MX_EPI_QUANT", true);
     const bool mlp_chain = epi_q && f8.on && d->wtq[VW_FC1] && d->wtq_s[VW_FC1] && d->wtq[VW_FC2] && d->wtq_s[VW_FC2];
     // dx[M,K] = (dz[M,N] W[N,K]) * act'(aux) over the M video tokens: MX-fp8 on the quantised transposed weight when the desc
     // carries it (the output gradient is quantised along N, the contraction), bf16 otherwise
@@ -572,7 +574,7 @@ extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
     //    as soon as its operands exist, fp32 slabs + reduction launch (egv_gemm4.hip).
     const bool side_group = vgroup_ok(d) && vdefer_ok(d) && fk.forked() && (d->flags & EGV_BLOCK_NO_JOIN);
     const bool group = vgroup_ok(d) && (side_group || !fk.forked());
-    static const int main_limit = getenv("EGV_WGRAD_MAIN_LIMIT") ? atoi(getenv("EGV_WGRAD_MAIN_LIMIT")) : 0;
+    static const int main_limit = egv_cfg_int("EGV_WGRAD_MAIN_LIMIT", 0);
     CuLimit cu_limit(side_group ? (main_limit > 0 ? main_limit : device_cus() - vgroup_cus(d)) : 0);
     egv_wgrad_problem grp[8];
     int ngrp = 0;
@@ -660,7 +662,7 @@ inline bool tmq(const egv_tlayer_desc* d) { return d->dtype == EGV_BF16 && d->w_
 inline bool tmc(const egv_tlayer_desc* d) { return d->dtype == EGV_BF16 && d->S > 0 && d->w_ckv != nullptr; }
 // the weight gradients over the B*L text rows as ONE grouped launch (egv_gemm5.hip) at the end of the backward call
 inline bool tgroup(const egv_tlayer_desc* d) {
-    static const bool on = !getenv("EGV_TEXT_WGRAD_GROUP") || atoi(getenv("EGV_TEXT_WGRAD_GROUP")) != 0;
+    static const bool on = egv_cfg_on("EGV_TEXT_WGRAD_GROUP", true);
     return on && d->dtype == EGV_BF16 && (d->D % 256) == 0 && (d->Hd % 256) == 0 && d->B * d->L >= 64;
 }
 inline bool tres32(const egv_tlayer_desc* d) { return (d->flags & EGV_BLOCK_RES_F32) && d->dtype == EGV_BF16; }

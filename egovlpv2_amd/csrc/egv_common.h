@@ -143,6 +143,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // ---- host side error plumbing shared by the C ABI translation units ----
 extern "C" const char* egv_last_error(void);
+// run-time switches (egv_api.cpp: the one table of names and defaults; the environment overrides one switch at a time)
+int egv_cfg_int(const char* name, int def);
+double egv_cfg_f64(const char* name, double def);
+bool egv_cfg_on(const char* name, bool def);
 void egv_set_error(const char* fmt, ...);
 #define EGV_CHECK(cond, ...)                      \
     do {                                          \

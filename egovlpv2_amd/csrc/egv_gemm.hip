@@ -347,12 +347,12 @@ static inline int wgrad_splits(int tiles, int M, long long out_elems, double flo
 int egv_gemm4_launch(const egv::GemmArgs& g, int nz, hipStream_t st);
 // ping-pong weight-gradient kernel (egv_gemm4.hip): 256x256 tiles, one (tile, split) item per CU
 static inline bool wgrad_use_pp(int dtype, int M, int N, int K) {
-    static const int on = getenv("EGV_WGRAD_PP") ? atoi(getenv("EGV_WGRAD_PP")) : 1;
+    static const int on = egv_cfg_int("EGV_WGRAD_PP", 1);
     return on && dtype == EGV_BF16 && (N % 256) == 0 && (K % 256) == 0 && M >= 4096 && (N / 256) * (K / 256) <= 128;
 }
 static inline int wgrad_pp_splits(int M, int N, int K) {
     const int tiles = (N / 256) * (K / 256);
-    static const int items = getenv("EGV_WGRAD_ITEMS") ? atoi(getenv("EGV_WGRAD_ITEMS")) : 224;   // 7/8 of the CUs: the rest serve the other streams (measured 92.6 -> 91.8 ms per step)
+    static const int items = egv_cfg_int("EGV_WGRAD_ITEMS", 224);   // 7/8 of the CUs: the rest serve the other streams (measured 92.6 -> 91.8 ms per step)
     int nz = items / tiles;
     while (nz > 1 && M / nz < 512) --nz;
     return nz < 1 ? 1 : nz;

@@ -413,7 +413,7 @@ int egv_gemm2_launch(const GemmArgs& g, int a_trans, int b_trans, int out_f32, i
         return 1;
     }
     {
-        static const int pp = getenv("EGV_GEMM_PP") ? atoi(getenv("EGV_GEMM_PP")) : 1;     // persistent ping-pong kernel (egv_gemm3.hip) for large grids; 0 = ring kernels only
+        static const int pp = egv_cfg_int("EGV_GEMM_PP", 1);     // persistent ping-pong kernel (egv_gemm3.hip) for large grids; 0 = ring kernels only
         if (pp && (long long)((g.M + 255) / 256) * ((g.N + 255) / 256) >= 64 && egv_gemm3_launch(g, st)) return 2;   // 2: persistent kernel
         const long long tb = (long long)((g.M + 255) / 256) * ((g.N + 127) / 128);
         if (tb <= 128) { launch_ring<CfgC, 6>(g, st); return 3; }   // 3: small-grid ring     // latency-bound small grids (text tokens): 128x128 tiles, 5 K-tiles in flight

@@ -686,7 +686,7 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
     GemmArgs g = gin;
 #ifdef EGV_INSTRUMENT
     g.colsum = egv::g_timing_buf;
-    static const bool stamps = getenv("EGV_PP_STAMPS") != nullptr;     // the STAMPS variant of the plain kind
+    static const bool stamps = egv_cfg_on("EGV_PP_STAMPS", false);     // the STAMPS variant of the plain kind
 #else
     constexpr bool stamps = false;
 #endif
@@ -713,7 +713,7 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
         // The persistent workgroups own their CU (144 KB LDS, 512 threads x 252 VGPRs): kernels of the text / weight-gradient
         // streams can only run beside them on CUs the grid leaves free.  The grid is trimmed per call (below) to the smallest
         // size that keeps the number of rounds; EGV_PP_CUS caps it (with untrimmed grids 7/8 of the CUs measured best).
-        if (const char* cap = getenv("EGV_PP_CUS")) ncu = (atoi(cap) / 8) * 8;
+        if (const int cap = egv_cfg_int("EGV_PP_CUS", 0)) ncu = (cap / 8) * 8;
         if (ncu < 8) ncu = 8;
         ncu_dev = ncu;
     }
@@ -722,7 +722,7 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
     // taken when that removes a whole round of the walk (1176 tiles of the fc1 / fc2 class: 8 rounds on 160 CUs, 7 on 168) -- a few
     // workgroups then start late, behind the weight-gradient workgroups that hold their CUs, instead of every workgroup walking one
     // tile more (measured on configs[2]: limit 160 -> 168, 78.1 -> 76.7 ms per step)
-    static const int slack = getenv("EGV_PP_LIMIT_SLACK") ? atoi(getenv("EGV_PP_LIMIT_SLACK")) : 16;
+    static const int slack = egv_cfg_int("EGV_PP_LIMIT_SLACK", 16);
     int ncu_soft = 0;
     if (g_cu_limit > 0 && g_cu_limit < ncu_all) {
         ncu = g_cu_limit >= 8 ? (g_cu_limit / 8) * 8 : 8;
@@ -730,10 +730,10 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
     }
     // tile height: 192-row tiles where they shorten the walk (rounds x tile work, + 6 % for the smaller tile's lower operand
     // reuse); only the plain and the residual epilogue kinds are built for them
-    static const bool allow192 = !getenv("EGV_PP_BM192") || atoi(getenv("EGV_PP_BM192")) != 0;
+    static const bool allow192 = egv_cfg_on("EGV_PP_BM192", true);
     const bool kind192 = !e.dact && (!e.pre || e.res2) && !e.act && !stamps;
     const int t256 = ((g.M + 255) / 256) * g.tiles_n, t192 = ((g.M + 191) / 192) * g.tiles_n;
-    static const double pen192 = getenv("EGV_PP_192_PENALTY") ? atof(getenv("EGV_PP_192_PENALTY")) : 1.06;
+    static const double pen192 = egv_cfg_f64("EGV_PP_192_PENALTY", 1.06);
     auto rounds_of = [&](int t) {
         const int r = (t + ncu - 1) / ncu;
         return ncu_soft > ncu && (t + ncu_soft - 1) / ncu_soft < r ? (t + ncu_soft - 1) / ncu_soft : r;
@@ -749,7 +749,7 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
         rounds = (ntiles + ncu_soft - 1) / ncu_soft;
         ncu = ncu_soft;
     }
-    static const bool trim = !getenv("EGV_PP_TRIM") || atoi(getenv("EGV_PP_TRIM")) != 0;
+    static const bool trim = egv_cfg_on("EGV_PP_TRIM", true);
     int grid = trim ? (((ntiles + rounds - 1) / rounds + 7) / 8) * 8 : ncu;
     if (grid > ncu) grid = ncu;
     if (ntiles < grid) grid = ((ntiles + 7) / 8) * 8;
@@ -765,7 +765,7 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
         hipLaunchKernelGGL((gemm_pp_kernel<X, P, AC>), dim3(grid), dim3(512), PP_LDS, st, g, ntiles);                    \
         return 1;                                                                                                        \
     } while (0)
-    static const int res_min_k = getenv("EGV_PP_RES_MINK") ? atoi(getenv("EGV_PP_RES_MINK")) : 1536;
+    static const int res_min_k = egv_cfg_int("EGV_PP_RES_MINK", 1536);
     if (e.res1 && g.K < res_min_k && !(use192 && g.K >= res_min_k / 2)) return 0;   // short-K residual GEMMs on 256-row tiles: the 2-workgroup ring kernel hides their epilogue better
 #define PP_LAUNCH192P(X, P)                                                                                              \
     do {                                                                                                                 \

@@ -564,7 +564,7 @@ extern "C" int egv_layernorm_fwd_res32(const float* x, float* y, void* y16, cons
 
 static inline int ln_bwd_blocks(int M) {
     int nb = (M + 3) / 4;
-    static const int cap = getenv("EGV_LN_BLOCKS") ? atoi(getenv("EGV_LN_BLOCKS")) : 512;
+    static const int cap = egv_cfg_int("EGV_LN_BLOCKS", 512);
     return nb > cap ? cap : nb;          // 2 workgroups per CU (two rows in flight per wave); the partial-sum reduction reads nb rows
 }
 
@@ -590,7 +590,7 @@ extern "C" int egv_layernorm_bwd2(int dtype, const void* dy, const void* x, cons
     const int rpb = (M + nb - 1) / nb;
     const int nb2 = (M + rpb - 1) / rpb;
     float* partial = (float*)workspace;
-    static const int packed = getenv("EGV_LN_PACKED") ? atoi(getenv("EGV_LN_PACKED")) : 1;
+    static const int packed = egv_cfg_int("EGV_LN_PACKED", 1);
     if (dtype == EGV_BF16 && packed && D == 1024) {                  // ViT-L / RoBERTa-large width: two packed rows per wave
         const bf16_t *pdy = (const bf16_t*)dy, *pxx = (const bf16_t*)x, *pa = (const bf16_t*)add, *pb = (const bf16_t*)add2;
         if (pb && !pa) { pa = pb; pb = nullptr; }

@@ -17,6 +17,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib as L
+from . import switches as SW
 from ._lib import lib, check, AttnDesc
 
 ACT = {'none': L.ACT_NONE, 'gelu': L.ACT_GELU, 'relu': L.ACT_RELU, 'tanh': L.ACT_TANH}
@@ -415,9 +416,9 @@ def companion_stream(device, kind='wgrad'):
     """A stream for work that runs beside the calling stream (kind 'wgrad': weight gradients, 'text': the text tower).  HIP
     priority EGV_SIDE_PRIORITY (default 1 = low: the companions' workgroups only take CUs the calling stream's kernels leave free;
     0 = a plain torch stream); EGV_TEXT_PRIORITY overrides it for the text stream."""
-    prio = int(os.environ.get('EGV_SIDE_PRIORITY', '1'))
-    if kind == 'text' and os.environ.get('EGV_TEXT_PRIORITY') is not None:
-        prio = int(os.environ['EGV_TEXT_PRIORITY'])
+    prio = int(SW.value('EGV_SIDE_PRIORITY'))
+    if kind == 'text' and SW.value('EGV_TEXT_PRIORITY') != '':
+        prio = int(SW.value('EGV_TEXT_PRIORITY'))
     if prio == 0:
         return torch.cuda.Stream(device=device)
     h = C.c_void_p()
@@ -434,7 +435,7 @@ def _wgrad_fork(M, fn, uses):
     on the current stream so far; `uses` (current-stream tensors fn reads) are recorded on it.  Returns (out, join):
     join() orders the current stream after fn, to be called before the gradients are handed back to autograd.
     EGV_NO_OVERLAP=1 (or a small problem) runs fn inline."""
-    if M < 4096 or os.environ.get('EGV_NO_OVERLAP'):
+    if M < 4096 or SW.on('EGV_NO_OVERLAP'):
         return fn(), (lambda: None)
     cur = torch.cuda.current_stream()
     key = (cur.device.index, cur.cuda_stream)
@@ -745,8 +746,8 @@ def _nsplit_for(n_other):
     return 1 if n_other <= 224 else max(2, min(32, n_other // 384))     # 8 splits at S = 3137: the combine pass stays short
 
 
-FUSED_ATTN_BWD = os.environ.get('EGV_ATTN_FUSED_BWD', '1') != '0'
-FUSED_ATTN_CLS = os.environ.get('EGV_ATTN_FUSED_CLS', '1') != '0'     # the one-pass kernel also produces the CLS row's gradients
+FUSED_ATTN_BWD = SW.on('EGV_ATTN_FUSED_BWD')
+FUSED_ATTN_CLS = SW.on('EGV_ATTN_FUSED_CLS')     # the one-pass kernel also produces the CLS row's gradients
 
 
 class DividedAttnFn(Function):
@@ -935,7 +936,7 @@ def dropout_add(x, p, seed, r1=None, r2=None):
 # ---- block-level calls (csrc/egv_block.cpp): one C-ABI call per SpaceTimeBlock / RobertaLayer and direction -----------------
 def _side_stream_ptr():
     """raw handle of the weight-gradient companion stream of the current stream (None: single-stream mode)"""
-    if os.environ.get('EGV_NO_OVERLAP'):
+    if SW.on('EGV_NO_OVERLAP'):
         return None
     cur = torch.cuda.current_stream()
     key = (cur.device.index, cur.cuda_stream)
@@ -1136,7 +1137,7 @@ def _tracks_grad(params):
 
 def _defer_side(params):
     """(companion stream, calling stream) if this backward call may return before its weight gradients are done, else None"""
-    if not _defer_allowed[0] or os.environ.get('EGV_NO_OVERLAP') or os.environ.get('EGV_WGRAD_DEFER', '1') == '0':
+    if not _defer_allowed[0] or SW.on('EGV_NO_OVERLAP') or not SW.on('EGV_WGRAD_DEFER'):
         return None
     for p in params:
         if p.grad is not None or p._backward_hooks or getattr(p, '_post_accumulate_grad_hooks', None):
@@ -1193,7 +1194,7 @@ class VideoBlockFn(Function):
         check(lib.egv_vblock_fwd(C.byref(d)), 'egv_vblock_fwd')
         ctx.cfg = cfg
         ctx.key = ('v', id(params[0]))
-        ctx.tail = bool(cfg[7] and _first_vblock[0] and os.environ.get('EGV_WGRAD_TAIL', '1') != '0')
+        ctx.tail = bool(cfg[7] and _first_vblock[0] and SW.on('EGV_WGRAD_TAIL'))
         if cfg[7]:
             _first_vblock[0] = False
         _acc_forward(ctx.key, cfg[7], cfg[6] > 0)

@@ -27,6 +27,7 @@ import torch.nn.functional as F
 import torch.distributed as dist
 
 from .. import hipops as ops
+from .. import switches as SW
 from ..config import PathConfig
 from ..synthetic import param_shapes
 from ..utils.util import state_dict_data_parallel_fix
@@ -147,13 +148,13 @@ class FrozenInTime(nn.Module):
         self.num_fuse_block = self.cfg.n_fuse
         self.num_text_layer = self.cfg.depth
         self.compute_dtype = compute_dtype
-        self.text_fp32 = bool(text_fp32) or os.environ.get('EGV_TEXT_FP32', '0') == '1'
+        self.text_fp32 = bool(text_fp32) or SW.on('EGV_TEXT_FP32')
         # BASELINE.json configs[4] ("fp8 MFMA weight path"): the forward / data-gradient GEMMs of the video blocks on MX-fp8 (OCP
         # MXFP8 E4M3) weights and activations; weight gradients, attention, LayerNorm, the text tower and the heads stay bf16
-        self.video_fp8 = (bool(video_fp8) or os.environ.get('EGV_VIDEO_FP8', '0') == '1') and compute_dtype == torch.bfloat16
+        self.video_fp8 = (bool(video_fp8) or SW.on('EGV_VIDEO_FP8')) and compute_dtype == torch.bfloat16
         # bf16 mode: the text tower's residual stream (LayerNorm inputs / outputs, residual sums) stays fp32 between bf16 GEMMs, as under
         # torch.autocast (trainer/trainer_egoclip.py:143); EGV_TEXT_RES32=0 stores it in bf16 like the video tower's
-        self.text_res32 = compute_dtype == torch.bfloat16 and os.environ.get('EGV_TEXT_RES32', '1') != '0'
+        self.text_res32 = compute_dtype == torch.bfloat16 and SW.on('EGV_TEXT_RES32')
         self.patches_per_frame = self.cfg.n_patches
 
         gen = torch.Generator().manual_seed(init_seed)
@@ -168,10 +169,10 @@ class FrozenInTime(nn.Module):
         # with strict=False when no full checkpoint is given).  The reference hard-codes its file locations; here they come from
         # text_params['pretrained_path'] / video_params['pretrained_path'] (or EGV_ROBERTA_CHECKPOINT / EGV_VIT_CHECKPOINT).
         # Without a path the towers keep their seeded random init (there is no network for the hub downloads).
-        tpath = text_params.get('pretrained_path') or os.environ.get('EGV_ROBERTA_CHECKPOINT')
+        tpath = text_params.get('pretrained_path') or SW.value('EGV_ROBERTA_CHECKPOINT') or None
         if tpath:
             self.load_pretrained_text(tpath)
-        vpath = video_params.get('pretrained_path') or os.environ.get('EGV_VIT_CHECKPOINT')
+        vpath = video_params.get('pretrained_path') or SW.value('EGV_VIT_CHECKPOINT') or None
         if vpath and video_params.get('pretrained', True) and load_checkpoint in ["", None]:
             self.load_pretrained_vit(vpath)
 
@@ -250,7 +251,7 @@ class FrozenInTime(nn.Module):
         hooks were created on the calling stream, autograd makes that stream wait for the producing stream before each
         accumulation, and the reducer orders a bucket's all-reduce after the calling stream at the time the bucket's last
         hook fires (tests/test_multirank_gpu.py runs both modes against the oracle)."""
-        return not os.environ.get('EGV_NO_OVERLAP') and torch.cuda.is_available()
+        return not SW.on('EGV_NO_OVERLAP') and torch.cuda.is_available()
 
     def _fork_text(self, fn, uses=(), after=None, kind='text'):
         """Run text-encoder work (latency-bound: a dozen workgroups per kernel) on a second HIP stream so that it overlaps
@@ -259,7 +260,7 @@ class FrozenInTime(nn.Module):
         queued on the calling stream so far.  `uses`: tensors allocated on the calling stream that fn reads -- they are
         recorded on the side stream, otherwise the caching allocator may recycle them while side-stream kernels (forward
         or backward) are still queued.  Returns (out, join); join() orders the calling stream after fn's work only."""
-        if not self._overlap() or os.environ.get('EGV_TEXT_STREAM', '1') == '0' or (kind == 'tail' and os.environ.get('EGV_TAIL_STREAM', '1') == '0'):
+        if not self._overlap() or not SW.on('EGV_TEXT_STREAM') or (kind == 'tail' and not SW.on('EGV_TAIL_STREAM')):
             return fn(), (lambda: None)
         kind = 'text'                                          # the loss tails follow the text tower on its stream
         main = torch.cuda.current_stream()
@@ -315,7 +316,7 @@ class FrozenInTime(nn.Module):
                     sets.append([f'{pfx}.crossattention_t2i.self.{m}' for m in ('key', 'value')])
                 for names in sets:
                     groups.append(([self.p(n + '.weight') for n in names], [self.p(n + '.bias') for n in names]))
-            self.__dict__['_gemm_groups'] = groups if os.environ.get('EGV_MERGE_PROJ', '1') != '0' else []
+            self.__dict__['_gemm_groups'] = groups if SW.on('EGV_MERGE_PROJ') else []
             c = self.cfg
             mx = []
             if self.video_fp8 and c.dim % 128 == 0 and c.dim >= 384:
@@ -643,8 +644,8 @@ class FrozenInTime(nn.Module):
             # the concatenated batch (per-sample results unchanged: every kernel is batch-independent; dropout masks are a function
             # of (seed, element) and stay independent per element); the ITM prefix cannot join -- its batch is drawn from the EgoNCE
             # similarities.  EGV_TEXT_BATCH=0 restores the separate passes.
-            pair_prefix = ('MLM' in task_names and want_itm and c.depth > c.n_fuse and not os.environ.get('EGV_NO_PREFIX_SHARING')
-                           and not self.text_fp32 and os.environ.get('EGV_TEXT_BATCH', '1') != '0'
+            pair_prefix = ('MLM' in task_names and want_itm and c.depth > c.n_fuse and not SW.on('EGV_NO_PREFIX_SHARING')
+                           and not self.text_fp32 and SW.on('EGV_TEXT_BATCH')
                            and data['text_mlm_ids'].shape == text_data['input_ids'].shape)
             txt_mlm_pair = None
             if pair_prefix:
@@ -712,7 +713,7 @@ class FrozenInTime(nn.Module):
                 loss_terms.insert(0, (1.0, loss_e))
             tail_state = {}
             loss_dict['EgoNCE'] = None                      # (keeps the reference's key order)
-            late_tail = want_itm and os.environ.get('EGV_EGONCE_TAIL_LATE', '1') != '0'
+            late_tail = want_itm and SW.on('EGV_EGONCE_TAIL_LATE')
             if late_tail:
                 # The ITM draw needs the similarities NOW, but the engine runs backward nodes in reverse creation order and the text
                 # stream executes in order: a differentiable tail created here has its backward enqueued behind the backward of both
@@ -741,7 +742,7 @@ class FrozenInTime(nn.Module):
             # batch while the calling stream is still busy with the MLM pass
             # (the reference all-gathers the pixels here, :430; with the shared prefix only the prefix tokens of the clips that
             # are actually drawn from another rank travel -- trainer/exchange.py)
-            share_px = ('MLM' in task_names and c.depth > c.n_fuse and not os.environ.get('EGV_NO_PREFIX_SHARING'))
+            share_px = ('MLM' in task_names and c.depth > c.n_fuse and not SW.on('EGV_NO_PREFIX_SHARING'))
             all_video = data['video'] if (world == 1 or share_px) else gather(data['video'])
             all_text_ids = gather(data['text']['input_ids'])
             all_text_masks = gather(data['text']['attention_mask'])
@@ -756,7 +757,7 @@ class FrozenInTime(nn.Module):
         # (model.py:449-468).  The reference recomputes it in the ITM pass; here it is computed once and the ITM pass gathers
         # clip rows from it (same values, and autograd sums both consumers' gradients exactly as the two passes would).
         share_prefix = ('MLM' in task_names and 'ITM' in task_names and c.depth > c.n_fuse
-                        and not os.environ.get('EGV_NO_PREFIX_SHARING'))
+                        and not SW.on('EGV_NO_PREFIX_SHARING'))
         v_pre = None
         data_mlm = data
         if share_prefix:
@@ -805,6 +806,12 @@ class FrozenInTime(nn.Module):
             stage[2].copy_(itm_labels.long())
             idx_dev = stage.to(dev, non_blocking=True)
             vid_list = vid_idx.tolist()
+            req = None
+            if world > 1 and share_prefix:
+                # which clips does every rank need from which owner?  The exchange of the drawn ids starts NOW (text stream: idle at
+                # this point, and the ids get their own host->device copy there), the table is read in run_itm()
+                from ..trainer.exchange import start_request_gather
+                req, _ = self._fork_text(lambda: start_request_gather(vid_list, stage[0].to(dev, non_blocking=True), rank, bsz, world), after=ev_in)
             vid_idx, txt_idx, labels_dev = idx_dev[0], idx_dev[1], idx_dev[2]
             if share_prefix:
                 def text_itm():            # runs on the text stream: it only needs the gathered ids, not the MLM pass
@@ -816,9 +823,9 @@ class FrozenInTime(nn.Module):
             else:
                 data_itm = {'text': {'input_ids': all_text_ids.index_select(0, txt_idx),
                                      'attention_mask': all_text_masks.index_select(0, txt_idx)}}
-            return dict(itm_labels=itm_labels, neg_log=neg_log, vid_idx=vid_idx, vid_list=vid_list, labels_dev=labels_dev, data_itm=data_itm)
+            return dict(itm_labels=itm_labels, neg_log=neg_log, vid_idx=vid_idx, vid_list=vid_list, labels_dev=labels_dev, data_itm=data_itm, req=req)
 
-        itm_state = itm_draw() if ('ITM' in task_names and share_prefix and os.environ.get('EGV_ITM_DRAW_EARLY', '1') != '0') else None
+        itm_state = itm_draw() if ('ITM' in task_names and share_prefix and SW.on('EGV_ITM_DRAW_EARLY')) else None
         if itm_state is not None and 'EgoNCE' in task_names and late_tail:
             make_tail()          # after both text prefixes were created, before the fused stacks: see late_tail above
 
@@ -864,8 +871,8 @@ class FrozenInTime(nn.Module):
                     # replicated parameters, batch-independent kernels), so the prefix TOKENS are fetched from the owner and
                     # the token gradients return to it in backward (trainer/exchange.py) -- no pixel all-gather, no second
                     # prefix pass, and every rank runs the same graph every step (DDP static_graph).
-                    from ..trainer.exchange import gather_requests, ExchangeClipsFn
-                    table = gather_requests(vid_list, rank, bsz, world)
+                    from ..trainer.exchange import ExchangeClipsFn
+                    table = drawn['req']()
                     assert table[rank] == remote
                     v_rem = ExchangeClipsFn.apply(v_pre, table, rank, bsz, c.seq)
                 plan = [(0, j - lo) if lo <= j < lo + bsz else (1, remote.index(j)) for j in vid_list]
@@ -890,7 +897,7 @@ class FrozenInTime(nn.Module):
             loss_dict['loss_mlm'] = None
         if 'ITM' in task_names:
             loss_dict['loss_itm'] = None
-        for name, fn in ((('ITM', run_itm), ('MLM', run_mlm)) if os.environ.get('EGV_ITM_FIRST', '0') == '1' else (('MLM', run_mlm), ('ITM', run_itm))):
+        for name, fn in ((('ITM', run_itm), ('MLM', run_mlm)) if SW.on('EGV_ITM_FIRST') else (('MLM', run_mlm), ('ITM', run_itm))):
             if name in task_names:
                 fn()
         for key in ('mlm', 'itm'):

@@ -3,8 +3,8 @@
 The reference all-gathers the raw pixels of every rank (model/model.py:429-431: 77 MB per rank at configs[2], 616 MB per
 step at 8 GPUs) and pushes every sampled negative through the video prefix again.  Here the ranks exchange
 
-  1. the sampled clip indices (a B-entry int64 vector per rank; host-side all-gather on a gloo side group, so no device
-     synchronisation is involved), and
+  1. the sampled clip indices (a B-entry int64 vector per rank: one device all-gather on RCCL, read back through pinned memory
+     behind an event; on gloo -- the CPU / one-GPU tests -- a host all-gather), and
   2. only the prefix TOKENS of the clips that were actually drawn from another rank (bf16 (S, d) per clip, at most
      ceil(B/2) clips per rank and step), point to point from their owner,
 
@@ -30,17 +30,48 @@ def meta_group():
     return _meta_group[0]
 
 
+def _table(rows, bsz):
+    """rows[r] = the clip ids rank r sampled -> table[requester] = sorted remote clip ids it needs (ids are global: owner = id // bsz)"""
+    table = []
+    for r, ids in enumerate(rows):
+        lo = r * bsz
+        table.append(sorted({int(j) for j in ids if not lo <= j < lo + bsz}))
+    return table
+
+
 def gather_requests(vid_list, rank, bsz, world):
-    """every rank's list of sampled clip ids -> table[requester] = sorted remote clip ids it needs (ids are global: owner =
-    id // bsz).  One small host all-gather."""
+    """every rank's list of sampled clip ids -> the request table.  One small HOST all-gather (gloo): blocks the calling host thread
+    until every rank's host has arrived -- the transport of the gloo tests; on RCCL use start_request_gather."""
     mine = torch.tensor(list(vid_list), dtype=torch.int64)
     out = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(out, mine, group=meta_group())
-    table = []
-    for r in range(world):
-        lo = r * bsz
-        table.append(sorted({int(j) for j in out[r].tolist() if not lo <= j < lo + bsz}))
-    return table
+    return _table([o.tolist() for o in out], bsz)
+
+
+def start_request_gather(vid_list, ids_dev, rank, bsz, world):
+    """Start the exchange of the sampled clip ids and return a function that yields the request table when it is needed.
+
+    RCCL (backend 'nccl'): the B ids of this rank (`ids_dev`, already on the device) go through ONE device all-gather on the
+    current stream, the result is copied to pinned host memory behind it, and the returned function waits for that copy's event --
+    no host-side collective, no extra process group, and the wait is over by the time the ITM pass is assembled (the draw happens
+    before the MLM pass is enqueued, FrozenInTime.forward).  The collective is issued at the same point of the step by every rank
+    (the draw), like every other collective of the step.
+    gloo (device tensors cannot travel): the host all-gather of gather_requests, done here.  EGV_EXCHANGE_HOST_TABLE=1 forces it."""
+    from .. import switches as SW
+    if dist.get_backend() == 'gloo' or SW.on('EGV_EXCHANGE_HOST_TABLE') or ids_dev is None or not ids_dev.is_cuda:
+        table = gather_requests(vid_list, rank, bsz, world)
+        return lambda: table
+    buf = torch.empty(world * bsz, dtype=torch.int64, device=ids_dev.device)
+    dist.all_gather_into_tensor(buf, ids_dev.contiguous())
+    host = torch.empty(world * bsz, dtype=torch.int64, pin_memory=True)
+    host.copy_(buf, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+
+    def get():
+        ev.synchronize()
+        return _table(host.view(world, bsz).tolist(), bsz)
+    return get
 
 
 def _p2p(ops_):

@@ -26,6 +26,7 @@ import torch
 import torch.distributed as dist
 
 from .. import hipops as ops
+from .. import switches as SW
 
 
 class FlatGradSync:
@@ -34,7 +35,7 @@ class FlatGradSync:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         # EGV_SYNC_FORCE=1 (test aid): issue the collectives even in a one-rank group, to run the RCCL code path on a 1-GPU box
-        self.comm = self.world > 1 or (bool(os.environ.get('EGV_SYNC_FORCE')) and dist.is_available() and dist.is_initialized())
+        self.comm = self.world > 1 or (SW.on('EGV_SYNC_FORCE') and dist.is_available() and dist.is_initialized())
         self._works = []
         self._packed = set()
         self._flats = []

@@ -6,6 +6,8 @@ from collections import OrderedDict
 
 import torch
 
+from .. import switches as SW
+
 
 class _InertObject:
     """what a non-tensor object pickled inside a checkpoint becomes when the file is read without executing its code: a bag of
@@ -49,7 +51,7 @@ def load_checkpoint_file(path, map_location='cpu', allow_unsafe=None):
             return torch.load(path, map_location=map_location, weights_only=True)
     except Exception as second:                          # noqa: BLE001 -- report both, decide below
         err = second
-    if allow_unsafe or (allow_unsafe is None and os.environ.get('EGV_ALLOW_UNSAFE_CHECKPOINT') == '1'):
+    if allow_unsafe or (allow_unsafe is None and SW.on('EGV_ALLOW_UNSAFE_CHECKPOINT')):
         return torch.load(path, map_location=map_location, weights_only=False)
     raise RuntimeError(f"{path}: cannot be read without executing pickled code ({type(err).__name__}: {err}); if the file is trusted, "
                        f"pass allow_unsafe=True or set EGV_ALLOW_UNSAFE_CHECKPOINT=1") from err

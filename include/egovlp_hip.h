@@ -41,6 +41,9 @@ extern "C" {
 
 int egv_abi_version(void);
 const char* egv_last_error(void);
+/* run-time switches of the library: one line "NAME\tdefault\tcurrent\tmeaning" per switch (egv_api.cpp holds the one table; an
+ * environment variable of the same name overrides a switch -- an A/B aid, the defaults are the tested configuration) */
+const char* egv_config_dump(void);
 
 /* A non-blocking HIP stream for companion work (weight gradients, the text tower) at HIP priority `priority`:
  * -1 high, 0 normal, 1 low (hipDeviceGetStreamPriorityRange on gfx950).  Low-priority companions only take the CUs the
@@ -97,6 +100,11 @@ int egv_layernorm_fwd(int dtype, const void* x, void* y, const float* gamma, con
 long long egv_layernorm_bwd_workspace_bytes(int M, int D);
 int egv_layernorm_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma,
                       const void* add, void* dx, float* dgamma, float* dbeta, int M, int D, void* workspace, void* stream);
+/* dx = LN'(dy) + add + add2 (either may be NULL): the input of a divided space-time block feeds norm3 AND both residual sums
+ * (video_transformer.py:218,222), so its gradient collects two skip paths while the LayerNorm backward writes dx */
+int egv_layernorm_bwd2(int dtype, const void* dy, const void* x, const float* stats, const float* gamma,
+                       const void* add, const void* add2, void* dx, float* dgamma, float* dbeta, int M, int D, void* workspace,
+                       void* stream);
 
 /* out[n] (fp32) = scale * (*gate) * sum_m X[m,n]  -- bias gradients */
 long long egv_colsum_workspace_bytes(int M, int N);

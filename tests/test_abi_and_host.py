@@ -108,7 +108,7 @@ def test_missing_library_fails_loudly(tmp_path):
     env = dict(os.environ)
     pkg = tmp_path / 'egovlpv2_amd'
     pkg.mkdir()
-    for f in ('__init__.py', '_lib.py'):
+    for f in ('__init__.py', '_lib.py', 'switches.py'):
         (pkg / f).write_text(open(os.path.join(REPO, 'egovlpv2_amd', f)).read())
     r = subprocess.run([sys.executable, '-c', "import egovlpv2_amd._lib"], cwd=str(tmp_path), env=env, capture_output=True, text=True)
     assert r.returncode != 0 and 'no CPU fallback' in r.stderr
@@ -129,3 +129,40 @@ def test_data_parallel_fix_and_inflate():
     sd = make_state_dict(tiny_config(), 0)
     out = m._inflate_positional_embeds({'video_model.temporal_embed': sd['video_model.temporal_embed'].clone()})
     assert np.allclose(out['video_model.temporal_embed'][0, :, :8].numpy(), g['inflate_slice'], atol=1e-6)
+
+
+def test_switch_tables_are_the_only_readers_of_the_environment_and_defaults_are_pinned():
+    """Run-time switches: ONE table per side (csrc/egv_api.cpp: egv_config_dump(); egovlpv2_amd/switches.py), no other reader of the
+    environment in the product path, and the defaults -- the configuration that is benchmarked and tested -- equal the committed
+    tests/golden/switch_defaults.json (a changed default has to change that file too, i.e. it is a reviewed decision)."""
+    import ctypes
+    import glob
+    import json
+    import re
+    from egovlpv2_amd import _lib, switches
+    want = json.load(open(os.path.join(REPO, 'tests', 'golden', 'switch_defaults.json')))
+    for f in glob.glob(os.path.join(REPO, 'egovlpv2_amd', 'csrc', '*.[hc]*')):
+        if os.path.basename(f) != 'egv_api.cpp':
+            assert 'getenv' not in open(f).read(), f
+    for f in glob.glob(os.path.join(REPO, 'egovlpv2_amd', '**', '*.py'), recursive=True):
+        if os.path.basename(f) != 'switches.py':
+            assert not re.search(r'os\.environ|getenv', open(f).read()), f
+    got = {}
+    for line in _lib.lib.egv_config_dump().decode().strip().split('\n'):
+        name, default, current, doc = line.split('\t')
+        got[name] = float(default)
+        assert doc.strip(), name
+        if name not in os.environ:
+            assert float(current) == float(default), name
+    assert got == want['c']
+    assert switches.defaults() == want['python']
+    # every switch the C sources name is in the table with the default the call site states (the library aborts otherwise): the
+    # names used in the sources and the table agree
+    used = set()
+    for f in glob.glob(os.path.join(REPO, 'egovlpv2_amd', 'csrc', '*.[hc]*')):
+        used |= set(re.findall(r'egv_cfg_(?:on|int|f64)\("(EGV_[A-Z0-9_]+)"', open(f).read()))
+    assert used == set(got), (used ^ set(got))
+    used_py = set()
+    for f in glob.glob(os.path.join(REPO, 'egovlpv2_amd', '**', '*.py'), recursive=True):
+        used_py |= set(re.findall(r"SW\.(?:on|value)\('(EGV_[A-Z0-9_]+)'\)", open(f).read())) | set(re.findall(r"_sw\.value\('(EGV_[A-Z0-9_]+)'\)", open(f).read()))
+    assert used_py == set(switches.SWITCHES), (used_py ^ set(switches.SWITCHES))

@@ -136,3 +136,41 @@ def test_world2_full_step_vs_oracle(overlap, gsync):
         assert info['grad'] < 5e-3, info
     # the negative draws must have exercised the other-rank clip path at least once across ranks and steps
     assert sum(info['remote'] for _, _, info in res) > 0, res
+
+
+def _run_bench(nproc, extra, env_extra, port):
+    """bench.py as the driver launches it (torch.distributed.run for nproc > 1); returns rank 0's JSON line"""
+    import json
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), **env_extra)
+    base = ['bench.py', '--gpus', str(nproc), '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-gemm-events'] + extra
+    if nproc > 1:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}', '--master-addr', '127.0.0.1',
+               '--master-port', str(port)] + base
+    else:
+        cmd = [sys.executable] + base
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]                     # exactly ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_flat_grad_sync_rehearsal():
+    """`bench.py --gpus 2` the way the driver launches it (torch.distributed.run, one process per rank), on ONE GPU under
+    EGV_BENCH_REHEARSAL=1 (gloo rendezvous, both ranks on cuda:0), default gradient sync (--grad-sync flat: in-place all-reduce of the
+    per-block flat gradient buffers), the full three-loss step with the other rank's hard negatives: the launch path, the
+    max-over-ranks timing and the one-JSON-line contract, and -- dropout off -- the losses against 1-rank runs: the MLM loss is the
+    label-count-weighted mean of the two ranks' own MLM losses (no cross-rank term but the mean), EgoNCE / ITM see 16 instead of 8
+    candidates and must stay finite and in range."""
+    common = ['--batch', '4', '--frames', '4', '--drop-rate', '0']
+    two = _run_bench(2, common + ['--grad-sync', 'flat'], {'EGV_BENCH_REHEARSAL': '1'}, 29631)
+    assert two['n_gpus'] == 2 and two['steps'] == 2 and two['scaling'] == 'weak' and two['value'] > 0
+    assert two['config']['global_batch'] == 8
+    singles = [_run_bench(1, common + ['--seed-offset', str(r)], {}, 29641 + r) for r in range(2)]
+    cnt = two['losses']['mlm_labels_per_rank']
+    assert len(cnt) == 2 and [s['losses']['mlm_labels_per_rank'][0] for s in singles] == cnt
+    want = sum(s['losses']['loss_mlm'] * c for s, c in zip(singles, cnt)) / sum(cnt)
+    assert abs(two['losses']['loss_mlm'] - want) <= 2e-3 * abs(want), (two['losses'], [s['losses'] for s in singles])
+    for k in ('EgoNCE', 'loss_itm', 'loss_total'):
+        assert np.isfinite(two['losses'][k]) and 0 < two['losses'][k] < 50, two['losses']
