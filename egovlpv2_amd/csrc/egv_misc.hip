@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const long long* __rest
 template <typename T>
 __global__ __launch_bounds__(256) void text_embed_bwd_kernel(const long long* __restrict__ ids, const T* __restrict__ de,
                                                              float* __restrict__ dword, float* __restrict__ dpos, int BL, int L,
-                                                             int D, int pad) {
+                                                             int D, int pad, int accumulate) {
     extern __shared__ int pids[];                                  // [BL] position id of every token
     for (int t = threadIdx.x; t < BL; t += blockDim.x) pids[t] = position_id(ids + (long long)(t / L) * L, t % L, pad);
     __syncthreads();
@@ -231,7 +231,15 @@ __global__ __launch_bounds__(256) void text_embed_bwd_kernel(const long long* __
                     }
                 }
             }
-            if (live) st4(out + c, acc);
+            if (live) {
+                if (accumulate) {                                  // a later chunk of a long token list (chunks run one after the other)
+                    float prev[4];
+                    ld4(out + c, prev);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += prev[e];
+                }
+                st4(out + c, acc);
+            }
         }
     }
 }
@@ -554,13 +562,24 @@ extern "C" int egv_text_embed_fwd(int dtype, const long long* ids, const float* 
 
 extern "C" int egv_text_embed_bwd(int dtype, const long long* ids, const void* de, float* dword, float* dpos, int B, int L, int D,
                                   int pad_id, void* stream) {
-    dim3 grid((B * L + 3) / 4);
-    EGV_CHECK((D % 4) == 0 && (long long)B * L * 4 <= 64 * 1024, "egv_text_embed_bwd: D must be a multiple of 4 and B*L <= 16384 tokens");
-    const size_t lds = (size_t)B * L * sizeof(int);
-    if (dtype == EGV_BF16)
-        hipLaunchKernelGGL(text_embed_bwd_kernel<bf16_t>, grid, dim3(256), lds, EGV_ST, ids, (const bf16_t*)de, dword, dpos, B * L, L, D, pad_id);
-    else
-        hipLaunchKernelGGL(text_embed_bwd_kernel<float>, grid, dim3(256), lds, EGV_ST, ids, (const float*)de, dword, dpos, B * L, L, D, pad_id);
+    EGV_CHECK((D % 4) == 0 && L > 0 && L <= 16384, "egv_text_embed_bwd: D must be a multiple of 4 and L <= 16384 tokens per sequence");
+    // the kernel keeps the position ids of its token list in LDS (64 KB = 16384 tokens): longer lists go in chunks of whole
+    // sequences, one launch after the other on the stream, every chunk after the first adding to what the earlier ones wrote --
+    // still no atomics, still a fixed summation order (chunk order, then token order)
+    const int seqs = 16384 / L;
+    const size_t esz = dtype == EGV_BF16 ? 2 : 4;
+    for (int b0 = 0; b0 < B; b0 += seqs) {
+        const int nb = B - b0 < seqs ? B - b0 : seqs;
+        const int bl = nb * L;
+        const long long* idc = ids + (long long)b0 * L;
+        const char* dec = reinterpret_cast<const char*>(de) + (size_t)b0 * L * D * esz;
+        dim3 grid((bl + 3) / 4);
+        const size_t lds = (size_t)bl * sizeof(int);
+        if (dtype == EGV_BF16)
+            hipLaunchKernelGGL(text_embed_bwd_kernel<bf16_t>, grid, dim3(256), lds, EGV_ST, idc, (const bf16_t*)dec, dword, dpos, bl, L, D, pad_id, b0 > 0 ? 1 : 0);
+        else
+            hipLaunchKernelGGL(text_embed_bwd_kernel<float>, grid, dim3(256), lds, EGV_ST, idc, (const float*)dec, dword, dpos, bl, L, D, pad_id, b0 > 0 ? 1 : 0);
+    }
     EGV_LAUNCH_CHECK();
     return 0;
 }

@@ -366,12 +366,14 @@ def test_patch_tokens(ops, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-def test_text_embed(ops, dtype):
-    B, L, D, V = 3, 12, 128, 500
+@pytest.mark.parametrize('B,L', [(3, 12), (600, 32)])               # (600, 32): 19 200 tokens = two chunks of the table-gradient kernel
+def test_text_embed(ops, dtype, B, L):
+    D, V = 128, 500
     ids = torch.randint(3, V, (B, L), generator=torch.Generator().manual_seed(1))
     ids[:, 0] = 0
     ids[0, 7:] = 1
     ids[1, 10:] = 1
+    ids[B - 1, L - 3:] = 1
     word = _rnd((V, D), torch.float32, 1.0, 2).cuda().requires_grad_(True)
     pos = _rnd((40, D), torch.float32, 1.0, 3).cuda().requires_grad_(True)
     typ = _rnd((1, D), torch.float32, 1.0, 4).cuda().requires_grad_(True)
@@ -384,9 +386,10 @@ def test_text_embed(ops, dtype):
     dy = _rnd((B * L, D), dtype, 1.0, 5)
     y.backward(dy.cuda())
     y64.backward(dy.double())
-    assert _rel(word.grad, w64.grad) < 1e-5
-    assert _rel(pos.grad, p64.grad) < 1e-5
-    assert _rel(typ.grad, t64.grad) < 1e-5
+    tolg = 1e-5 if B * L < 1000 else 2e-5                                  # fp32 sums over up to B rows
+    assert _rel(word.grad, w64.grad) < tolg
+    assert _rel(pos.grad, p64.grad) < tolg
+    assert _rel(typ.grad, t64.grad) < tolg
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
