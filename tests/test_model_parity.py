@@ -110,14 +110,18 @@ def test_tiny_embeddings_and_losses_vs_oracle_and_golden(dtype, tol_e, tol_l):
 
 def _bf16_bounds(name):
     """bf16 acceptance criterion: no worse than 1.1x the distance of the REFERENCE ITSELF, run under
-    torch.autocast(bf16) the way its trainer runs it (trainer/trainer_egoclip.py:143), from its own fp32 values -- per tower for the
-    pooled embeddings; for the losses 1.1x the reference's distance or 5e-4, whichever is larger (the reference's own loss errors are
-    as small as 2e-5 on some fixtures by cancellation).  tests/golden/autocast_error.json is written by oracle/ref_autocast_error.py
-    from the imported reference."""
+    torch.autocast(bf16) the way its trainer runs it (trainer/trainer_egoclip.py:143), from its own fp32 values.
+    Pooled embeddings (relative L2 over B x 4096 values: a well-averaged statistic): per fixture and per tower.
+    Losses (ONE scalar each, computed from those embeddings through a 1 / 0.05 temperature): the reference's own realised loss errors
+    scatter over two orders of magnitude from fixture to fixture for the same code (EgoNCE: 2.4e-5, 3.9e-4, 1.8e-3) -- a single
+    realisation bounds nothing -- so the bound of a loss is 1.1x the LARGEST error the reference shows for that loss on any of the
+    fixtures (or 5e-4, whichever is larger).  tests/golden/autocast_error.json is written by oracle/ref_autocast_error.py from the
+    imported reference."""
     import json
-    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'autocast_error.json')))[name]
+    allref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'autocast_error.json')))
+    ref = allref[name]
     return ({k: 1.1 * ref[k] for k in ('text_embeds', 'video_embeds')},
-            {k: max(1.1 * ref[k], 5e-4) for k in ('EgoNCE', 'loss_mlm', 'loss_itm', 'loss_total')})
+            {k: max(1.1 * max(f[k] for f in allref.values()), 5e-4) for k in ('EgoNCE', 'loss_mlm', 'loss_itm', 'loss_total')})
 
 
 def test_tiny_egonce_only_step_fp32():
