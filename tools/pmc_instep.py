@@ -14,6 +14,10 @@ GROUPS = [('gemm_pp_kernel', r'gemm_pp_kernel'), ('gemm_ring_kernel<256x128>', r
           ('gemm_wgrad_group_kernel', r'gemm_wgrad_group_kernel'), ('attn time fwd/dq/dkv (17 keys)', r'attn_(fwd|dq|dkv)_mfma_kernel<2, 1, 0, 0>'),
           ('attn_fwd_mfma (space, 196+1 keys)', r'attn_fwd_mfma_kernel<14, 4, 0, 13>'), ('attn_dq_mfma (space)', r'attn_dq_mfma_kernel<14, 4, 0, 0>'),
           ('attn_dkv_mfma (space)', r'attn_dkv_mfma_kernel<14, 4, 0, 0>'), ('attn_bwd_fused (space: dQ+dK+dV)', r'attn_bwd_fused_kernel'),
+          ('attn_time_fwd (round 4: one wave per group, CLS query folded in)', r'attn_time_fwd_kernel'),
+          ('attn_time_bwd (round 4: one-launch backward)', r'attn_time_bwd_kernel'),
+          ('attn_space_fwd (round 4: row-major LDS images)', r'attn_space_fwd_kernel'),
+          ('attn_space_bwd (round 4: two-phase one-launch backward)', r'attn_space_bwd_kernel'),
           ('layernorm_fwd', r'layernorm_fwd_kernel'), ('layernorm_bwd', r'layernorm_bwd(_bf16)?_kernel'), ('reduce_slabs', r'reduce_slabs_kernel')]
 
 
