@@ -57,6 +57,7 @@ class VBlockDesc(C.Structure):
         ('stream', vp), ('stream2', vp),
         ('flags', i32),
         ('wq', vp * 9), ('wq_s', vp * 9), ('wtq', vp * 9), ('wtq_s', vp * 9),
+        ('x32', vp), ('out32', vp),
     ]
 
 
@@ -111,6 +112,7 @@ PROTOTYPES = {
     'egv_dropout_add': (i32, [i32, vp, vp, vp, vp, i64, f32, C.c_uint, vp]),
     'egv_dropout_add_mixed': (i32, [i32, vp, vp, vp, i32, vp, i64, f32, C.c_uint, vp]),
     'egv_layernorm_fwd_res32': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
+    'egv_sum_layernorm': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     'egv_layernorm_bwd_res32': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     'egv_cast': (i32, [i32, i32, vp, vp, i64, vp]),
     'egv_cast_transpose': (i32, [vp, vp, i32, i32, vp]),

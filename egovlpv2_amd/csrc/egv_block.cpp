@@ -409,6 +409,7 @@ extern "C" long long egv_vblock_ws_bytes(const egv_vblock_desc* d, int backward)
         if (p.ws_bytes() > attn) attn = p.ws_bytes();
     }
     size_t tot = al((size_t)attn) + 4096 + vfp8_ws_bytes(d);
+    if (!backward && (d->flags & EGV_BLOCK_RES_F32)) tot += al(M * D * es);      // the space projection's output beside the fp32 stream
     if (backward) {
         long long wg = 0;
         auto mx = [&](long long v) { if (v > wg) wg = v; };
@@ -468,6 +469,48 @@ extern "C" int egv_vblock_fwd(const egv_vblock_desc* d) {
         return lin(w, N, K, h, y, act, nullptr, pre);
     };
 
+    if (d->flags & EGV_BLOCK_RES_F32) {
+        // fp32 residual stream (bf16 GEMM operands and outputs, the three residual sums and the LayerNorm inputs in fp32: what
+        // torch.autocast keeps in fp32, trainer_egoclip.py:143).  d->x32 = the stream's fp32 value at the block input (NULL: d->x is
+        // exact), d->out32 receives the fp32 output; d->x / d->out / the saved tr, sr are their bf16 roundings -- the backward pass
+        // reads those and is unchanged.  The Linears run WITHOUT their residual epilogues; every sum is formed by the kernel that
+        // normalises it (egv_sum_layernorm) from the fp32 base and the bf16 Linear outputs.
+        if (dt != EGV_BF16 || f8.on || !d->out32) {
+            egv_set_error("egv_vblock_fwd: EGV_BLOCK_RES_F32 needs a bf16 block without MX-fp8 operands and an out32 buffer");
+            return -1;
+        }
+        void* ys = ws.take((size_t)M * D * esz(dt));
+        if (!ws.ok()) { egv_set_error("egv_vblock_fwd: workspace too small"); return -1; }
+        const float* x32 = d->x32;
+        auto sumln = [&](const void* d1, const void* d2, const void* dg, float* s32, void* s16, void* y, int ln, float* stats) -> int {
+            return egv_sum_layernorm(x32, x32 ? nullptr : d->x, d1, d2, dg, dg ? d->alpha : nullptr, s32, s16, y, y ? d->ln_g[ln] : nullptr,
+                                     y ? d->ln_b[ln] : nullptr, stats, M, D, d->eps, st);
+        };
+        BCHK(sumln(nullptr, nullptr, nullptr, nullptr, nullptr, sv + L.h3, VL_NORM3, (float*)(sv + L.stats3)));
+        BCHK(lin(VW_TQKV, 3 * D, D, sv + L.h3, sv + L.qkv_t, 0, nullptr, nullptr));
+        BCHK(dvt.fwd(sv + L.qkv_t, sv + L.tctx, (float*)(sv + L.lse_t), aws, awb, st));
+        BCHK(lin(VW_TPROJ, D, D, sv + L.tctx, sv + L.tr, 0, nullptr, nullptr));                    // the projection, then tr = x + it in place
+        BCHK(sumln(sv + L.tr, nullptr, nullptr, nullptr, sv + L.tr, sv + L.h1, VL_NORM1, (float*)(sv + L.stats1)));
+        BCHK(lin(VW_SQKV, 3 * D, D, sv + L.h1, sv + L.qkv_s, 0, nullptr, nullptr));
+        BCHK(dvs.fwd(sv + L.qkv_s, sv + L.sctx, (float*)(sv + L.lse_s), aws, awb, st));
+        const void *a1, *ag = nullptr;                                                             // sr = x + a1 (+ alpha * ag)
+        if (!fused) {
+            BCHK(lin(VW_SPROJ, D, D, sv + L.sctx, ys, 0, nullptr, nullptr));
+            a1 = ys;
+        } else {
+            const int BL = d->B * d->L;
+            BCHK(lin(VW_SPROJ, D, D, sv + L.sctx, sv + L.s, 0, nullptr, nullptr));
+            BCHK(lin_fwd(dt, BL, 2 * D, D, d->y, d->w[VW_KV_I2T], d->b[VW_KV_I2T], sv + L.kv, 0, nullptr, nullptr, nullptr, nullptr, st));
+            BCHK(ln_lin(VL_NORM_I2T, sv + L.s, sv + L.hs, (float*)(sv + L.stats_i), VW_Q_I2T, D, D, sv + L.q, 0, nullptr));
+            BCHK(px.fwd(sv + L.q, D, sv + L.kv, at(sv + L.kv, (size_t)D * esz(dt)), 2 * D, sv + L.o, (float*)(sv + L.lse_x), aws, awb, st));
+            BCHK(lin_fwd(dt, M, D, D, sv + L.o, d->w[VW_PROJ_I2T], d->b[VW_PROJ_I2T], sv + L.pg, 0, nullptr, nullptr, nullptr, nullptr, st));
+            a1 = sv + L.s; ag = sv + L.pg;
+        }
+        BCHK(sumln(a1, nullptr, ag, nullptr, sv + L.sr, sv + L.h2, VL_NORM2, (float*)(sv + L.stats2)));
+        BCHK(lin(VW_FC1, Hd, D, sv + L.h2, sv + L.act, mlp_act(dt), nullptr, sv + L.pre));
+        BCHK(lin(VW_FC2, D, Hd, sv + L.act, d->out, 0, nullptr, nullptr));                         // the MLP's output, then out = sr + it in place
+        return sumln(a1, d->out, ag, d->out32, d->out, nullptr, 0, nullptr);
+    }
     // temporal attention (video_transformer.py:217-218): x + proj(attn(qkv(norm3 x)))
     BCHK(ln_lin(VL_NORM3, d->x, sv + L.h3, (float*)(sv + L.stats3), VW_TQKV, 3 * D, D, sv + L.qkv_t, 0, nullptr));
     BCHK(dvt.fwd(sv + L.qkv_t, sv + L.tctx, (float*)(sv + L.lse_t), aws, awb, st));

@@ -95,6 +95,7 @@ __device__ __forceinline__ float dgelu_f(float x) {
     return cdf + x * pdf;
 }
 
+#ifdef EGV_GELU_OLD
 // GELU / GELU' for the bf16 storage mode: Phi(x) from the Abramowitz-Stegun 7.1.26 rational form of erf (absolute error
 // < 1.5e-7, far below the 2^-9 rounding of the bf16 value that is stored).  The negative tail is formed without
 // cancellation (Phi(x<0) = q, Phi(x>=0) = 1 - q) and the same exp(-x^2/2) serves the density in the derivative; about half
@@ -128,6 +129,39 @@ __device__ __forceinline__ void gelu_pair_fast_f(float x, float& g, float& d) {
     g = x * cdf;
     d = cdf + x * 0.39894228040143267794f * e;
 }
+
+#else
+// GELU / GELU' for the bf16 storage mode.  Phi(x) = 1 / (1 + 2^(x P(|x|))): the logit of the normal distribution function is x times a
+// smooth even function, P is its degree-5 fit in |x| (minimax on the RELATIVE error of x Phi(x) over |x| <= 6 with a floor of 2e-3 on the
+// magnitude; -log2(e) folded into the coefficients; tools/fit_gelu.py).  x Phi(x) within 4.0e-5 relative (6.6e-6 absolute), the
+// derivative within 1.8e-5 absolute: below 1/25 of the 2^-9 rounding of the bf16 value that is stored.  10 VALU instructions per
+// value (5 FMA, 2 transcendentals, no select) against 19 for a rational erfc form: the fc1 / fc2-dgrad epilogues (128 values per
+// thread and tile) are bound by VALU issue, not by the MFMA pipe (profiles/round4_experiments.md section 6).  x P(|x|) is monotone,
+// +-huge inputs give x or -0, no NaN for finite x.
+__device__ __forceinline__ float phi_fast_f(float x) {
+    const float a = fabsf(x);
+    float p = fmaf(-0.0004328800132498145f, a, 0.005315648391842842f);
+    p = fmaf(p, a, -0.014343290589749813f);
+    p = fmaf(p, a, -0.08734285086393356f);
+    p = fmaf(p, a, -0.00952006783336401f);
+    p = fmaf(p, a, -2.300459146499634f);
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * p));
+}
+__device__ __forceinline__ float gelu_fast_f(float x) { return x * phi_fast_f(x); }
+__device__ __forceinline__ float dgelu_fast_f(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);      // exp(-x^2 / 2)
+    return fmaf(x * 0.39894228040143267794f, e, phi_fast_f(x));
+}
+
+// GELU and its derivative from ONE evaluation of Phi (the pair the EGV_ACT_GELU_D epilogues store)
+__device__ __forceinline__ void gelu_pair_fast_f(float x, float& g, float& d) {
+    const float cdf = phi_fast_f(x);
+    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);
+    g = x * cdf;
+    d = fmaf(x * 0.39894228040143267794f, e, cdf);
+}
+
+#endif
 
 // bijective XCD-aware remap of a linear workgroup id (cdna_hip_programming.md §5 template):
 // consecutive logical tiles land on the same XCD (= same L2) instead of round-robin over the 8 XCDs.

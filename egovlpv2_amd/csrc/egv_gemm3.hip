@@ -32,6 +32,14 @@
 #include "egv_gemm.h"
 #include <cstdlib>
 
+// cache policy of the epilogue's stores / one-time operand loads (aux bits of the buffer instructions: 2 = nt)
+#ifndef PP_ST_AUX
+#define PP_ST_AUX 0
+#endif
+#ifndef PP_LD_AUX
+#define PP_LD_AUX 0
+#endif
+
 namespace egv {
 
 typedef __attribute__((address_space(3))) void* lptr3_t;
@@ -111,9 +119,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
 #ifndef EGV_PP_EXP
 #define EGV_PP_EXP 0
 #endif
-    // EGV_PP_EXP (tools/pp_exp.sh, never in the product build): 1 = the epilogue stores are dropped; 2 = dropped and replaced by the same
+    // EGV_PP_EXP (tools/pp_exp.sh, never in the product build): 1 = the epilogue stores are dropped; 3 = the residual / GELU' operand loads are dropped; 2 = stores dropped and replaced by the same
     // number of stores trickled one per wave into phases 1 and 3 of the tile's plain K-tiles (counted waits left conservative)
-    constexpr int NSP = EGV_PP_EXP ? 0 : (PREK ? 4 : 2) * IM + (QOUT ? 3 * IM : 0);
+    constexpr int NSP = (EGV_PP_EXP == 1 || EGV_PP_EXP == 2) ? 0 : (PREK ? 4 : 2) * IM + (QOUT ? 3 * IM : 0);
     constexpr bool BULK = X1K != 0;                                // residual / GELU' operand: epilogue in one piece at the tile's end
     constexpr unsigned int OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -258,6 +266,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
     const __amdgpu_buffer_rsrc_t rs_q = mk(QOUT ? e.oq : nullptr, (long long)g.M * g.N);
     const __amdgpu_buffer_rsrc_t rs_s = mk(QOUT ? e.os : nullptr, (long long)(g.N >> 7) * (((g.M + 191) / 192) * 4) * 256);
     const float gate = e.gate ? *e.gate : 1.0f;
+    const bool has_gate = e.gate != nullptr;
 
     // quadrant q (= the phase that computes it): (s, t) = (0,0) (0,1) (1,1) (1,0)
     // element (s, i, t) of a lane: row m0 + wr*128 + s*64 + i*16 + fr, columns n0 + wc*64 + t*32 + fg*8 .. +7.
@@ -351,11 +360,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                     pr[t] = u32x4_t{pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]), pack_bf16x2(pv[4], pv[5]), pack_bf16x2(pv[6], pv[7])};
                 }
                 pair_swap(pr[0], pr[1], f, sec);
-#if EGV_PP_EXP
+#if EGV_PP_EXP == 1 || EGV_PP_EXP == 2
                 asm volatile("" :: "v"(f), "v"(sec));
 #else
-                __builtin_amdgcn_raw_buffer_store_b128(f, rs_pre, p_off(tl, s, i, 0, false), 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(sec, rs_pre, p_off(tl, s, i, 1, false), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(f, rs_pre, p_off(tl, s, i, 0, false), 0, PP_ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(sec, rs_pre, p_off(tl, s, i, 1, false), 0, PP_ST_AUX);
 #endif
             }
             u32x4_t o[2];
@@ -376,8 +385,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                         for (int k = 0; k < 8; ++k) v[k] = apply_act(v[k], e.act);
                     }
                 }
+                if (X1K == 3 || has_gate) {                       // (x * 1.0f is x: skipping the multiply changes no bit)
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { v[k] *= gate; asm volatile("" : "+v"(v[k])); }   // not contracted with the residual add (bit-equal across the GEMM kernels)
+                    for (int k = 0; k < 8; ++k) { v[k] *= gate; asm volatile("" : "+v"(v[k])); }   // not contracted with the residual add (bit-equal across the GEMM kernels)
+                }
                 if (X1K == 1 || X1K == 3) {
                     const u32x4_t r = xop[s][i][t];
 #pragma unroll
@@ -451,11 +462,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                 }
             }
             pair_swap(o[0], o[1], f, sec);
-#if EGV_PP_EXP
+#if EGV_PP_EXP == 1 || EGV_PP_EXP == 2
             asm volatile("" :: "v"(f), "v"(sec));
 #else
-            __builtin_amdgcn_raw_buffer_store_b128(f, rs_c, p_off(tl, s, i, 0, true), 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(sec, rs_c, p_off(tl, s, i, 1, true), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(f, rs_c, p_off(tl, s, i, 0, true), 0, PP_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(sec, rs_c, p_off(tl, s, i, 1, true), 0, PP_ST_AUX);
 #endif
         }
     };
@@ -636,7 +647,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                 for (int i = 0; i < IM; ++i)
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
-                        xop[s][i][t] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, q_off(cur, true, s, i, t, false), 0, 0);
+#if EGV_PP_EXP == 3                                                   // experiment: no operand loads (the VALU work and the stores stay)
+                    { xop[s][i][t] = u32x4_t{0x3f803f80u, 0x3f003f00u, 0xbf80bf80u, 0x40004000u}; asm volatile("" : "+v"(xop[s][i][t])); }
+#else
+                        xop[s][i][t] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, q_off(cur, true, s, i, t, false), 0, PP_LD_AUX);
+#endif
             if constexpr (X1K == 3) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
@@ -646,7 +661,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                         for (int t = 0; t < 2; ++t)
                             xop2[s][i][t] = __builtin_amdgcn_raw_buffer_load_b128(rs_x2, q_off(cur, true, s, i, t, false), 0, 0);
             }
-            pp_wait_vmcnt<6 + (MX ? 1 : 0) + (X1K == 3 ? 8 : 4) * IM>();                // the bias DMA of LAST phase 1 (16 operand loads are younger)
+            pp_wait_vmcnt<6 + (MX ? 1 : 0) + (EGV_PP_EXP == 3 ? 0 : (X1K == 3 ? 8 : 4) * IM)>();                // the bias DMA of LAST phase 1 (16 operand loads are younger)
             pair_epilogue(0, cur);
             pair_epilogue(1, cur);
         }

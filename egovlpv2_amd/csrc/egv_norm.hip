@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
         stats[2 * (size_t)row] = mean;
         stats[2 * (size_t)row + 1] = rstd;
     }
+    if (!y) return;                                               // statistics only (EGV_EXP_LN_STATS_ONLY, a timing experiment)
     T* yr = y + (size_t)row * D;
 #pragma unroll
     for (int j = 0; j < LN_MAXV; ++j) {
@@ -84,6 +85,106 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
                     const int kb = c >> 5, blk = row / 48, rb = row - blk * 48, nblk = ((M + 191) / 192) * 4;
                     mxs[(((size_t)(kb >> 2) * nblk + blk) * 4 + (kb & 3)) * 64 + (rb & 15) * 4 + (rb >> 4)] = (unsigned char)e8;
                 }
+            }
+        }
+    }
+}
+
+// fp32 residual stream of the video tower in the bf16 mode (EGV_BLOCK_RES_F32 of egv_vblock_fwd): the residual sums of a
+// SpaceTimeBlock (video_transformer.py:218,222,226) and the LayerNorm that reads them are formed in fp32, as torch.autocast keeps
+// them (trainer_egoclip.py:143) -- s = base + d1 + d2 + gate * dg with base in fp32 (or, at the head of the stream, bf16) and the
+// Linear outputs d1 / d2 / dg in bf16; s leaves as fp32 (sum32) and / or bf16 (sum16: what the backward pass and the GEMMs read),
+// y = LayerNorm(s) in bf16 is the next Linear's operand.  One wave per row, every operand read once.
+#ifndef EGV_SUMLN_ROWS
+#define EGV_SUMLN_ROWS 1
+#endif
+template <int R>                                                   // rows per wave, all of their loads in flight together
+__global__ __launch_bounds__(256) void sum_ln_kernel(const float* __restrict__ base32, const bf16_t* __restrict__ base16,
+                                                     const bf16_t* d1, const bf16_t* d2, const bf16_t* dg,      // (sum16 may alias one of them)
+                                                     const float* __restrict__ gate,
+                                                     float* __restrict__ sum32, bf16_t* sum16, bf16_t* __restrict__ y,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ stats, int M, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + wave_id()) * R;
+    if (row0 >= M) return;
+    const float gt = (dg && gate) ? *gate : 1.0f;
+    float v[R][LN_MAXV][4];
+    float t1[R][LN_MAXV][4], t2[R][LN_MAXV][4], t3[R][LN_MAXV][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const size_t ro = (size_t)min(row0 + r, M - 1) * D;         // (a row past the end re-reads the last one and stores nothing)
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const int c = (j * 64 + lane) * 4;
+            if (c < D) {
+                if (base32) ld4(base32 + ro + c, v[r][j]);
+                else ld4(base16 + ro + c, v[r][j]);
+                if (d1) ld4(d1 + ro + c, t1[r][j]);
+                if (d2) ld4(d2 + ro + c, t2[r][j]);
+                if (dg) ld4(dg + ro + c, t3[r][j]);
+            }
+        }
+    }
+    float s[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const bool live = row0 + r < M;
+        const size_t ro = (size_t)min(row0 + r, M - 1) * D;
+        s[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const int c = (j * 64 + lane) * 4;
+            if (c < D) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a = v[r][j][e];
+                    if (d1) a += t1[r][j][e];
+                    if (d2) a += t2[r][j][e];
+                    if (dg) a += gt * t3[r][j][e];
+                    v[r][j][e] = a;
+                }
+                if (live) {
+                    if (sum32) st4(sum32 + ro + c, v[r][j]);
+                    if (sum16) st4(sum16 + ro + c, v[r][j]);
+                }
+                s[r] += v[r][j][0] + v[r][j][1] + v[r][j][2] + v[r][j][3];
+            } else {
+                v[r][j][0] = v[r][j][1] = v[r][j][2] = v[r][j][3] = 0.f;
+            }
+        }
+    }
+    if (!y) return;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = row0 + r;
+        const float mean = wave_sum(s[r]) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const int c = (j * 64 + lane) * 4;
+            if (c < D) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dlt = v[r][j][e] - mean;
+                    q += dlt * dlt;
+                }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+        if (row >= M) continue;
+        if (stats && lane == 0) {
+            stats[2 * (size_t)row] = mean;
+            stats[2 * (size_t)row + 1] = rstd;
+        }
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const int c = (j * 64 + lane) * 4;
+            if (c < D) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (v[r][j][e] - mean) * rstd * gamma[c + e] + beta[c + e];
+                st4(y + (size_t)row * D + c, o);
             }
         }
     }
@@ -531,6 +632,10 @@ extern "C" int egv_layernorm_fwd(int dtype, const void* x, void* y, const float*
     LnProf prof(stream, 30, 2.0 * M * D * (dtype == EGV_BF16 ? 2 : 4));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((M + 3) / 4);
+    // timing experiment ("LayerNorm inside the GEMM"): the LayerNorms of the video tokens only compute their
+    // statistics -- what a GEMM with a normalising prologue would still need as a separate pass; y keeps whatever it held
+    static const bool stats_only = egv_cfg_on("EGV_EXP_LN_STATS_ONLY", false);
+    if (stats_only && M >= 4096 && stats) y = nullptr;
     if (dtype == EGV_BF16)
         hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, gamma, beta, stats, M, D, eps);
     else
@@ -558,6 +663,22 @@ extern "C" int egv_layernorm_fwd_res32(const float* x, float* y, void* y16, cons
     EGV_CHECK(D % 4 == 0 && D <= LN_MAXV * 256 && M > 0, "egv_layernorm_fwd_res32: M=%d D=%d unsupported", M, D);
     hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3((M + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y, gamma, beta, stats,
                        M, D, eps, (bf16_t*)y16);
+    EGV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int egv_sum_layernorm(const float* base32, const void* base16, const void* d1, const void* d2, const void* dg, const float* gate,
+                                 float* sum32, void* sum16, void* y, const float* gamma, const float* beta, float* stats, int M, int D,
+                                 float eps, void* stream) {
+    EGV_CHECK(D % 4 == 0 && D <= LN_MAXV * 256 && M > 0, "egv_sum_layernorm: M=%d D=%d unsupported", M, D);
+    EGV_CHECK((base32 != nullptr) != (base16 != nullptr), "egv_sum_layernorm: exactly one of base32 / base16");
+    EGV_CHECK(!y || (gamma && beta), "egv_sum_layernorm: LayerNorm output without its affine terms");
+    EGV_CHECK(y || sum32 || sum16, "egv_sum_layernorm: no output");
+    double bytes = (double)M * D * ((base32 ? 4 : 2) + (d1 ? 2 : 0) + (d2 ? 2 : 0) + (dg ? 2 : 0) + (sum32 ? 4 : 0) + (sum16 ? 2 : 0) + (y ? 2 : 0));
+    LnProf prof(stream, 30, bytes);
+    constexpr int R = EGV_SUMLN_ROWS;
+    hipLaunchKernelGGL(sum_ln_kernel<R>, dim3((M + 4 * R - 1) / (4 * R)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), base32, (const bf16_t*)base16,
+                       (const bf16_t*)d1, (const bf16_t*)d2, (const bf16_t*)dg, gate, sum32, (bf16_t*)sum16, (bf16_t*)y, gamma, beta, stats, M, D, eps);
     EGV_LAUNCH_CHECK();
     return 0;
 }

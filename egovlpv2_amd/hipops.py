@@ -1154,7 +1154,7 @@ class VideoBlockFn(Function):
 
     @staticmethod
     def _desc(cfg, x, y, y_mask, params):
-        B, Fr, N, H, Hd, eps, L_, _track, fp8 = cfg
+        B, Fr, N, H, Hd, eps, L_, _track, fp8 = cfg[:9]
         fused = L_ > 0
         d = L.VBlockDesc()
         d.dtype, d.B, d.F, d.N, d.H, d.D, d.Hd, d.L, d.eps = _dt(x), B, Fr, N, H, x.shape[1], Hd, L_, eps
@@ -1187,24 +1187,34 @@ class VideoBlockFn(Function):
         assert x.dim() == 2 and x.is_contiguous()
         d = VideoBlockFn._desc(cfg, x, y, y_mask, params)
         out = torch.empty_like(x)
+        res32, x32 = cfg[9], cfg[10]
+        out32 = None
+        if res32:
+            # the fp32 residual stream rides beside the bf16 tensors autograd sees (x32: the fp32 value x is the rounding of, or None)
+            out32 = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+            d.flags |= L.BLOCK_RES_F32
+            d.x32, d.out32 = _p(x32), _p(out32)
         nsave = lib.egv_vblock_save_bytes(C.byref(d))
         save = torch.empty(nsave, dtype=torch.uint8, device=x.device)
         ws = workspace(lib.egv_vblock_ws_bytes(C.byref(d), 0), x.device, slot=2)
         d.out, d.save, d.save_bytes, d.ws, d.ws_bytes = _p(out), _p(save), nsave, _p(ws), ws.numel()
         check(lib.egv_vblock_fwd(C.byref(d)), 'egv_vblock_fwd')
-        ctx.cfg = cfg
+        ctx.cfg = cfg[:9]
         ctx.key = ('v', id(params[0]))
         ctx.tail = bool(cfg[7] and _first_vblock[0] and SW.on('EGV_WGRAD_TAIL'))
         if cfg[7]:
             _first_vblock[0] = False
         _acc_forward(ctx.key, cfg[7], cfg[6] > 0)
         ctx.save_for_backward(x, y, y_mask, save, *params)
+        if res32:
+            ctx.mark_non_differentiable(out32)
+            return out, out32
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, *_unused):
         x, y, y_mask, save, *params = ctx.saved_tensors
-        cfg = ctx.cfg
+        cfg = ctx.cfg[:9]
         fused = cfg[6] > 0
         dout = dout.contiguous()
         d = VideoBlockFn._desc(cfg, x, y, y_mask, params)
@@ -1242,9 +1252,49 @@ class VideoBlockFn(Function):
         return (None, dx, dy, None, *_acc_backward(ctx.key, gp, params, 18, side))
 
 
+class StreamRowsFn(Function):
+    """first row of every sample of a video residual-stream tensor, read from its fp32 value x32; the gradient goes to x (the
+    bf16 tensor autograd tracks), exactly as for x.reshape(B, rows, -1)[:, 0]"""
+
+    @staticmethod
+    def forward(ctx, x, x32, B, rows):
+        ctx.meta = (x.shape, x.dtype, B, rows)
+        return x32.reshape(B, rows, -1)[:, 0].contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, dtype, B, rows = ctx.meta
+        dx = torch.zeros(shape, dtype=dtype, device=g.device)
+        dx.reshape(B, rows, -1)[:, 0] = g.to(dtype)
+        return dx, None, None, None
+
+
+def stream_rows(x, x32, B, rows):
+    return StreamRowsFn.apply(x, x32, B, rows)
+
+
+def video_res32(x, fp8=False):
+    """does a video block on x run with the fp32 residual stream (EGV_VIDEO_RES32; bf16 storage without MX-fp8 operands)?"""
+    return x.dtype == torch.bfloat16 and not fp8 and SW.on('EGV_VIDEO_RES32')
+
+
+def stream32(x):
+    """the fp32 value of a video residual-stream tensor whose bf16 rounding is x (None: x itself is all there is)"""
+    return getattr(x, '_res32', None)
+
+
 def video_block(x, params, B, Fr, N, H, Hd, eps, y=None, y_mask=None, L=0, fp8=False):
-    """fp8: the forward / dgrad GEMMs over the video tokens on MX-fp8 operands (bf16 mode only; BASELINE.json configs[4])"""
-    return VideoBlockFn.apply((B, Fr, N, H, Hd, float(eps), L if y is not None else 0, _tracks_grad(params), bool(fp8)), x, y, y_mask, *params)
+    """fp8: the forward / dgrad GEMMs over the video tokens on MX-fp8 operands (bf16 mode only; BASELINE.json configs[4]).
+    With EGV_VIDEO_RES32 (bf16 mode) the residual stream is fp32, as under the reference's autocast (trainer_egoclip.py:143): the
+    returned bf16 tensor -- the one autograd sees, GEMMs read and the backward pass uses -- carries its fp32 value as `._res32`,
+    which the next block (and the final LayerNorm) picks up."""
+    res32 = video_res32(x, fp8)
+    cfg = (B, Fr, N, H, Hd, float(eps), L if y is not None else 0, _tracks_grad(params), bool(fp8), res32, stream32(x) if res32 else None)
+    if not res32:
+        return VideoBlockFn.apply(cfg, x, y, y_mask, *params)
+    out, out32 = VideoBlockFn.apply(cfg, x, y, y_mask, *params)
+    out._res32 = out32
+    return out
 
 
 class TextLayerFn(Function):

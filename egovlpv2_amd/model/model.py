@@ -390,6 +390,15 @@ class FrozenInTime(nn.Module):
     def _cls_rows(self, x, B, rows_per_sample):
         return x.reshape(B, rows_per_sample, -1)[:, 0].contiguous()
 
+    def _video_out_norm(self, x, B, prefix, eps):
+        """LayerNorm of the CLS rows of the video stream (video_model.norm, video_transformer.py:392-394; self.norm, model.py:275).
+        With the fp32 residual stream (ops.video_block under EGV_VIDEO_RES32) the rows come from the stream's fp32 value and the
+        LayerNorm runs in fp32, as under the reference's autocast; its result is the next Linear's operand either way."""
+        x32 = ops.stream32(x)
+        if x32 is None:
+            return self._ln(self._cls_rows(x, B, self.cfg.seq), prefix, eps)
+        return ops.CastFn.apply(self._ln(ops.stream_rows(x, x32, B, self.cfg.seq), prefix, eps), self.compute_dtype)
+
     def _proj_mlp(self, x, prefix):
         """txt_proj / vid_proj (model.py:105-115); cfg.proj_style 'linear': the fine-tune variant's txt ReLU-Linear / vid Linear
         (model_epic_charades.py:116-119)"""
@@ -497,7 +506,7 @@ class FrozenInTime(nn.Module):
         x = self._patch_tokens(video_data, 'video_model.cls_token')
         for i in range(self.cfg.depth):
             x = self._video_block(x, i, B)
-        return self._ln(self._cls_rows(x, B, self.cfg.seq), 'video_model.norm', self.cfg.eps_video)
+        return self._video_out_norm(x, B, 'video_model.norm', self.cfg.eps_video)
 
     def compute_video(self, video_data):
         """model.py:524-530: SpaceTimeTransformer.forward_features (video_model.cls_token / video_model.norm) -> vid_proj."""
@@ -569,7 +578,7 @@ class FrozenInTime(nn.Module):
             B, L = text_data['input_ids'].shape
             v, t = self._fused_stack(video_data, text_data['input_ids'], text_data['attention_mask'],
                                      video_prefix=data.get('_video_prefix'), text_prefix=data.get('_text_prefix'))
-            vf = self._ln(self._cls_rows(v, B, c.seq), 'norm', c.eps_model_norm)            # self.norm(v)[:, 0]  (:275)
+            vf = self._video_out_norm(v, B, 'norm', c.eps_model_norm)                       # self.norm(v)[:, 0]  (:275)
             tf = self._lin(self._text_operand(self._cls_rows(t, B, L)), 'cross_modal_text_transform')
             vf = self._lin(vf, 'cross_modal_video_transform')
             ct = self._lin(tf, 'cross_modal_text_pooler.dense', act='tanh')

@@ -128,6 +128,14 @@ int egv_layernorm_fwd_res32(const float* x, float* y, void* y16, const float* ga
                             float eps, void* stream);
 int egv_layernorm_bwd_res32(const void* dy16, const float* dy32, const float* x, const float* stats, const float* gamma,
                             const float* add32, float* dx, float* dgamma, float* dbeta, int M, int D, void* workspace, void* stream);
+/* fp32 residual stream of the video tower inside the bf16 mode (EGV_BLOCK_RES_F32 of egv_vblock_fwd): a residual sum of
+ * SpaceTimeBlock.forward (video_transformer.py:218,222,226) formed in fp32 by the kernel that normalises it --
+ * s = base + d1 + d2 + (*gate) * dg, base = base32 (fp32) or base16 (bf16; exactly one of the two), d1 / d2 / dg = bf16 Linear outputs
+ * (each may be NULL; gate NULL = 1); outputs, each optional: sum32 = s, sum16 = bf16(s), y = bf16(LayerNorm(s)) with stats[M][2] =
+ * (mean, rstd).  sum16 may alias d1 / d2 / dg (element-wise in place). */
+int egv_sum_layernorm(const float* base32, const void* base16, const void* d1, const void* d2, const void* dg, const float* gate,
+                      float* sum32, void* sum16, void* y, const float* gamma, const float* beta, float* stats, int M, int D, float eps,
+                      void* stream);
 int egv_cast(int dtype_src, int dtype_dst, const void* src, void* dst, long long n, void* stream);
 /* dst[C][R] (bf16) = src[R][C] (fp32): transposed bf16 compute copy of a weight, so that dgrad runs in the NT form */
 int egv_cast_transpose(const float* src, void* dst, int R, int C, void* stream);
@@ -283,7 +291,8 @@ int egv_adamw_step(const void* table, const int* prefix, int ntensors, int nchun
  * Weight order: timeattn.qkv, timeattn.proj, attn.qkv, attn.proj, mlp.fc1, mlp.fc2; LayerNorm order: norm3, norm1, norm2. */
 #define EGV_BLOCK_NO_JOIN 1
 #define EGV_BLOCK_RES_F32 2
-      /* egv_tlayer_*: hid / out / dout / dhid are fp32 (the text tower's fp32 residual stream), dtype = EGV_BF16 */
+      /* egv_tlayer_*: hid / out / dout / dhid are fp32 (the text tower's fp32 residual stream), dtype = EGV_BF16;
+         egv_vblock_fwd: the fp32 stream rides beside the bf16 tensors (x32 / out32 below) */
 #define EGV_BLOCK_FP8 4       /* egv_vblock_*: MX-fp8 forward / dgrad GEMMs where the desc carries quantised weights */
 #define EGV_BLOCK_TAIL 8      /* egv_vblock_bwd with EGV_BLOCK_NO_JOIN: nothing but the join follows this call on the calling stream (the last block of a
                                  backward pass): its grouped weight-gradient launch gets 7/8 of the CUs instead of its share */
@@ -307,6 +316,11 @@ typedef struct egv_vblock_desc {
      * dgrad over the M video tokens as egv_gemm_mx on activations quantised on the fly (role 0); NULL entries, the weight gradients,
      * the gated i2t projection and the B*L-row text projections stay bf16. */
     const void* wq[9]; const void* wq_s[9]; const void* wtq[9]; const void* wtq_s[9];
+    /* EGV_BLOCK_RES_F32 (egv_vblock_fwd, bf16 blocks without EGV_BLOCK_FP8): the residual stream in fp32, as torch.autocast keeps it
+     * (trainer_egoclip.py:143; the sums at video_transformer.py:218,222,226 and the LayerNorms that read them).  x32 [B*S, D] = the
+     * stream's fp32 value at the block input (NULL: x is exact), out32 receives the fp32 output; x / out stay the bf16 roundings
+     * (GEMM operands, and all egv_vblock_bwd reads).  The backward pass ignores both fields. */
+    const float* x32; float* out32;
 } egv_vblock_desc;
 long long egv_vblock_save_bytes(const egv_vblock_desc* d);
 long long egv_vblock_ws_bytes(const egv_vblock_desc* d, int backward);

@@ -660,9 +660,11 @@ def test_persistent_gemm_bitwise_equals_ring_gemm(ops, N, K, kind):
 
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('fused', [False, True])
-def test_block_entry_points_match_per_op_composition(ops, dtype, fused):
+def test_block_entry_points_match_per_op_composition(ops, dtype, fused, monkeypatch):
     """egv_vblock_* / egv_tlayer_* (csrc/egv_block.cpp) against the same block composed from the per-operation entry points:
-    identical forward values (same kernels, same order), gradients equal up to the order of the skip-gradient sums."""
+    identical forward values (same kernels, same order), gradients equal up to the order of the skip-gradient sums.  (The video
+    block with its residual sums in the GEMM epilogues, EGV_VIDEO_RES32=0; the fp32-stream form has its own test below.)"""
+    monkeypatch.setenv('EGV_VIDEO_RES32', '0')
     dev = 'cuda'
     B, L, H, D, Hd, Fr, N = 2, 16, 12, 768, 3072, 4, 49
     S = 1 + Fr * N
@@ -747,6 +749,110 @@ def test_block_entry_points_match_per_op_composition(ops, dtype, fused):
             if not (name == 'text' and i in (3, 19)):     # key biases have an exactly-zero true gradient: noise / noise
                 # (the gate gradients are dot products of two noisy bf16 vectors: a looser bound)
                 assert _rel(bb, a.double().cpu()) < (1e-5 if dtype == torch.float32 else (1e-1 if a.numel() == 1 else 2e-2)), (name, i)
+
+
+def test_sum_layernorm_vs_torch(ops):
+    """egv_sum_layernorm: s = base + d1 + d2 + gate * dg in fp32 (fp32 or bf16 base), its fp32 / bf16 forms and LayerNorm(s), against
+    torch on the same operands; in-place form (sum16 aliasing d1); a width that is not a multiple of 256 and a ragged row count."""
+    import ctypes as C
+    from egovlpv2_amd import _lib as L
+    for M, D in ((1571, 768), (333, 520)):
+        base32 = _rnd((M, D), torch.float32, 2.0, 1).cuda()
+        d1, d2, dg = (_rnd((M, D), torch.bfloat16, 1.0, 2 + i).cuda() for i in range(3))
+        gate = torch.tensor([0.37], device='cuda')
+        gamma, beta = _rnd((D,), torch.float32, 1.0, 7).cuda(), _rnd((D,), torch.float32, 0.1, 8).cuda()
+        for b32 in (True, False):
+            base = base32 if b32 else base32.bfloat16()
+            s32 = torch.empty(M, D, device='cuda')
+            s16 = torch.empty(M, D, device='cuda', dtype=torch.bfloat16)
+            y = torch.empty_like(s16)
+            stats = torch.empty(M, 2, device='cuda')
+            p = lambda t: C.c_void_p(t.data_ptr())        # noqa: E731
+            rc = L.lib.egv_sum_layernorm(p(base) if b32 else None, None if b32 else p(base), p(d1), p(d2), p(dg), p(gate), p(s32), p(s16), p(y),
+                                         p(gamma), p(beta), p(stats), M, D, 1e-5, None)
+            assert rc == 0, L.lib.egv_last_error()
+            torch.cuda.synchronize()
+            ref = base.double() + d1.double() + d2.double() + 0.37 * dg.double()
+            assert _rel(s32, ref.cpu()) < 1e-6
+            assert torch.equal(s16, s32.bfloat16())
+            ln = torch.nn.functional.layer_norm(s32.double(), (D,), gamma.double(), beta.double(), 1e-5)
+            assert _rel(y, ln.cpu()) < 4e-3
+            assert _rel(stats[:, 0], s32.double().mean(1).cpu()) < 1e-5
+            # in place: the Linear output becomes the sum, only the LayerNorm output is new
+            d1c = d1.clone()
+            rc = L.lib.egv_sum_layernorm(p(base) if b32 else None, None if b32 else p(base), p(d1c), None, None, None, None, p(d1c), p(y),
+                                         p(gamma), p(beta), None, M, D, 1e-5, None)
+            assert rc == 0, L.lib.egv_last_error()
+            torch.cuda.synchronize()
+            assert torch.equal(d1c, (base.float() + d1.float()).bfloat16())
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_video_block_fp32_residual_stream(ops, fused, monkeypatch):
+    """EGV_VIDEO_RES32 (the default of the bf16 mode): SpaceTimeBlock.forward with its three residual sums and LayerNorm inputs in fp32
+    (video_transformer.py:217-226 under trainer_egoclip.py:143's autocast).  Against the block composed from the per-operation
+    entry points (bf16 GEMMs without residual epilogues) with the sums and LayerNorms in torch fp32; the bf16 output is the rounding
+    of the fp32 one; a second block continues from the fp32 value; over a stack of blocks the fp32 stream stays closer to fp32
+    arithmetic than the bf16 stream does."""
+    F = torch.nn.functional
+    B, L, H, D, Hd, Fr, N = 2, 16, 12, 768, 3072, 4, 49
+    S = 1 + Fr * N
+    seeds = iter(range(500, 900))
+    mk = lambda shape, sc=0.05: _rnd(shape, torch.float32, sc, next(seeds)).cuda()   # noqa: E731
+    P = [mk((3 * D, D)), mk((3 * D,)), mk((D, D)), mk((D,)), mk((3 * D, D)), mk((3 * D,)), mk((D, D)), mk((D,)),
+         mk((Hd, D)), mk((Hd,)), mk((D, Hd)), mk((D,))]
+    for _ in range(3):
+        P += [mk((D,), 1.0), mk((D,))]
+    if fused:
+        P += [mk((2 * D, D)), mk((2 * D,)), mk((D, D)), mk((D,)), mk((D, D)), mk((D,)), mk((D,), 1.0), mk((D,)), mk((1,), 1.0)]
+    x32 = _rnd((B * S, D), torch.float32, 1.0, 2).cuda()
+    x = x32.bfloat16()
+    y = _rnd((B * L, D), torch.bfloat16, 1.0, 1).cuda() if fused else None
+    m = torch.ones(B, L, device='cuda')
+    m[0, -3:] = 0
+    mask = ((1 - m) * torch.finfo(torch.float32).min).contiguous()
+    bf = torch.bfloat16
+
+    def ref(base):
+        ln = lambda t, i: F.layer_norm(t, (D,), P[i], P[i + 1], 1e-5).to(bf)      # noqa: E731
+        yt = ops.linear(ops.divided_attention(ops.linear(ln(base, 12), P[0], P[1]), B, Fr, N, H, 'time'), P[2], P[3])
+        s_ctx = ops.divided_attention(ops.linear(ln(base + yt.float(), 14), P[4], P[5]), B, Fr, N, H, 'space')
+        s = ops.linear(s_ctx, P[6], P[7])
+        sr = base + s.float()
+        if fused:
+            kv = ops.linear(y, P[18], P[19])
+            hs = ops.layernorm(s, P[24], P[25], 1e-5)
+            o = ops.plain_attention(ops.linear(hs, P[20], P[21]), kv[:, :D], kv[:, D:], B, H, S, L, 0.125, mask=mask)
+            sr = sr + P[26] * ops.linear(o, P[22], P[23]).float()
+        return sr + ops.mlp(ln(sr, 16), P[8], P[9], P[10], P[11]).float()
+
+    def blk(t):
+        return ops.video_block(t, P, B, Fr, N, H, Hd, 1e-5, y=y, y_mask=mask if fused else None, L=L)
+
+    with torch.no_grad():
+        out = blk(x)                                               # head of the stream: the bf16 tensor is exact
+        o32 = ops.stream32(out)
+        assert o32 is not None and o32.dtype == torch.float32
+        assert torch.equal(out, o32.to(bf))
+        r1 = ref(x.float())
+        assert _rel(o32, r1.double().cpu()) < 6e-3                 # (bf16 roundings of the LayerNorm outputs differ between torch and the kernel)
+        out2 = blk(out)                                            # continues from the fp32 value, not from its rounding
+        assert _rel(ops.stream32(out2), ref(o32).double().cpu()) < 6e-3
+        if not fused:
+            # a stack of blocks (the same weights again and again): distance from fp32 arithmetic, fp32 stream vs bf16 stream
+            Pf = [p.clone() for p in P]
+            xf = x.float()
+            a = x
+            monkeypatch.setenv('EGV_VIDEO_RES32', '0')
+            b = x
+            for _ in range(6):
+                b = blk(b)
+            monkeypatch.setenv('EGV_VIDEO_RES32', '1')
+            for _ in range(6):
+                xf = ops.video_block(xf, Pf, B, Fr, N, H, Hd, 1e-5)
+                a = blk(a)
+            e32, e16 = _rel(ops.stream32(a), xf.double().cpu()), _rel(b, xf.double().cpu())
+            assert e32 < e16, (e32, e16)
 
 
 @pytest.mark.parametrize('M', [25096, 4096 + 8, 1100])
