@@ -52,7 +52,6 @@ const Switch g_switches[] = {
     {"EGV_WGRAD_CUS", 0, "CU grant of the grouped weight-gradient launch (0: 2/3 CU per output tile)"},
     {"EGV_WGRAD_DEFER_MAXTILES", 192, "largest group whose launch is left running beside the next block call"},
     {"EGV_WGRAD_MAIN_LIMIT", 0, "CU limit of the calling stream's grids beside a grouped launch (0: the CUs the grant leaves)"},
-    {"EGV_EXP_LN_STATS_ONLY", 0, "timing experiment: LayerNorm forward of the video tokens computes its statistics only (wrong results)"},
     {"EGV_TEXT_WGRAD_GROUP", 1, "weight gradients over the text rows of a RoBERTa layer as one grouped launch"},
     {"EGV_MX_EPI_QUANT", 1, "MX-fp8 path: GELU / GELU' epilogues also emit the quantised form of their output"},
     {"EGV_LN_MX", 1, "MX-fp8 path: LayerNorm forward also writes the quantised form of its output"},

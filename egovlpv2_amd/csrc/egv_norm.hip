@@ -53,7 +53,6 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
         stats[2 * (size_t)row] = mean;
         stats[2 * (size_t)row + 1] = rstd;
     }
-    if (!y) return;                                               // statistics only (EGV_EXP_LN_STATS_ONLY, a timing experiment)
     T* yr = y + (size_t)row * D;
 #pragma unroll
     for (int j = 0; j < LN_MAXV; ++j) {
@@ -632,10 +631,6 @@ extern "C" int egv_layernorm_fwd(int dtype, const void* x, void* y, const float*
     LnProf prof(stream, 30, 2.0 * M * D * (dtype == EGV_BF16 ? 2 : 4));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((M + 3) / 4);
-    // timing experiment ("LayerNorm inside the GEMM"): the LayerNorms of the video tokens only compute their
-    // statistics -- what a GEMM with a normalising prologue would still need as a separate pass; y keeps whatever it held
-    static const bool stats_only = egv_cfg_on("EGV_EXP_LN_STATS_ONLY", false);
-    if (stats_only && M >= 4096 && stats) y = nullptr;
     if (dtype == EGV_BF16)
         hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, gamma, beta, stats, M, D, eps);
     else
