@@ -221,11 +221,15 @@ def main():
     for i in range(a.warmup):
         ld = step()                                 # a failure of the default gradient-sync path fails the benchmark on every rank
     sync()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]     # one event per step on the calling stream (no sync): the spread
+    marks[0].record()                                                              # of the K step times, reported beside their mean
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for i in range(a.steps):
         ld = step()
+        marks[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
     # Per-kernel durations for the roofline object: the same K steps twice more with one HIP event pair around every GEMM,
     # attention and LayerNorm launch, on the stream the kernel is launched on -- once exactly as timed above (text-side and
     # weight-gradient kernels share the CUs with the kernel being timed: "in_step", what rocprofv3 sees in the step) and once
@@ -371,6 +375,7 @@ def main():
         out = {"metric": "video-text pairs/sec/node (EgoClip fwd+bwd, 16x224^2, 32 tok)", "value": round(value, 3),
                "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "step_ms_min_median_max": [round(step_ms[0], 2), round(step_ms[len(step_ms) // 2], 2), round(step_ms[-1], 2)],
                "dtype": (a.dtype + "+mxfp8(video fwd/dgrad GEMMs)") if a.fp8 else a.dtype, "data": "synthetic",
                "config": {"workload": (("configs[2] full fusion EgoNCE+MLM+ITM" if a.arch == 'base16' else "full fusion EgoNCE+MLM+ITM") if a.workload == 'full' else "configs[1] dual encoder EgoNCE")
                           + (f", ViT-B/16 TimeSformer + RoBERTa-base" if a.arch == 'base16' else ", configs[4] geometry: ViT-L/14 TimeSformer + RoBERTa-large width, bf16 weights")

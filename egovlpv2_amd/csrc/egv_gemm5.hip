@@ -20,6 +20,7 @@
 // counter; consumer: one relaxed poll loop, ONE agent acquire, plain loads); the counters are zeroed by a memset node ahead of
 // every launch.  Nothing depends on dispatch order or XCD placement.
 #include "egv_wgrad_core.h"
+#include <mutex>
 #include "../../include/egovlp_hip.h"
 #include <cstdlib>
 
@@ -139,6 +140,10 @@ __global__ __launch_bounds__(512) void gemm_wgrad_group_kernel(const WgGroup g) 
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             reinterpret_cast<int*>(smem)[1] = ok ? 1 : 0;
+            // every publisher of this tile has made both of its increments: the counters go back to zero for the next launch on
+            // this stream (they live in a per-stream pool that is zeroed once, not in front of every launch)
+            __hip_atomic_store(g.cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g.cnt + g.ntile + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         ok = reinterpret_cast<int*>(smem)[1] != 0;
@@ -270,6 +275,26 @@ static int group_plan(int M, int nprob, const egv_wgrad_problem* pr, int cus, Gr
     return 1;
 }
 
+// arrive / done counters of the reduction splits: a per-stream pool, zeroed when it is created; the last arriver of a tile puts its two
+// counters back to zero, so a launch finds them clean without a memset in front of it (two launches on one stream are ordered,
+// launches on different streams have different pools)
+static int* group_counters(hipStream_t st, size_t n_ints) {
+    struct Pool { hipStream_t st; int* p; size_t n; };
+    static Pool pools[16];
+    static int npool = 0;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    for (int i = 0; i < npool; ++i)
+        if (pools[i].st == st && pools[i].n >= n_ints) return pools[i].p;
+    if (npool == 16) return nullptr;
+    const size_t n = n_ints < 4096 ? 4096 : n_ints;
+    int* p = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, n * sizeof(int)) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    pools[npool++] = Pool{st, p, n};
+    return p;
+}
+
 extern "C" long long egv_gemm_wgrad_grouped_workspace_bytes(int M, int nprob, const egv_wgrad_problem* problems, int cus) {
     GroupPlan gp;
     if (!group_plan(M, nprob, problems, group_cus(cus), gp)) return -1;
@@ -313,15 +338,17 @@ extern "C" int egv_gemm_wgrad_grouped(int dtype, int M, int nprob, const egv_wgr
         bytes += 2.0 * ((double)M * q.N + (double)M * q.K) + 4.0 * q.N * q.K;
     }
     g.slabs = (float*)workspace;
-    g.cnt = (int*)((char*)workspace + (size_t)gp.nslab * WG_SLAB_FLOATS * 4);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    g.cnt = gp.nslab > 0 ? group_counters(st, (size_t)2 * ntile) : nullptr;
+    const bool pooled = g.cnt != nullptr;
+    if (!pooled) g.cnt = (int*)((char*)workspace + (size_t)gp.nslab * WG_SLAB_FLOATS * 4);   // (no pool: counters in the workspace, zeroed per launch)
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
         attr = true;
     }
     void* ph = egv_prof_begin(stream);
-    if (gp.nslab > 0) (void)hipMemsetAsync(g.cnt, 0, (size_t)2 * ntile * 4, st);
+    if (gp.nslab > 0 && !pooled) (void)hipMemsetAsync(g.cnt, 0, (size_t)2 * ntile * 4, st);
     int nwg = 0;
     for (int i = 0; i < gp.nphase; ++i) nwg = gp.tiles[i] * gp.splits[i] > nwg ? gp.tiles[i] * gp.splits[i] : nwg;
     egv_prof_cus_hint = nwg;

@@ -1208,6 +1208,7 @@ class VideoBlockFn(Function):
         ctx.save_for_backward(x, y, y_mask, save, *params)
         if res32:
             ctx.mark_non_differentiable(out32)
+            ctx.set_materialize_grads(False)             # (no 77 MB zero gradient for out32 in every backward call)
             return out, out32
         return out
 
@@ -1215,6 +1216,8 @@ class VideoBlockFn(Function):
     def backward(ctx, dout, *_unused):
         x, y, y_mask, save, *params = ctx.saved_tensors
         cfg = ctx.cfg[:9]
+        if dout is None:                                     # (only with set_materialize_grads(False): the output was not used)
+            dout = torch.zeros_like(x)
         fused = cfg[6] > 0
         dout = dout.contiguous()
         d = VideoBlockFn._desc(cfg, x, y, y_mask, params)
