@@ -163,6 +163,15 @@ __device__ __forceinline__ void gelu_pair_fast_f(float x, float& g, float& d) {
 
 #endif
 
+// priority of a wave inside its MFMA segment (ping-pong GEMM kernels).  -DPP_SETPRIO_OFF: experiment hook
+#ifdef PP_SETPRIO_OFF
+#define PP_SETPRIO(X) do { } while (0)
+#elif defined(PP_SETPRIO_HI)
+#define PP_SETPRIO(X) __builtin_amdgcn_s_setprio((X) ? 3 : 0)
+#else
+#define PP_SETPRIO(X) __builtin_amdgcn_s_setprio(X)
+#endif
+
 // bijective XCD-aware remap of a linear workgroup id (cdna_hip_programming.md §5 template):
 // consecutive logical tiles land on the same XCD (= same L2) instead of round-robin over the 8 XCDs.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

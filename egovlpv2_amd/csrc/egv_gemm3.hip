@@ -129,6 +129,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
     const int wave = wave_id();
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, fg = lane >> 4;
+#ifdef PP_SETPRIO_STATIC                                            // experiment: the later-dispatched half of the workgroup at priority 1 throughout, no per-segment flips
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     const int KT = MX ? g.K >> 7 : g.K >> 6;
     const GemmEpi& e = g.e;
 
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
         (T) * 2 + (JP), sc_b, (I), (S) == 0 ? sc_a0 : sc_a1)
 #define PP_MFMA(S, BF, T, ZERO)                                                                                            \
     do {                                                                                                                   \
-        __builtin_amdgcn_s_setprio(1);                                                                                     \
+        PP_SETPRIO(1);                                                                                                     \
         if constexpr (MX) {                                                                                                \
             /* pinned inside the phase: every MFMA reads sc_b (defined here, after the barrier) and its result is consumed */ \
             /* by an empty volatile statement before the closing barrier -- hipcc otherwise sinks all 32 to the loop's end */ \
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
             acc[(S) * IM + i][(T) * 2 + jp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                     \
                 BF[jp][kh], af[i][kh], ((ZERO) && kh == 0) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[(S) * IM + i][(T) * 2 + jp], 0, 0, 0); \
         }                                                                                                                  \
-        __builtin_amdgcn_s_setprio(0);                                                                                     \
+        PP_SETPRIO(0);                                                                                                     \
     } while (0)
 #if EGV_PP_EXP == 2
 #define PP_EXP_TRICKLE(KIND, H)                                                                                            \

@@ -107,13 +107,13 @@ __device__ __forceinline__ void w4_mainloop(const void* A, const void* B, int ld
 
 #define W4_MFMA(S, BF, T, ZERO)                                                                                            \
     do {                                                                                                                   \
-        __builtin_amdgcn_s_setprio(1);                                                                                     \
+        PP_SETPRIO(1);                                                                                                     \
         _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                                   \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                      \
         _Pragma("unroll") for (int jp = 0; jp < 2; ++jp)                                                                   \
             acc[(S) * 4 + i][(T) * 2 + jp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                      \
                 BF[jp][kh], af[i][kh], (ZERO) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[(S) * 4 + i][(T) * 2 + jp], 0, 0, 0);    \
-        __builtin_amdgcn_s_setprio(0);                                                                                     \
+        PP_SETPRIO(0);                                                                                                     \
     } while (0)
 #define W4_COLSUM(S)                                                                                                       \
     do {                                                                                                                   \

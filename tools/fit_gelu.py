@@ -1,3 +1,8 @@
+"""Fit of the bf16-mode GELU (egv_common.h: phi_fast_f): Phi(x) ~ 1 / (1 + exp(-x P(|x|))) with P a polynomial in |x| -- the logit of the
+normal distribution function is x times a smooth even function (x^2 / 2 growth in the tails, hence the |x| terms).  Iteratively
+re-weighted least squares towards the minimax RELATIVE error of x Phi(x) over |x| <= 6 (floor 2e-3 on the magnitude), degrees 3-6.
+The kernel uses degree 5 with -log2(e) folded into the coefficients (max relative error 4.0e-5, absolute 6.6e-6).
+usage: python tools/fit_gelu.py"""
 import numpy as np
 from scipy.special import ndtr, log_ndtr
 from scipy.optimize import least_squares
