@@ -40,19 +40,16 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const GemmArgs g) {
     const int KT = (kend - kbeg + 63) >> 6;
 
     f32x4_t acc[8][4];
-    float bsum[8];                                                 // column sums of dY (bias gradient): rows wr*128 + s*64 + i*16 + fr of the tile
-    const bool want_colsum = (g.colsum != nullptr) && (n0 == 0) && (wc == 0);
-    w4_mainloop(g.A, g.B, g.lda, g.ldb, g.K, m0, n0, kbeg, KT, want_colsum, smem, acc, bsum);
+    f32x4_t bacc[2];                                               // column sums of dY (bias gradient): rows w4_row(wr, wc, s, 0) + fr of the tile
+    const bool want_colsum = (g.colsum != nullptr) && (n0 == 0);
+    w4_mainloop(g.A, g.B, g.lda, g.ldb, g.K, m0, n0, kbeg, KT, want_colsum, smem, acc, bacc);
 
-    // ---- bias gradient partials: [split][N] (rows of dW); lanes of the four token groups hold partial sums of the same row
-    if (want_colsum) {
+    // ---- bias gradient partials: [split][N] (rows of dW); every register and token group of a lane holds the same sum
+    if (want_colsum && fg == 0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float v = bsum[i];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            const int row = m0 + wr * 128 + (i >> 2) * 64 + (i & 3) * 16 + fr;
-            if (fg == 0 && row < g.M) g.colsum[(size_t)split * g.M + row] = v;
+        for (int sb = 0; sb < 2; ++sb) {
+            const int row = m0 + w4_row(wr, wc, sb, 0) + fr;
+            if (row < g.M) g.colsum[(size_t)split * g.M + row] = bacc[sb][0];
         }
     }
     // ---- epilogue: fp32 slab [N, K] of this split; lane (fr, fg) of fragment (s, i, t, j'): row .. + fr, 4 consecutive columns
@@ -62,12 +59,12 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const GemmArgs g) {
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = m0 + wr * 128 + s * 64 + i * 16 + fr;
+            const int row = m0 + w4_row(wr, wc, s, i) + fr;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int jp = 0; jp < 2; ++jp) {
-                    const int col = n0 + wc * 64 + t * 32 + jp * 16 + fg * 4;
+                    const int col = n0 + w4_col(wc, t, jp) + fg * 4;
                     f32x4_t v = acc[s * 4 + i][t * 2 + jp];
                     v[0] *= sc; v[1] *= sc; v[2] *= sc; v[3] *= sc;
                     if (row < g.M && col < g.N) *reinterpret_cast<f32x4_t*>(C + (size_t)row * g.ldc + col) = v;

@@ -85,19 +85,9 @@ __global__ __launch_bounds__(512) void gemm_wgrad_group_kernel(const WgGroup g) 
     const int KT = (kend - kbeg + 63) >> 6;
 
     f32x4_t acc[8][4];
-    float bsum[8];
+    f32x4_t bacc[2];                                               // bias gradient: column sums of dY, rows w4_row(wr, wc, s, 0) + fr of the tile
     const bool has_db = (P.db != nullptr) && (n0 == 0);
-    const bool want_colsum = has_db && (wc == 0);
-    w4_mainloop(P.A, P.B, P.lda, P.ldb, g.M, m0, n0, kbeg, KT, want_colsum, smem, acc, bsum);
-    if (want_colsum) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float v = bsum[i];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            bsum[i] = v;                                           // row wr*128 + (i>>2)*64 + (i&3)*16 + fr of the tile (all fg alike)
-        }
-    }
+    w4_mainloop(P.A, P.B, P.lda, P.ldb, g.M, m0, n0, kbeg, KT, has_db, smem, acc, bacc);
 
     // ---- who sums this tile?
     int my_rank = 0;
@@ -118,11 +108,11 @@ __global__ __launch_bounds__(512) void gemm_wgrad_group_kernel(const WgGroup g) 
 #pragma unroll
             for (int b = 0; b < 4; ++b)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[a][b]), rs, (unsigned int)(((a * 4 + b) * 512 + tid) * 16), 0, 16);   // aux 16 = sc1
-        if (want_colsum && fg == 0) {
+        if (has_db && fg == 0) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(bsum[i]), rs,
-                                                      (unsigned int)((256 * 256 + wr * 128 + (i >> 2) * 64 + (i & 3) * 16 + fr) * 4), 0, 16);
+            for (int sb = 0; sb < 2; ++sb)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(bacc[sb][0]), rs,
+                                                      (unsigned int)((256 * 256 + w4_row(wr, wc, sb, 0) + fr) * 4), 0, 16);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains its write-through stores
         __syncthreads();
@@ -154,7 +144,7 @@ __global__ __launch_bounds__(512) void gemm_wgrad_group_kernel(const WgGroup g) 
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = m0 + wr * 128 + s * 64 + i * 16 + fr;
+            const int row = m0 + w4_row(wr, wc, s, i) + fr;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -171,15 +161,15 @@ __global__ __launch_bounds__(512) void gemm_wgrad_group_kernel(const WgGroup g) 
                         v = sum;
                     }
                     v[0] = v[0] * sc + poison; v[1] = v[1] * sc + poison; v[2] = v[2] * sc + poison; v[3] = v[3] * sc + poison;
-                    const int col = n0 + wc * 64 + t * 32 + jp * 16 + fg * 4;
+                    const int col = n0 + w4_col(wc, t, jp) + fg * 4;
                     *reinterpret_cast<f32x4_t*>(P.C + (size_t)row * P.ldc + col) = v;
                 }
         }
-    if (want_colsum && fg == 0) {
+    if (has_db && fg == 0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int rl = wr * 128 + (i >> 2) * 64 + (i & 3) * 16 + fr;
-            float v = bsum[i];
+        for (int sb = 0; sb < 2; ++sb) {
+            const int rl = w4_row(wr, wc, sb, 0) + fr;
+            float v = bacc[sb][0];
             if (nsplit > 1) {
                 float sum = split == 0 ? v : tile_slabs[256 * 256 + rl];
                 for (int z = 1; z < nsplit; ++z) sum += z == split ? v : tile_slabs[(size_t)z * WG_SLAB_FLOATS + 256 * 256 + rl];

@@ -29,6 +29,18 @@ constexpr int W4_LDS = 2 * W4_BUF + 8192;      // + 1 KiB per wave: target of th
 
 __device__ __forceinline__ int w4_swz(int k) { return 2 * ((k & 3) + 4 * ((k >> 3) & 1)); }
 
+// Which 128 columns of the 256-column tile side make up a staged unit.  W4_CONTIG (default): sub-tile s of wave row wr is tile rows
+// s*128 + wr*64 .. +63 and sub-tile t of wave column wc is tile columns t*128 + wc*32 .. +31, so a unit is 128 CONSECUTIVE columns
+// of the operand: every DMA lane group of 16 fetches one contiguous 256-byte token row (two whole cache lines).  W4_CONTIG=0 is
+// the round-3 map (a wave's 128 x 64 tile contiguous: units gather 128-byte pieces of dY and 64-byte pieces of X, so every cache
+// line of X is requested by two DMA instructions of different phases).
+#ifndef W4_CONTIG
+#define W4_CONTIG 1
+#endif
+// (wave column wc keeps row block i ^ wc in its fragment slot i, so that slot 0 is the block whose bias gradient it owns)
+__device__ __forceinline__ int w4_row(int wr, int wc, int s, int i) { return (W4_CONTIG ? s * 128 + wr * 64 : wr * 128 + s * 64) + (i ^ wc) * 16; }
+__device__ __forceinline__ int w4_col(int wc, int t, int jp) { return W4_CONTIG ? t * 128 + wc * 32 + jp * 16 : wc * 64 + t * 32 + jp * 16; }
+
 // fragment: tokens fg*8 .. fg*8+7 (of a 32-token half) of unit column idx0 + fr; unit image = [token][128 columns], 256-byte rows
 __device__ __forceinline__ bf16x8_t w4_frag(const unsigned char* s, int idx0, int fr, int fg) {
     const int c16 = (idx0 >> 3) + ((fr >> 1) & 1);
@@ -43,11 +55,14 @@ __device__ __forceinline__ bf16x8_t w4_frag(const unsigned char* s, int idx0, in
 
 // A = dY [Ktot tokens, lda], B = X [Ktot tokens, ldb]; the workgroup's tile is dY columns m0.., X columns n0..; tokens
 // kbeg .. kbeg + 64*KT (those >= Ktot read as zero).  On return acc holds the tile (fragment (s*4+i, t*2+jp) of lane (fr, fg):
-// row m0 + wr*128 + s*64 + i*16 + fr, columns n0 + wc*64 + t*32 + jp*16 + fg*4 .. +3) and, with want_colsum, bsum[s*4+i] this lane's
-// partial column sum of dY for that row (to be summed over the four fg groups); every DMA has landed and all waves are past
-// the last barrier of the loop (LDS may be reused after one more barrier).
+// row m0 + w4_row(wr, wc, s, i) + fr, columns n0 + w4_col(wc, t, jp) + fg*4 .. +3) and, with want_colsum (workgroup-uniform), every
+// register of bacc[s] the column sum of dY (bias gradient) of row m0 + w4_row(wr, wc, s, 0) + fr: wave column wc owns the row
+// block of its fragment slot 0.  The sums are formed on the matrix pipe -- one MFMA per K-half with an all-ones first operand, 4 of them per
+// K-tile and wave on top of the 64 -- because the vector-ALU form of round 3 (192 shift / mask / packed-add instructions per K-tile
+// in the waves of column 0 only) made those waves, and through the barriers every tile that has a bias gradient, late.
+// Every DMA has landed and all waves are past the last barrier of the loop (LDS may be reused after one more barrier).
 __device__ __forceinline__ void w4_mainloop(const void* A, const void* B, int lda, int ldb, int Ktot, int m0, int n0, int kbeg, int KT,
-                                            bool want_colsum, unsigned char* smem, f32x4_t (&acc)[8][4], float (&bsum)[8]) {
+                                            bool want_colsum, unsigned char* smem, f32x4_t (&acc)[8][4], f32x4_t (&bacc)[2]) {
     const int lane = threadIdx.x & 63;
     const int wave = wave_id();
     const int wr = wave >> 2, wc = wave & 3;
@@ -64,8 +79,8 @@ __device__ __forceinline__ void w4_mainloop(const void* A, const void* B, int ld
         const int tok = (p * 8 + wave) * 4 + (lane >> 4);
         const int c = (lane & 15) ^ w4_swz(tok & 31);
         const int u = c * 8;                                       // unit column of this lane's chunk
-        const int colA0 = (u >> 6) * 128 + (u & 63), colA1 = colA0 + 64;                // A units: both wave rows' sub-tile
-        const int colB0 = (u >> 5) * 64 + (u & 31), colB1 = colB0 + 32;                 // B units: every wave column's half
+        const int colA0 = W4_CONTIG ? u : (u >> 6) * 128 + (u & 63), colA1 = colA0 + (W4_CONTIG ? 128 : 64);   // A units: both wave rows' sub-tile
+        const int colB0 = W4_CONTIG ? u : (u >> 5) * 64 + (u & 31), colB1 = colB0 + (W4_CONTIG ? 128 : 32);    // B units: every wave column's half
         soff[0][p] = (unsigned int)((kbeg + tok) * lda + m0 + colA0) * 2u;
         soff[3][p] = (unsigned int)((kbeg + tok) * lda + m0 + colA1) * 2u;
         soff[1][p] = (unsigned int)((kbeg + tok) * ldb + n0 + colB0) * 2u;
@@ -94,8 +109,8 @@ __device__ __forceinline__ void w4_mainloop(const void* A, const void* B, int ld
     };
 
     bf16x8_t af[4][2], bf0[2][2], bf1[2][2];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
+    bacc[0] = bacc[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, u32x4_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
 
     // prologue: U0..U3 of K-tile 0, U0 U1 of K-tile 1
     stage_unit(0); stage_unit(1); stage_unit(2); stage_unit(3);
@@ -105,28 +120,31 @@ __device__ __forceinline__ void w4_mainloop(const void* A, const void* B, int ld
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();                    // the second wave row runs one barrier behind the first
 
-#define W4_MFMA(S, BF, T, ZERO)                                                                                            \
+#define W4_BS(S, KH)                                                                                                       \
+    do {                                                                                                                   \
+        if (want_colsum) bacc[S] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[0][KH], bacc[S], 0, 0, 0);             \
+    } while (0)
+// CS: this phase's A fragments are new (phases 0 and 2): their column sums go first (K-half 0) and last (K-half 1) in the segment
+#define W4_MFMA(S, BF, T, ZERO, CS)                                                                                        \
     do {                                                                                                                   \
         PP_SETPRIO(1);                                                                                                     \
+        if (CS) W4_BS(S, 0);                                                                                               \
+        if (W4_EXP != 3)                                                                                                   \
         _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                                   \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                      \
         _Pragma("unroll") for (int jp = 0; jp < 2; ++jp)                                                                   \
             acc[(S) * 4 + i][(T) * 2 + jp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                      \
                 BF[jp][kh], af[i][kh], (ZERO) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[(S) * 4 + i][(T) * 2 + jp], 0, 0, 0);    \
+        if (CS) W4_BS(S, 1);                                                                                               \
         PP_SETPRIO(0);                                                                                                     \
     } while (0)
-#define W4_COLSUM(S)                                                                                                       \
-    do {                                                                                                                   \
-        if (want_colsum) {                                                                                                 \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                  \
-            _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) {                                                             \
-                const u32x4_t u = __builtin_bit_cast(u32x4_t, af[i][kh]);                                                  \
-                _Pragma("unroll") for (int d = 0; d < 4; ++d)                                                              \
-                    bsum[(S) * 4 + i] += __uint_as_float(u[d] << 16) + __uint_as_float(u[d] & 0xffff0000u);               \
-            }                                                                                                              \
-        }                                                                                                                  \
-    } while (0)
 
+    // W4_EXP (timing ablations, results wrong): 1 = fragments read in the first K-tile only, 2 = no DMA inside the loop, 3 = no MFMAs
+#ifndef W4_EXP
+#define W4_EXP 0
+#endif
+#define W4_RD(first) (W4_EXP != 1 || (first))
+#define W4_STAGE(u) do { if (W4_EXP != 2) stage_unit(u); } while (0)
     for (int kt = 0; kt < KT; ++kt) {
         const unsigned char* buf = smem + (kt & 1) * W4_BUF;
         const bool first = kt == 0;
@@ -134,64 +152,68 @@ __device__ __forceinline__ void w4_mainloop(const void* A, const void* B, int ld
         {
             const unsigned char* pa = buf + 0 * W4_UNIT;
             const unsigned char* pb = buf + 1 * W4_UNIT;
+            if (W4_RD(first))
 #pragma unroll
             for (int jp = 0; jp < 2; ++jp) {
                 bf0[jp][0] = w4_frag(pb, wc * 32 + jp * 16, fr, fg);
                 bf0[jp][1] = w4_frag(pb + 8192, wc * 32 + jp * 16, fr, fg);
             }
+            if (W4_RD(first))
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                af[i][0] = w4_frag(pa, wr * 64 + i * 16, fr, fg);
-                af[i][1] = w4_frag(pa + 8192, wr * 64 + i * 16, fr, fg);
+                af[i][0] = w4_frag(pa, wr * 64 + (i ^ wc) * 16, fr, fg);
+                af[i][1] = w4_frag(pa + 8192, wr * 64 + (i ^ wc) * 16, fr, fg);
             }
-            stage_unit(2);
+            W4_STAGE(2);
             w4_wait_vmcnt<8>();
             __builtin_amdgcn_s_barrier();
-            if (first) W4_MFMA(0, bf0, 0, kh == 0); else W4_MFMA(0, bf0, 0, false);
-            W4_COLSUM(0);
+            if (first) W4_MFMA(0, bf0, 0, kh == 0, true); else W4_MFMA(0, bf0, 0, false, true);
             __builtin_amdgcn_s_barrier();
         }
         // ---- phase 1: B sub 1 (U2); stage U3 of kt+1; quadrant (0,1)
         {
             const unsigned char* pb = buf + 2 * W4_UNIT;
+            if (W4_RD(first))
 #pragma unroll
             for (int jp = 0; jp < 2; ++jp) {
                 bf1[jp][0] = w4_frag(pb, wc * 32 + jp * 16, fr, fg);
                 bf1[jp][1] = w4_frag(pb + 8192, wc * 32 + jp * 16, fr, fg);
             }
-            stage_unit(3);
+            W4_STAGE(3);
             ++s_kt;
             w4_wait_vmcnt<8>();
             __builtin_amdgcn_s_barrier();
-            if (first) W4_MFMA(0, bf1, 1, kh == 0); else W4_MFMA(0, bf1, 1, false);
+            if (first) W4_MFMA(0, bf1, 1, kh == 0, false); else W4_MFMA(0, bf1, 1, false, false);
             __builtin_amdgcn_s_barrier();
         }
         // ---- phase 2: A sub 1 (U3); stage U0 of kt+2; quadrant (1,1)
         {
             const unsigned char* pa = buf + 3 * W4_UNIT;
+            if (W4_RD(first))
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                af[i][0] = w4_frag(pa, wr * 64 + i * 16, fr, fg);
-                af[i][1] = w4_frag(pa + 8192, wr * 64 + i * 16, fr, fg);
+                af[i][0] = w4_frag(pa, wr * 64 + (i ^ wc) * 16, fr, fg);
+                af[i][1] = w4_frag(pa + 8192, wr * 64 + (i ^ wc) * 16, fr, fg);
             }
-            stage_unit(0);
+            W4_STAGE(0);
             w4_wait_vmcnt<8>();
             __builtin_amdgcn_s_barrier();
-            if (first) W4_MFMA(1, bf1, 1, kh == 0); else W4_MFMA(1, bf1, 1, false);
-            W4_COLSUM(1);
+            if (first) W4_MFMA(1, bf1, 1, kh == 0, true); else W4_MFMA(1, bf1, 1, false, true);
             __builtin_amdgcn_s_barrier();
         }
         // ---- phase 3: no reads; stage U1 of kt+2; quadrant (1,0)
         {
-            stage_unit(1);
+            W4_STAGE(1);
             w4_wait_vmcnt<8>();
             __builtin_amdgcn_s_barrier();
-            if (first) W4_MFMA(1, bf0, 0, kh == 0); else W4_MFMA(1, bf0, 0, false);
+            if (first) W4_MFMA(1, bf0, 0, kh == 0, false); else W4_MFMA(1, bf0, 0, false, false);
             __builtin_amdgcn_s_barrier();
         }
     }
 #undef W4_MFMA
-#undef W4_COLSUM
+#undef W4_RD
+#undef W4_STAGE
+#undef W4_BS
     if (wr == 0) __builtin_amdgcn_s_barrier();
     w4_wait_vmcnt<0>();                                            // the dummy DMAs
 }
