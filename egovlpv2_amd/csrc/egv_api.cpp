@@ -41,6 +41,7 @@ const Switch g_switches[] = {
     {"EGV_PP_STAMPS", 0, "instrumentation build only: per-K-tile cycle stamps of the persistent GEMM"},
     {"EGV_PP_CUS", 0, "cap of the persistent GEMM's grid (0: all CUs)"},
     {"EGV_PP_LIMIT_SLACK", 16, "CUs a persistent grid may take beyond its CU limit when that removes a round of its tile walk"},
+    {"EGV_PP_LIMIT_SLACK_FUSED", 0, "the same inside a fused video block's backward call (its weight-gradient launch stays resident: exact limit)"},
     {"EGV_PP_BM192", 1, "192-row tiles where they shorten the walk"},
     {"EGV_PP_192_PENALTY", 1.06, "cost factor of a 192-row tile relative to 3/4 of a 256-row tile"},
     {"EGV_PP_TRIM", 1, "grid trimmed to the smallest size that keeps the round count"},
@@ -50,6 +51,8 @@ const Switch g_switches[] = {
     {"EGV_GELU_DERIV", 0, "video MLP saves gelu'(x) instead of x in the bf16 mode (EGV_ACT_GELU_D; measured slower, off)"},
     {"EGV_WGRAD_GROUP", 1, "all weight gradients of a video block call as one persistent grouped launch"},
     {"EGV_WGRAD_CUS", 0, "CU grant of the grouped weight-gradient launch (0: 2/3 CU per output tile)"},
+    {"EGV_WGRAD_CUS_FUSED", 0, "CU grant of a fused block's grouped launch (0: as EGV_WGRAD_CUS / 2/3 CU per output tile)"},
+    {"EGV_FUSED_LIMIT_LIFT", 1, "fused block backward: the GEMMs after the image-to-text part plan for the whole chip"},
     {"EGV_WGRAD_DEFER_MAXTILES", 192, "largest group whose launch is left running beside the next block call"},
     {"EGV_WGRAD_MAIN_LIMIT", 0, "CU limit of the calling stream's grids beside a grouped launch (0: the CUs the grant leaves)"},
     {"EGV_TEXT_WGRAD_GROUP", 1, "weight gradients over the text rows of a RoBERTa layer as one grouped launch"},

@@ -20,6 +20,7 @@ void egv_set_error(const char* fmt, ...);
 int egv_cfg_int(const char* name, int def);          // run-time switches: the one table in egv_api.cpp
 bool egv_cfg_on(const char* name, bool def);
 void egv_gemm_set_cu_limit(int n);                  // egv_gemm3.hip: CUs the persistent forward / dgrad grids of this thread plan for
+void egv_gemm_set_cu_slack(int n);                  // ... and how many CUs beyond that plan a grid may take to save a round (-1: EGV_PP_LIMIT_SLACK)
 extern "C" int egv_layernorm_bwd2(int dtype, const void* dy, const void* x, const float* stats, const float* gamma,
                                   const void* add, const void* add2, void* dx, float* dgamma, float* dbeta, int M, int D,
                                   void* workspace, void* stream);
@@ -356,10 +357,17 @@ int device_cus() {
 // EGV_WGRAD_CUS overrides.
 int vgroup_cus(const egv_vblock_desc* d) {
     static const int forced = egv_cfg_int("EGV_WGRAD_CUS", 0);
+    static const int forced_fused = egv_cfg_int("EGV_WGRAD_CUS_FUSED", 0);
+    if (d->L > 0 && forced_fused > 0) return forced_fused;
     if (forced > 0) return forced;
     const int tD = d->D / 256, tH = d->Hd / 256;
-    const int ntile = 2 * tD * tH + 2 * tD * tD + 2 * 3 * tD * tD + (d->L > 0 ? 2 * tD * tD : 0);
-    int g = (2 * ntile + 2) / 3;
+    // A fused block gets the grant of the unfused form (96 CUs at ViT-B for 162 instead of 144 tiles): its data-gradient chain is a
+    // third longer, so the launch has the time, and the 8 CUs this leaves beside the chain's 152-workgroup grids are what the text
+    // layer's backward kernels (a dozen workgroups each, on the text stream) run on -- with 104 or 108 every CU is owned by a
+    // persistent workgroup and the text layer, whose gradient the NEXT video block call waits for, only gets CUs between launches
+    // (alternating A/B: 73.3 -> 72.2 ms per step).
+    const int ntile = 2 * tD * tH + 2 * tD * tD + 2 * 3 * tD * tD;
+    int g = ((2 * ntile + 2) / 3 / 8) * 8;                         // a multiple of 8: so is what it leaves the XCD-aware grids of the calling stream
     const int cap = device_cus() / 2;
     return g > cap ? cap : g;
 }
@@ -373,10 +381,10 @@ bool vdefer_ok(const egv_vblock_desc* d) {
     const int ntile = 2 * tD * tH + 2 * tD * tD + 2 * 3 * tD * tD + (d->L > 0 ? 2 * tD * tD : 0);
     return vfp8_on(d) || ntile <= max_tiles;
 }
-struct CuLimit {                                    // scoped egv_gemm_set_cu_limit
+struct CuLimit {                                    // scoped egv_gemm_set_cu_limit / egv_gemm_set_cu_slack
     bool on;
-    explicit CuLimit(int n) : on(n > 0) { if (on) egv_gemm_set_cu_limit(n); }
-    ~CuLimit() { if (on) egv_gemm_set_cu_limit(0); }
+    explicit CuLimit(int n, int slack = -1) : on(n > 0) { if (on) { egv_gemm_set_cu_limit(n); egv_gemm_set_cu_slack(slack); } }
+    ~CuLimit() { if (on) { egv_gemm_set_cu_limit(0); egv_gemm_set_cu_slack(-1); } }
 };
 long long vgroup_ws_bytes(const egv_vblock_desc* d) {
     if (!vgroup_ok(d)) return 0;
@@ -618,7 +626,10 @@ extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
     const bool side_group = vgroup_ok(d) && vdefer_ok(d) && fk.forked() && (d->flags & EGV_BLOCK_NO_JOIN);
     const bool group = vgroup_ok(d) && (side_group || !fk.forked());
     static const int main_limit = egv_cfg_int("EGV_WGRAD_MAIN_LIMIT", 0);
-    CuLimit cu_limit(side_group ? (main_limit > 0 ? main_limit : device_cus() - vgroup_cus(d)) : 0);
+    // fused blocks: the group's launch starts with this call (the calling stream first waits for the text layer's gradient) and
+    // is resident through the MLP's data gradients -- their grids take exactly the CUs it leaves (EGV_PP_LIMIT_SLACK_FUSED)
+    static const int slack_fused = egv_cfg_int("EGV_PP_LIMIT_SLACK_FUSED", 0);
+    CuLimit cu_limit(side_group ? (main_limit > 0 ? main_limit : device_cus() - vgroup_cus(d)) : 0, fused ? slack_fused : -1);
     egv_wgrad_problem grp[8];
     int ngrp = 0;
     auto wgrad = [&](int N, int K, const void* dz, const void* x, int w, const float* gate, int rows) -> int {
@@ -663,6 +674,10 @@ extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
         if (d->dy) BCHK(lin_dgrad(dt, BL, 2 * D, D, dkv, d->w[VW_KV_I2T], d->wt[VW_KV_I2T], d->dy, nullptr, nullptr, 0, st));
         d_sproj_out = d_s;
     }
+    // fused blocks: by now (MLP and image-to-text part done) the grouped launch of the previous call has finished or is in its last
+    // phase: the remaining GEMMs of the chain plan for the whole chip (EGV_FUSED_LIMIT_LIFT; alternating A/B 72.2 -> 71.9 ms per step)
+    static const bool lift = egv_cfg_on("EGV_FUSED_LIMIT_LIFT", true);
+    if (fused && lift && cu_limit.on) egv_gemm_set_cu_limit(0);
     // ---- spatial attention
     BCHK(wgrad(D, D, d_sproj_out, sv + L.sctx, VW_SPROJ, nullptr, M));
     BCHK(dgrad(VW_SPROJ, D, D, d_sproj_out, d_sctx, nullptr, 0));

@@ -139,8 +139,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
     // hold 32 CONSECUTIVE tiles of every round (m-major): they share A panels through that XCD's L2.
     const int G = gridDim.x;
     const int wg = blockIdx.x;
-    const int per_xcd = G >> 3;                                   // G % 8 == 0 (launcher)
-    const int first = (wg & 7) * per_xcd + (wg >> 3);
+    // (any G: XCD x = wg % 8 holds G / 8 workgroups, one more for x < G % 8 -- a grid beside a resident weight-gradient launch
+    // takes exactly the CUs that launch leaves)
+    const int first = (wg & 7) * (G >> 3) + min(wg & 7, G & 7) + (wg >> 3);
     const int my_tiles = first < ntiles ? (ntiles - 1 - first) / G + 1 : 0;
     if (my_tiles == 0) return;
 
@@ -693,6 +694,8 @@ using namespace egv;
 // backward call whose weight gradients run as a persistent launch on a granted share of the chip (egv_gemm5.hip): a grid
 // planned for CUs it cannot get would run its surplus workgroups as a second, nearly empty round.
 static thread_local int g_cu_limit = 0;
+static thread_local int g_cu_slack = -1;            // -1: EGV_PP_LIMIT_SLACK
+void egv_gemm_set_cu_slack(int n) { g_cu_slack = n; }
 extern thread_local int egv_prof_cus_hint;     // egv_api.cpp: the grid of a persistent launch, for the per-launch profile records
 void egv_gemm_set_cu_limit(int n) { g_cu_limit = n; }
 
@@ -740,10 +743,15 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
     // taken when that removes a whole round of the walk (1176 tiles of the fc1 / fc2 class: 8 rounds on 160 CUs, 7 on 168) -- a few
     // workgroups then start late, behind the weight-gradient workgroups that hold their CUs, instead of every workgroup walking one
     // tile more (measured on configs[2]: limit 160 -> 168, 78.1 -> 76.7 ms per step)
-    static const int slack = egv_cfg_int("EGV_PP_LIMIT_SLACK", 16);
+    // -- which only pays when the companion launch ends early in the walk: a late workgroup walks ALL of its tiles after the others.
+    // Where the companion is known to stay (fused blocks: its launch starts with the call and outlasts the first GEMMs) the
+    // caller sets the slack to 0 (egv_gemm_set_cu_slack) and the limit is exact: a grid of 147 or 148 workgroups beside a
+    // 108-workgroup launch instead of 152 of which four start after everything else has finished (fc2 data gradient 480 -> 240 us).
+    static const int slack_env = egv_cfg_int("EGV_PP_LIMIT_SLACK", 16);
+    const int slack = g_cu_slack >= 0 ? g_cu_slack : slack_env;
     int ncu_soft = 0;
     if (g_cu_limit > 0 && g_cu_limit < ncu_all) {
-        ncu = g_cu_limit >= 8 ? (g_cu_limit / 8) * 8 : 8;
+        ncu = slack > 0 ? (g_cu_limit >= 8 ? (g_cu_limit / 8) * 8 : 8) : (g_cu_limit >= 8 ? g_cu_limit : 8);
         ncu_soft = ncu + slack < ncu_all ? ncu + slack : ncu_all;
     }
     // tile height: 192-row tiles where they shorten the walk (rounds x tile work, + 6 % for the smaller tile's lower operand

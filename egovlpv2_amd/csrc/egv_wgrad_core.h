@@ -34,6 +34,10 @@ __device__ __forceinline__ int w4_swz(int k) { return 2 * ((k & 3) + 4 * ((k >> 
 // of the operand: every DMA lane group of 16 fetches one contiguous 256-byte token row (two whole cache lines).  W4_CONTIG=0 is
 // the round-3 map (a wave's 128 x 64 tile contiguous: units gather 128-byte pieces of dY and 64-byte pieces of X, so every cache
 // line of X is requested by two DMA instructions of different phases).
+// cache policy of the operand DMAs (build-time experiment hook: " nt", " sc1", " sc0 sc1" ...)
+#ifndef W4_LD_AUX
+#define W4_LD_AUX ""
+#endif
 #ifndef W4_CONTIG
 #define W4_CONTIG 1
 #endif
@@ -91,7 +95,7 @@ __device__ __forceinline__ void w4_mainloop(const void* A, const void* B, int ld
     int s_kt = 0;                                                  // K-tile of the unit to be issued next
     auto dma = [&](__amdgpu_buffer_rsrc_t rs, unsigned int voff, unsigned int lds_dst) {
         unsigned int keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen" W4_LD_AUX " lds\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep)
                      : "v"(voff), "s"(rs), "s"(lds_dst)
                      : "memory");
