@@ -148,6 +148,8 @@ PROTOTYPES = {
     'egv_ce_bwd': (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, vp]),
     'egv_l2norm_fwd': (i32, [vp, vp, vp, i32, i32, f32, vp]),
     'egv_l2norm_bwd': (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),
+    'egv_sim_small_fwd': (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    'egv_sim_small_bwd': (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     'egv_egonce_fwd': (i32, [vp, vp, vp, i32, f32, i32, i32, vp, vp, vp, vp]),
     'egv_egonce_bwd': (i32, [vp, vp, vp, vp, vp, vp, i32, f32, i32, i32, vp]),
     'egv_adamw_step': (i32, [vp, vp, i32, i32, f32, f32, f32, f32, f32, f32, f32, vp]),

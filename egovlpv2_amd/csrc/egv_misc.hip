@@ -326,6 +326,36 @@ __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict
     if (threadIdx.x == 0) nrm[r] = nr;
 }
 
+// sim[i, j] = <a[i, :], b[j, :]> for the small similarity matrices of the EgoNCE branch (n x m <= a few thousand entries over d =
+// 118 ... 4096 features): ONE WAVE PER ENTRY.  As a GEMM this is a single 128 x 128 output tile whose K loop one workgroup walks alone
+// -- 530 us for the 8 x 8 x 4096 text-video matrix, three such products per EgoNCE tail -- here every entry is a strided dot product
+// with a wave reduction (fixed order: deterministic).
+__global__ __launch_bounds__(256) void sim_small_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ sim,
+                                                            int n, int m, int d) {
+    const int e = blockIdx.x * 4 + wave_id();
+    if (e >= n * m) return;
+    const int i = e / m, j = e % m, lane = threadIdx.x & 63;
+    const float* pa = a + (long long)i * d;
+    const float* pb = b + (long long)j * d;
+    float s0 = 0.f, s1 = 0.f;
+    int c = lane;
+    for (; c + 64 < d; c += 128) { s0 += pa[c] * pb[c]; s1 += pa[c + 64] * pb[c + 64]; }
+    if (c < d) s0 += pa[c] * pb[c];
+    const float s = wave_sum(s0 + s1);
+    if (lane == 0) sim[e] = s;
+}
+// out[i, c] = sum_j g(i, j) * other[j, c],  g(i, j) = ds[i * ld + j] (trans = 0: gradient of the row operand) or ds[j * ld + i]
+// (trans = 1: gradient of the column operand); rows values of i, cols values of j (<= a few dozen)
+__global__ __launch_bounds__(256) void sim_small_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ other, float* __restrict__ out,
+                                                            int rows, int cols, int d, int ld, int trans) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)rows * d) return;
+    const int i = (int)(t / d), c = (int)(t % d);
+    float s = 0.f;
+    for (int j = 0; j < cols; ++j) s += (trans ? ds[(long long)j * ld + i] : ds[(long long)i * ld + j]) * other[(long long)j * d + c];
+    out[t] = s;
+}
+
 // dx = (dy - y * <y, dy>) / ||x||   if ||x|| > eps,  else dy / eps
 __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                          const float* __restrict__ nrm, float* __restrict__ dx, int n, int d, float eps) {
@@ -622,6 +652,22 @@ extern "C" int egv_l2norm_fwd(const float* x, float* y, float* nrm, int n, int d
 
 extern "C" int egv_l2norm_bwd(const float* dy, const float* y, const float* nrm, float* dx, int n, int d, float eps, void* stream) {
     hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(n), dim3(256), 0, EGV_ST, dy, y, nrm, dx, n, d, eps);
+    EGV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int egv_sim_small_fwd(const float* a, const float* b, float* sim, int n, int m, int d, void* stream) {
+    EGV_CHECK(n > 0 && m > 0 && d > 0 && (long long)n * m <= (1 << 20), "egv_sim_small_fwd: 1 <= n * m <= 2^20 entries");
+    hipLaunchKernelGGL(sim_small_fwd_kernel, dim3((n * m + 3) / 4), dim3(256), 0, EGV_ST, a, b, sim, n, m, d);
+    EGV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int egv_sim_small_bwd(const float* ds, const float* other, float* out, int rows, int cols, int d, int trans, void* stream) {
+    EGV_CHECK(rows > 0 && cols > 0 && d > 0, "egv_sim_small_bwd: bad shape");
+    const long long tot = (long long)rows * d;
+    hipLaunchKernelGGL(sim_small_bwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, EGV_ST, ds, other, out, rows, cols, d,
+                       trans ? rows : cols, trans);
     EGV_LAUNCH_CHECK();
     return 0;
 }

@@ -1527,6 +1527,9 @@ def cross_entropy_sum(logits, labels, V, ignore_index=-100):
     return CrossEntropySumFn.apply(logits, labels, V, ignore_index)
 
 
+_SIM_SMALL = 4096          # entries (64 x 64: the EgoNCE matrices of 8 ranks x 8 pairs) up to which sim_matrix takes the one-wave-per-entry kernels
+
+
 class SimMatrixFn(Function):
     """sim_matrix (model.py:576-584) in fp32: a/max(|a|,eps) @ (b/max(|b|,eps))^T."""
 
@@ -1543,7 +1546,10 @@ class SimMatrixFn(Function):
         check(lib.egv_l2norm_fwd(_p(a), _p(an), _p(na), n, d, eps, _st()), 'egv_l2norm_fwd')
         check(lib.egv_l2norm_fwd(_p(b), _p(bn), _p(nb), m, d, eps, _st()), 'egv_l2norm_fwd')
         sim = torch.empty(n, m, dtype=torch.float32, device=a.device)
-        gemm(an, bn, sim, M=n, N=m, K=d, lda=d, ldb=d, ldc=m)
+        if n * m <= _SIM_SMALL:          # the EgoNCE branch's matrices: one wave per entry instead of one workgroup walking K alone
+            check(lib.egv_sim_small_fwd(_p(an), _p(bn), _p(sim), n, m, d, _st()), 'egv_sim_small_fwd')
+        else:
+            gemm(an, bn, sim, M=n, N=m, K=d, lda=d, ldb=d, ldc=m)
         ctx.eps = eps
         ctx.save_for_backward(an, bn, na, nb)
         return sim
@@ -1557,12 +1563,18 @@ class SimMatrixFn(Function):
         da = db = None
         if ctx.needs_input_grad[0]:
             dan = torch.empty_like(an)
-            gemm(ds, bn, dan, a_trans=0, b_trans=1, M=n, N=d, K=m, lda=m, ldb=d, ldc=d)
+            if n * m <= _SIM_SMALL:
+                check(lib.egv_sim_small_bwd(_p(ds), _p(bn), _p(dan), n, m, d, 0, _st()), 'egv_sim_small_bwd')
+            else:
+                gemm(ds, bn, dan, a_trans=0, b_trans=1, M=n, N=d, K=m, lda=m, ldb=d, ldc=d)
             da = torch.empty_like(an)
             check(lib.egv_l2norm_bwd(_p(dan), _p(an), _p(na), _p(da), n, d, ctx.eps, _st()), 'egv_l2norm_bwd')
         if ctx.needs_input_grad[1]:
             dbn = torch.empty_like(bn)
-            gemm(ds, an, dbn, a_trans=1, b_trans=1, M=m, N=d, K=n, lda=m, ldb=d, ldc=d)
+            if n * m <= _SIM_SMALL:
+                check(lib.egv_sim_small_bwd(_p(ds), _p(an), _p(dbn), m, n, d, 1, _st()), 'egv_sim_small_bwd')
+            else:
+                gemm(ds, an, dbn, a_trans=1, b_trans=1, M=m, N=d, K=n, lda=m, ldb=d, ldc=d)
             db = torch.empty_like(bn)
             check(lib.egv_l2norm_bwd(_p(dbn), _p(bn), _p(nb), _p(db), m, d, ctx.eps, _st()), 'egv_l2norm_bwd')
         return da, db, None

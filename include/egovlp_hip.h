@@ -224,6 +224,10 @@ int egv_ce_bwd(int dtype, const void* logits, const long long* labels, const flo
 /* ---- sim_matrix + EgoNCE (model.py:576-584; loss.py:40-61), fp32 ---- */
 int egv_l2norm_fwd(const float* x, float* y, float* nrm, int n, int d, float eps, void* stream);
 int egv_l2norm_bwd(const float* dy, const float* y, const float* nrm, float* dx, int n, int d, float eps, void* stream);
+/* the matrix product of sim_matrix (model.py:582-583) for the small matrices of the EgoNCE branch (n x m entries, one wave each):
+   sim[n,m] = a[n,d] b[m,d]^T;  backward out[rows,d] = g other[cols,d] with g = ds[rows,cols] (trans = 0) or ds[cols,rows]^T (trans = 1) */
+int egv_sim_small_fwd(const float* a, const float* b, float* sim, int n, int m, int d, void* stream);
+int egv_sim_small_bwd(const float* ds, const float* other, float* out, int rows, int cols, int d, int trans, void* stream);
 int egv_egonce_fwd(const float* x, const float* sim_v, const float* sim_n, int n, float temperature, int noun, int verb,
                    float* stats /* [2n][4] */, float* loss, unsigned char* mask_bool /* [n][n] or NULL */, void* stream);
 int egv_egonce_bwd(const float* x, const float* sim_v, const float* sim_n, const float* stats, const float* gout, float* dx,

@@ -446,6 +446,23 @@ def test_sim_matrix_and_egonce(ops):
     assert _rel(b.grad, b64.grad) < 2e-4
 
 
+@pytest.mark.parametrize('n,m,d', [(5, 9, 100), (8, 8, 4096), (64, 64, 256), (70, 70, 256)])
+def test_sim_matrix_rectangular_and_both_paths(ops, n, m, d):
+    """sim_matrix (model.py:576-584) forward and both gradients for rectangular and ragged shapes: the one-wave-per-entry kernels
+    (up to 64 x 64 entries: the EgoNCE matrices) and the GEMM path above that, against fp64"""
+    a = _rnd((n, d), torch.float32, 1.0, 11).cuda().requires_grad_(True)
+    b = _rnd((m, d), torch.float32, 1.0, 12).cuda().requires_grad_(True)
+    w = _rnd((n, m), torch.float32, 1.0, 13)
+    sim = ops.sim_matrix_f32(a, b)
+    (sim * w.cuda()).sum().backward()
+    a64, b64 = a.detach().double().cpu().requires_grad_(True), b.detach().double().cpu().requires_grad_(True)
+    s64 = (a64 / a64.norm(dim=1, keepdim=True)) @ (b64 / b64.norm(dim=1, keepdim=True)).t()
+    (s64 * w.double()).sum().backward()
+    assert _rel(sim, s64) < 2e-5
+    assert _rel(a.grad, a64.grad) < 2e-4
+    assert _rel(b.grad, b64.grad) < 2e-4
+
+
 def test_cpu_tensor_is_refused(ops):
     with pytest.raises(RuntimeError):
         ops.linear(torch.randn(4, 8), torch.randn(8, 8))
