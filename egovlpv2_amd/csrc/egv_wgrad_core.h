@@ -10,8 +10,9 @@
 // 128 x 64 wave tiles, 4 phases per K-tile of {tr-read one sub-tile ; stage one 16 KB unit ; counted vmcnt ; barrier ; 16 MFMAs ;
 // barrier}, the two wave rows one barrier apart, units staged 5 phases ahead of their read.
 //
-// Units of a K-tile (64 tokens x 128 columns = 16 KB each): U0 = dY columns read in phase 0 (sub-tile 0 of both wave rows),
-// U1 = X columns of phase 0 (first 32 of every wave column), U2 = X columns of phase 1, U3 = dY columns of phase 2.
+// Units of a K-tile (64 tokens x 128 columns = 16 KB each): U0 = dY columns read in phase 0 (sub-tile 0 of both wave rows: tile rows
+// 0..127), U1 = X columns of phase 0 (sub-tile 0 of every wave column: tile columns 0..127), U2 = X columns of phase 1 (128..255),
+// U3 = dY columns of phase 2 (128..255).
 #pragma once
 #include "egv_gemm.h"
 
@@ -34,12 +35,12 @@ __device__ __forceinline__ int w4_swz(int k) { return 2 * ((k & 3) + 4 * ((k >> 
 // of the operand: every DMA lane group of 16 fetches one contiguous 256-byte token row (two whole cache lines).  W4_CONTIG=0 is
 // the round-3 map (a wave's 128 x 64 tile contiguous: units gather 128-byte pieces of dY and 64-byte pieces of X, so every cache
 // line of X is requested by two DMA instructions of different phases).
-// cache policy of the operand DMAs (build-time experiment hook: " nt", " sc1", " sc0 sc1" ...)
-#ifndef W4_LD_AUX
-#define W4_LD_AUX ""
-#endif
 #ifndef W4_CONTIG
 #define W4_CONTIG 1
+#endif
+// cache policy of the operand DMAs (build-time experiment hook: " nt", " sc1" ...; both measured slower than the default in the step)
+#ifndef W4_LD_AUX
+#define W4_LD_AUX ""
 #endif
 // (wave column wc keeps row block i ^ wc in its fragment slot i, so that slot 0 is the block whose bias gradient it owns)
 __device__ __forceinline__ int w4_row(int wr, int wc, int s, int i) { return (W4_CONTIG ? s * 128 + wr * 64 : wr * 128 + s * 64) + (i ^ wc) * 16; }
