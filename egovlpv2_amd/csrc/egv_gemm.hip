@@ -281,6 +281,58 @@ static inline int vec_ok(const void* p, int ld, int dtype) {
 }
 
 // See include/egovlp_hip.h for the contract.
+// ------------------------------------------------------------------------------------------------
+// Skinny bf16 Linear, M <= 16 rows (the projection heads over B pooled rows: [8, 4096] x [4096, 4096]^T, model.py:105-115): as a tiled GEMM
+// this is N / 128 workgroups that each walk K alone (86 us for a 33.5 MB weight); here one wave owns FOUR output columns, streams their
+// weight rows once (16 bytes per lane and row, 512 k per step) against the <= 16 activation rows (cache-resident) and reduces across
+// the lanes at the end: N / 16 workgroups, bound by one pass over the weight.  A row's sum does not depend on the other rows
+// (batch-independent bit for bit, like the tiled kernels).  y = act(x W^T + b), act in {none, relu, tanh}.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dot8_bf16(const u32x4_t& a, const u32x4_t& b, float acc) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        acc = fmaf(__uint_as_float(a[k] << 16), __uint_as_float(b[k] << 16), acc);
+        acc = fmaf(__uint_as_float(a[k] & 0xffff0000u), __uint_as_float(b[k] & 0xffff0000u), acc);
+    }
+    return acc;
+}
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
+                                                          bf16_t* __restrict__ C, int ldc, const float* __restrict__ bias, int act,
+                                                          int M, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n0 = (blockIdx.x * 4 + wave_id()) * 4;
+    if (n0 >= N) return;
+    float acc[16][4];
+#pragma unroll
+    for (int m = 0; m < 16; ++m)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[m][c] = 0.f;
+    for (int k0 = lane * 8; k0 < K; k0 += 512) {
+        u32x4_t w[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            w[c] = n0 + c < N ? *reinterpret_cast<const u32x4_t*>(B + (long long)(n0 + c) * ldb + k0) : u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            if (m < M) {
+                const u32x4_t x = *reinterpret_cast<const u32x4_t*>(A + (long long)m * lda + k0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[m][c] = dot8_bf16(x, w[c], acc[m][c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        if (m < M) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float v = wave_sum(acc[m][c]);
+                if (lane == 0 && n0 + c < N) C[(long long)m * ldc + n0 + c].v = f2bf(apply_act(v + (bias ? bias[n0 + c] : 0.f), act));
+            }
+        }
+    }
+}
+
 extern "C" int egv_gemm(int dtype, int a_trans, int b_trans, int M, int N, int K,
                         const void* A, int lda, const void* B, int ldb, void* C, int ldc, int out_f32,
                         const float* bias, int act, const float* gate, const void* res1, const void* res2,
@@ -307,6 +359,14 @@ extern "C" int egv_gemm(int dtype, int a_trans, int b_trans, int M, int N, int K
     // algorithmic bytes: operands + output once, plus every epilogue operand that is read or written
     const double abytes = es_ * ((double)M * K + (double)N * K + (double)M * N * (1 + (res1 != nullptr) + (res2 != nullptr) + (pre != nullptr) + (aux != nullptr)));
     void* ph = egv_prof_begin(stream);
+    if (dtype == EGV_BF16 && !a_trans && !b_trans && !out_f32 && M <= 16 && N >= 512 && K >= 512 && (K % 8) == 0 && g.a_vec_ok && g.b_vec_ok &&
+        !gate && !res1 && !res2 && !pre && !aux && !dact && scale == 1.0f && (act == 0 || act == 2 || act == 3)) {
+        hipLaunchKernelGGL(gemm_skinny_kernel, dim3((N + 15) / 16), dim3(256), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc,
+                           bias, act, M, N, K);
+        egv_prof_end(ph, stream, 2.0 * M * N * K, 6, abytes);        // 6 = skinny (<= 16 rows)
+        EGV_LAUNCH_CHECK();
+        return 0;
+    }
     const int took = dtype == EGV_BF16 ? egv_gemm2_launch(g, a_trans, b_trans, out_f32, 1, st) : 0;
     if (took) {
         egv_prof_end(ph, stream, 2.0 * M * N * K, took == 2 ? 12 : (took == 3 ? 13 : 8), abytes);   // 8 ring 256x128, 12 persistent ping-pong, 13 ring 128x128

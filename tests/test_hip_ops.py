@@ -64,6 +64,31 @@ def test_linear_forms(ops, dtype, shape):
     assert _rel(r.grad, r64.grad) < 1e-6
 
 
+@pytest.mark.parametrize('M,N,K,act,bias', [(8, 4096, 4096, 'relu', True), (8, 4096, 768, 'relu', False), (1, 4096, 4096, 'none', True),
+                                            (16, 1000, 1024, 'tanh', True), (13, 520, 2304, 'none', False)])
+def test_skinny_linear_bf16(ops, M, N, K, act, bias):
+    """Linear over <= 16 rows (the projection heads, model.py:105-115: gemm_skinny_kernel, one wave per four output columns):
+    forward and gradients against fp64 on the bf16 operands; a row's result does not depend on the other rows of the call (bitwise)"""
+    dtype = torch.bfloat16
+    x = _rnd((M, K), dtype, 1.0, 1).cuda().requires_grad_(True)
+    w = _rnd((N, K), torch.float32, 0.05, 2).cuda().requires_grad_(True)
+    b = _rnd((N,), torch.float32, 0.5, 3).cuda().requires_grad_(True) if bias else None
+    y = ops.linear(x, w, b, act=act)
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    w64 = w.detach().to(dtype).double().cpu().requires_grad_(True)
+    z = x64 @ w64.t() + (b.detach().double().cpu() if bias else 0.0)
+    y64 = {'relu': torch.relu, 'tanh': torch.tanh, 'none': (lambda t: t)}[act](z)
+    assert _rel(y, y64) < _tol(dtype)
+    dy = _rnd((M, N), dtype, 1.0, 5)
+    y.backward(dy.cuda())
+    y64.backward(dy.double())
+    assert _rel(x.grad, x64.grad) < _tol(dtype, True) * 1.5
+    assert _rel(w.grad, w64.grad) < _tol(dtype, True) * 1.5
+    with torch.no_grad():
+        one = ops.linear(x[M - 1:M].detach(), w.detach(), b.detach() if bias else None, act=act)
+    assert torch.equal(one[0], y[M - 1].detach())
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('act', ['relu', 'tanh', 'gelu'])
 def test_linear_act(ops, dtype, act):
