@@ -1,7 +1,7 @@
 """Two ranks of the HIP path on ONE GPU (gloo rendezvous, both processes on cuda:0): the world_size-2 semantics of
 FrozenInTime.forward -- global EgoNCE matrix, scalar-gathered MLM/ITM losses, hard negatives owned by the other rank
 (pixels gathered, shared video prefix for own clips) -- against the CPU oracle run under the same process group, and
-DDP(static_graph) gradient averaging over several steps, with and without the second (text) stream.  fp32 storage; tolerances 1e-3 on losses, 5e-3 on gradients."""
+DDP(static_graph) and flat-buffer gradient averaging over several steps, on the two-stream schedule (`overlap=False` stays available to the worker).  fp32 storage; tolerances 1e-3 on losses, 5e-3 on gradients."""
 import os
 import sys
 
