@@ -101,6 +101,7 @@ PROTOTYPES = {
     'egv_gemm_wgrad': (i32, [i32, i32, i32, i32, vp, i32, vp, i32, vp, vp, f32, vp, vp, i64, vp]),
     'egv_gemm_wgrad_grouped_workspace_bytes': (i64, [i32, i32, C.POINTER(WgradProblem), i32]),
     'egv_gemm_wgrad_grouped': (i32, [i32, i32, i32, C.POINTER(WgradProblem), i32, vp, i64, vp]),
+    'egv_gemm_wgrad_group_reset': (i32, []),
     'egv_layernorm_fwd': (i32, [i32, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     'egv_layernorm_bwd_workspace_bytes': (i64, [i32, i32]),
     'egv_layernorm_bwd': (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),

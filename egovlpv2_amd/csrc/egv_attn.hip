@@ -673,6 +673,9 @@ extern "C" long long egv_attn_split_workspace_bytes(int which, int B, int G, int
 extern "C" long long egv_attn_fwd_extra_workspace_bytes(int B, int G, int H) { return (long long)B * G * H * 66 * 4; }
 extern "C" int egv_attn_fwd_covers_extra(int dtype, const egv_attn_desc* d) {
     if (dtype != EGV_BF16 || !d || !d->ws) return 0;
+    // a workspace too small for the partial states covers nothing: egv_attn_fwd then computes the group rows only and the caller
+    // must issue the one-query launch itself (the extra row of O and lse would otherwise stay unwritten)
+    if (d->ws_bytes < egv_attn_fwd_extra_workspace_bytes(d->B, d->G, d->H)) return 0;
     AttnArgs a = to_args(d);
     return (egv_attn_fwd_cls_ok(a) || egv_attn_time_fwd_ok(a, d->B) || egv_attn_space_fwd_ok(a, d->B)) ? 1 : 0;
 }

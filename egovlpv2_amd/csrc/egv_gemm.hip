@@ -363,7 +363,7 @@ extern "C" int egv_gemm(int dtype, int a_trans, int b_trans, int M, int N, int K
         !gate && !res1 && !res2 && !pre && !aux && !dact && scale == 1.0f && (act == 0 || act == 2 || act == 3)) {
         hipLaunchKernelGGL(gemm_skinny_kernel, dim3((N + 15) / 16), dim3(256), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc,
                            bias, act, M, N, K);
-        egv_prof_end(ph, stream, 2.0 * M * N * K, 6, abytes);        // 6 = skinny (<= 16 rows)
+        egv_prof_end(ph, stream, 2.0 * M * N * K, 7, abytes);        // 7 = skinny (<= 16 rows)
         EGV_LAUNCH_CHECK();
         return 0;
     }

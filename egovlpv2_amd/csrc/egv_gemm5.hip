@@ -18,7 +18,7 @@
 // partials IN SPLIT ORDER (its own at its split's position: the sum does not depend on who arrives last) and writes dW / db.
 // Hand-off per cdna_hip_programming.md Guideline 16 (R1: sc1 payload, every storing wave drains, one lane bumps an agent-scope
 // counter; consumer: one relaxed poll loop, ONE agent acquire, plain loads); the counters are zeroed by a memset node ahead of
-// every launch.  Nothing depends on dispatch order or XCD placement.
+// every launch (or, pooled per (device, stream), put back by the last arriver of a tile).  Nothing depends on dispatch order or XCD placement.
 #include "egv_wgrad_core.h"
 #include <mutex>
 #include "../../include/egovlp_hip.h"
@@ -51,6 +51,7 @@ struct WgGroup {
     int nprob, nphase, ntile, M;
     float* slabs;
     int* cnt;               // [2][ntile]: arrive, done
+    int* err;               // sticky error word of the counter pool (null: counters zeroed per launch)
 };
 
 __global__ __launch_bounds__(512) void gemm_wgrad_group_kernel(const WgGroup g) {
@@ -129,11 +130,19 @@ __global__ __launch_bounds__(512) void gemm_wgrad_group_kernel(const WgGroup g) 
                 if (++spins > (1u << 26)) { ok = false; break; }   // never seen; a lost publisher must not hang the device
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (ok) {
+                // every publisher of this tile has made both of its increments: the counters go back to zero for the next launch on
+                // this stream (they live in a per-(device, stream) pool that is zeroed once, not in front of every launch)
+                __hip_atomic_store(g.cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(g.cnt + g.ntile + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (g.err) {
+                // a publisher never showed up: its increments may still come, so the counters are NOT put back (a later launch could
+                // otherwise read a complete count and sum unpublished slabs in silence) -- the pool is marked broken instead: every
+                // launch that uses it from now on poisons what it writes, until the host re-creates the pool (egv_gemm_wgrad_group_reset)
+                __hip_atomic_store(g.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (g.err && __hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ok = false;
             reinterpret_cast<int*>(smem)[1] = ok ? 1 : 0;
-            // every publisher of this tile has made both of its increments: the counters go back to zero for the next launch on
-            // this stream (they live in a per-stream pool that is zeroed once, not in front of every launch)
-            __hip_atomic_store(g.cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(g.cnt + g.ntile + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         ok = reinterpret_cast<int*>(smem)[1] != 0;
@@ -268,21 +277,39 @@ static int group_plan(int M, int nprob, const egv_wgrad_problem* pr, int cus, Gr
 // arrive / done counters of the reduction splits: a per-stream pool, zeroed when it is created; the last arriver of a tile puts its two
 // counters back to zero, so a launch finds them clean without a memset in front of it (two launches on one stream are ordered,
 // launches on different streams have different pools)
-static int* group_counters(hipStream_t st, size_t n_ints) {
-    struct Pool { hipStream_t st; int* p; size_t n; };
-    static Pool pools[16];
-    static int npool = 0;
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lk(mu);
-    for (int i = 0; i < npool; ++i)
-        if (pools[i].st == st && pools[i].n >= n_ints) return pools[i].p;
-    if (npool == 16) return nullptr;
-    const size_t n = n_ints < 4096 ? 4096 : n_ints;
+// The pool's last word is its sticky error flag (set by a launch whose spin timed out: the counters are then left as they are and every
+// later launch on the pool poisons its output); egv_gemm_wgrad_group_reset zeroes the pools of the calling device.
+namespace {
+struct WgPool { int dev; hipStream_t st; int* p; size_t n; };
+WgPool g_pools[32];
+int g_npool = 0;
+std::mutex g_pool_mu;
+}
+static int* group_counters(hipStream_t st, size_t n_ints, int** err) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (int i = 0; i < g_npool; ++i)
+        if (g_pools[i].dev == dev && g_pools[i].st == st && g_pools[i].n >= n_ints + 1) { *err = g_pools[i].p + g_pools[i].n - 1; return g_pools[i].p; }
+    if (g_npool == 32) return nullptr;
+    const size_t n = n_ints + 1 < 4096 ? 4096 : n_ints + 1;
     int* p = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(int)) != hipSuccess) return nullptr;
     if (hipMemset(p, 0, n * sizeof(int)) != hipSuccess) { (void)hipFree(p); return nullptr; }
-    pools[npool++] = Pool{st, p, n};
+    g_pools[g_npool++] = WgPool{dev, st, p, n};
+    *err = p + n - 1;
     return p;
+}
+
+// Zero the split-reduction counter pools (and their sticky error words) of the calling device, stream-ordered on each pool's stream.
+// For a host that has seen NaN weight gradients after a device fault and wants to go on without restarting the process.
+extern "C" int egv_gemm_wgrad_group_reset(void) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (int i = 0; i < g_npool; ++i)
+        if (g_pools[i].dev == dev) EGV_CHECK(hipMemsetAsync(g_pools[i].p, 0, g_pools[i].n * sizeof(int), g_pools[i].st) == hipSuccess, "egv_gemm_wgrad_group_reset: memset failed");
+    return 0;
 }
 
 extern "C" long long egv_gemm_wgrad_grouped_workspace_bytes(int M, int nprob, const egv_wgrad_problem* problems, int cus) {
@@ -329,7 +356,8 @@ extern "C" int egv_gemm_wgrad_grouped(int dtype, int M, int nprob, const egv_wgr
     }
     g.slabs = (float*)workspace;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    g.cnt = gp.nslab > 0 ? group_counters(st, (size_t)2 * ntile) : nullptr;
+    g.err = nullptr;
+    g.cnt = gp.nslab > 0 ? group_counters(st, (size_t)2 * ntile, &g.err) : nullptr;
     const bool pooled = g.cnt != nullptr;
     if (!pooled) g.cnt = (int*)((char*)workspace + (size_t)gp.nslab * WG_SLAB_FLOATS * 4);   // (no pool: counters in the workspace, zeroed per launch)
     static bool attr = false;

@@ -99,8 +99,9 @@ class ExchangeClipsFn(torch.autograd.Function):
             ids = [j - rank * bsz for j in table[q] if j // bsz == rank]
             send_plan[q] = ids
             if ids:
-                idx = torch.tensor([i * rows + t for i in ids for t in range(rows)], dtype=torch.int64, device=x.device)
-                buf = x.detach().index_select(0, idx)
+                # whole clips leave as (rows, d) blocks: one gather over the clip axis (ids: a handful of ints), no per-row index list
+                sel = torch.tensor(ids, dtype=torch.int64, device=x.device)
+                buf = x.detach().reshape(bsz, rows, d).index_select(0, sel).view(len(ids) * rows, d)
                 buf = buf.cpu() if host else buf.contiguous()
                 keep.append(buf)
                 ops_.append(dist.P2POp(dist.isend, buf, q))
@@ -133,10 +134,10 @@ class ExchangeClipsFn(torch.autograd.Function):
                 ops_.append(dist.P2POp(dist.irecv, b, q))
         _p2p(ops_)
         gx = torch.zeros(ctx.xshape, dtype=ctx.xdtype, device=ctx.xdev)
-        for ids, b in bufs:                                           # fixed order (rank order, then request order): deterministic
-            b = b.to(ctx.xdev)
-            for n, i in enumerate(ids):
-                gx[i * rows:(i + 1) * rows] += b[n * rows:(n + 1) * rows]
+        gv = gx.view(bsz, rows, d)
+        for ids, b in bufs:                                           # fixed order (rank order; the ids of one requester are distinct): deterministic
+            sel = torch.tensor(ids, dtype=torch.int64, device=ctx.xdev)
+            gv[sel] += b.to(ctx.xdev).view(len(ids), rows, d)         # one gather-add-scatter per requester, whole clips
         return gx, None, None, None, None
 
 

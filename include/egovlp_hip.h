@@ -91,6 +91,11 @@ typedef struct egv_wgrad_problem {
 long long egv_gemm_wgrad_grouped_workspace_bytes(int M, int nprob, const egv_wgrad_problem* problems, int cus);   /* -1: group not supported */
 int egv_gemm_wgrad_grouped(int dtype, int M, int nprob, const egv_wgrad_problem* problems, int cus, void* workspace,
                            long long workspace_bytes, void* stream);
+/* The split-reduction counters of the grouped launch live in a pool per (device, stream) that is zeroed once and put back by the
+ * launches themselves.  A launch whose wait for a publisher times out (never observed; a device fault) leaves its counters alone,
+ * writes NaN and marks the pool: every later launch on that pool writes NaN too (loud, not silently wrong) until this call zeroes
+ * the calling device's pools, stream-ordered on each pool's own stream. */
+int egv_gemm_wgrad_group_reset(void);
 
 /* ---- LayerNorm (video_transformer.py:196,207,210,304,115; roberta.py:160,336,417; model.py:155;
  * BertPredictionHeadTransform.LayerNorm heads.py:41).  stats = [M][2] fp32 {mean, rstd} (may be NULL in

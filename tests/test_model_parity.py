@@ -141,6 +141,37 @@ def test_tiny_egonce_only_step_fp32():
             assert pd[k].grad is None, k
 
 
+def _egonce_only_step_vs_golden(m, g, data, noun, verb, dtype, loss_tol):
+    """BASELINE.json configs[1] (dual encoder, EgoNCE only) at this fixture's depth: the EgoNCE-only forward + backward takes a
+    different autograd graph from the three-loss step (no MLM / ITM uses of the blocks: other flat-gradient accumulation and
+    weight-gradient deferral paths); loss and every parameter-gradient norm against the reference's own (`egonce_only_*` arrays of
+    the fixture, oracle/gen_golden.py).  Parameters the loss does not reach must have NO gradient (norm -1 in the fixture)."""
+    for p in m.parameters():
+        p.grad = None
+    loss, ld, ret = _forward(m, data, noun, verb, 'EgoNCE')
+    ref = float(g['egonce_only_loss'])
+    assert abs(float(loss) - ref) <= loss_tol * abs(ref), (float(loss), ref)
+    loss.backward()
+    names = [str(x) for x in g['param_names']]
+    pd = dict(m.named_parameters())
+    rn = g['egonce_only_grad_norms']
+    bad = []
+    big = rn > 1e-2 * rn.max()
+    for i, (k, r) in enumerate(zip(names, rn)):
+        if r < 0:
+            assert pd[k].grad is None or float(pd[k].grad.abs().max()) == 0.0, k
+            continue
+        if k.endswith('.key.bias'):
+            continue                                                    # exactly-zero true gradient
+        a = pd[k].grad.norm().item()
+        if dtype == torch.float32:
+            if abs(a - r) > 1e-2 * r + 1e-7:
+                bad.append((k, a, float(r)))
+        elif big[i] and abs(a - r) > 0.15 * r:
+            bad.append((k, a, float(r)))
+    assert not bad, bad[:8]
+
+
 @pytest.mark.parametrize('dtype,tol_e,tol_l', [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 2e-2, 5e-3)])
 def test_base_f4_vs_golden(dtype, tol_e, tol_l):
     """full-depth ViT-B/16 + RoBERTa-base at 4 x 224^2 frames against the reference's own outputs.  (bf16 storage: measured
@@ -176,6 +207,7 @@ def test_base_f4_vs_golden(dtype, tol_e, tol_l):
     rel = (np.abs(gn - g['grad_norms']) / (g['grad_norms'] + 1e-5))[keep]
     kn = [k for k, kk in zip(names, keep) if kk]
     assert (rel < gtol).all(), [(kn[i], float(rel[i])) for i in np.argsort(-rel)[:8]]
+    _egonce_only_step_vs_golden(m, g, data, noun, verb, dtype, tol_loss['EgoNCE'])
 
 
 @pytest.mark.parametrize('dtype,tol_e,tol_l', [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 2e-2, 5e-3)])
@@ -215,6 +247,7 @@ def test_base_f16_vs_golden(dtype, tol_e, tol_l):
     rel = (np.abs(gn - g['grad_norms']) / (g['grad_norms'] + 1e-5))[keep]
     kn = [k for k, kk in zip(names, keep) if kk]
     assert (rel < gtol).all(), [(kn[i], float(rel[i])) for i in np.argsort(-rel)[:8]]
+    _egonce_only_step_vs_golden(m, g, data, noun, verb, dtype, tol_loss['EgoNCE'])
 
 
 @pytest.mark.parametrize('dtype,tol_e,tol_l', [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 3e-2, 2e-2)])

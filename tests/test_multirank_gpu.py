@@ -174,3 +174,72 @@ def test_bench_two_ranks_flat_grad_sync_rehearsal():
     assert abs(two['losses']['loss_mlm'] - want) <= 2e-3 * abs(want), (two['losses'], [s['losses'] for s in singles])
     for k in ('EgoNCE', 'loss_itm', 'loss_total'):
         assert np.isfinite(two['losses'][k]) and 0 < two['losses'][k] < 50, two['losses']
+
+
+def _nccl_worker(port, q):
+    """ONE rank on the real transport (RCCL: backend 'nccl', world size 1 -- two ranks cannot share a GPU on RCCL)."""
+    try:
+        sys.path.insert(0, REPO)
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(port)
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        os.environ.pop('EGV_EXCHANGE_HOST_TABLE', None)
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+        from egovlpv2_amd.trainer import exchange as X
+        from egovlpv2_amd.trainer.trainer_egoclip import AllGather_multi
+        import types
+        out = {}
+        # (a) the request table over the device all-gather vs the host all-gather, issued from an external low-priority stream
+        # between other collectives of the same communicator (as in the step: gathers before, all-reduces after)
+        side = torch.cuda.Stream(priority=0)
+        bsz = 8
+        for trial in range(4):
+            ids = [(3 * trial + 5 * i) % (2 * bsz) for i in range(bsz)]          # global ids of a 2-rank job: half of them "remote"
+            t = torch.randn(bsz, 16, device='cuda')
+            g = AllGather_multi.apply(t, 1, types.SimpleNamespace(world_size=1, rank=0))
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                get = X.start_request_gather(ids, torch.tensor(ids, dtype=torch.int64).cuda(non_blocking=True), 0, bsz, 1)
+            flat = torch.randn(1 << 20, device='cuda')
+            ref = flat.clone()
+            w = dist.all_reduce(flat, async_op=True)
+            table = get()
+            w.wait()
+            torch.cuda.synchronize()
+            assert table == X.gather_requests(ids, 0, bsz, 1), (table, ids)
+            assert table == [sorted({j for j in ids if j >= bsz})], table
+            assert torch.equal(flat, ref) and torch.equal(g, t)
+        out['table'] = 'ok'
+        q.put(('ok', out))
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put(('error', traceback.format_exc()[-3000:]))
+
+
+def test_request_gather_on_rccl_matches_host_gather():
+    """trainer/exchange.py::start_request_gather on its PRODUCTION branch (device all-gather on RCCL + pinned-memory read-back behind
+    an event), from a side stream, interleaved with other collectives of the communicator, against the host all-gather of the gloo
+    tests (round-4 advisor finding: the branch had never run)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(29700 + os.getpid() % 90, q))
+    p.start()
+    status, info = q.get(timeout=600)
+    p.join(timeout=60)
+    if p.is_alive():
+        p.kill()
+    assert status == 'ok', info
+
+
+def test_bench_one_rank_on_rccl_flat_and_ddp():
+    """bench.py --force-ddp: the data-parallel step (process group on RCCL, FlatGradSync's in-place all-reduces issued from the
+    weight-gradient stream in backward order / DDP's reducer) on the real communicator at world size 1; the losses must equal the
+    plain 1-rank run's (an all-reduce over one rank is the identity; dropout off)."""
+    common = ['--batch', '4', '--frames', '4', '--drop-rate', '0']
+    plain = _run_bench(1, common, {}, 29651)
+    for gs in ('flat', 'ddp'):
+        r = _run_bench(1, common + ['--force-ddp', '--grad-sync', gs], {}, 29652)
+        for k in ('EgoNCE', 'loss_mlm', 'loss_itm', 'loss_total'):
+            assert abs(r["losses"][k] - plain["losses"][k]) <= 2e-5, (gs, k, r['losses'], plain['losses'])
