@@ -17,7 +17,7 @@ from . import switches as _sw  # noqa: E402
 
 LIB_PATH = _sw.value('EGV_LIB_PATH') or os.path.join(_HERE, 'libegovlp_hip.so')
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 EGV_F32, EGV_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH, ACT_GELU_D = 0, 1, 2, 3, 4
 
@@ -39,6 +39,7 @@ class AttnDesc(C.Structure):
         ('mask', vp), ('mask_ld', i32),
         ('nsplit', i32), ('ws', vp), ('ws_bytes', i64),
         ('drop_p', f32), ('drop_seed', C.c_uint),
+        ('O32', vp),
     ]
 
 

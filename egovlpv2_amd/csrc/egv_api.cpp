@@ -17,7 +17,7 @@ void egv_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int egv_abi_version(void) { return 4; }
+extern "C" int egv_abi_version(void) { return 5; }
 
 // ---- switches --------------------------------------------------------------------------------------------------------------
 // Every run-time switch of the library in ONE table (name, default, what it does).  The defaults are the configuration that is
@@ -43,7 +43,9 @@ const Switch g_switches[] = {
     {"EGV_PP_LIMIT_SLACK", 16, "CUs a persistent grid may take beyond its CU limit when that removes a round of its tile walk"},
     {"EGV_PP_LIMIT_SLACK_FUSED", 0, "the same inside a fused video block's backward call (its weight-gradient launch stays resident: exact limit)"},
     {"EGV_PP_BM192", 1, "192-row tiles where they shorten the walk"},
-    {"EGV_PP_192_PENALTY", 1.06, "cost factor of a 192-row tile relative to 3/4 of a 256-row tile"},
+    {"EGV_PP_MIXED", 1, "224- / 160- / 128-row tiles (A sub-tiles of different heights) for the plain kinds where they shorten the walk: 1 = grids planned for the whole chip, 2 = also under a CU limit, 0 = off"},
+    {"EGV_PP_FORCE_BM", 0, "tests: tile height of the persistent GEMM wherever the epilogue kind is built for it (0: chosen per call)"},
+    {"EGV_PP_TILE_C0", 56, "height-independent cost of a tile of the persistent GEMM, in rows (tile cost = rows + this)"},
     {"EGV_PP_TRIM", 1, "grid trimmed to the smallest size that keeps the round count"},
     {"EGV_PP_RES_MINK", 1536, "shortest K for which a residual-epilogue GEMM takes the persistent kernel on 256-row tiles"},
     {"EGV_LN_BLOCKS", 512, "workgroup cap of the LayerNorm backward"},

@@ -28,6 +28,7 @@ struct AttnArgs {
     int G;
     int nsplit; float* ws;                      // split of the other-side loop + fp32 partial slabs
     float drop_p; unsigned int drop_seed;       // attention-probability dropout (roberta.py:313); 0 = off
+    float* O32;                                 // optional fp32 copy of O (same ld / offsets): written by the forward, read for delta
 };
 
 // counter-based dropout mask: a pure function of (seed, global query row, global key row, head), so forward, dQ and dK/dV
@@ -64,6 +65,7 @@ struct egv_attn_desc {
     const float* mask; int mask_ld;
     int nsplit; float* ws; long long ws_bytes;
     float drop_p; unsigned int drop_seed;
+    float* O32;
 };
 
 static inline egv::AttnArgs to_args(const egv_attn_desc* d) {
@@ -78,6 +80,7 @@ static inline egv::AttnArgs to_args(const egv_attn_desc* d) {
     a.scale = d->scale; a.mask = d->mask; a.mask_ld = d->mask_ld; a.G = d->G;
     a.nsplit = d->nsplit > 0 ? d->nsplit : 1; a.ws = d->ws;
     a.drop_p = d->drop_p; a.drop_seed = d->drop_seed;
+    a.O32 = d->O32;
     return a;
 }
 

@@ -165,6 +165,7 @@ __global__ void attn_fwd_combine_kernel(const AttnArgs a, int P) {
     }
     const long long row = rs_row(a.q, b, g, i);
     Elem<T>::st(reinterpret_cast<T*>(a.O) + row * a.ldo + a.ooff + h * HD + lane, o / Lsum);
+    if (a.O32) a.O32[row * a.ldo + a.ooff + h * HD + lane] = o / Lsum;
     if (a.lse && lane == 0) a.lse[row * a.H + h] = M + __logf(Lsum);
 }
 

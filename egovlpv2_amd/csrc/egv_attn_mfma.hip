@@ -309,6 +309,11 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnArgs a
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
                 st_bf16x4(O + qrow * a.ldo + ho + dt * 16 + fg * 4, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+            if (a.O32) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    *reinterpret_cast<f32x4_t*>(a.O32 + qrow * a.ldo + ho + dt * 16 + fg * 4) = f32x4_t{o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
+            }
             if (a.lse && fg == 0) a.lse[qrow * a.H + h] = m * LN2 + __logf(l);
         }
     }
@@ -366,11 +371,17 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a,
         const bf16x8_t o0 = ld_frag_global(O + qrow * a.ldo + ho + fg * 8, qv);
         const bf16x8_t o1 = ld_frag_global(O + qrow * a.ldo + ho + 32 + fg * 8, qv);
         float dl = 0.f;
+        if (a.O32) {                                                          // delta from the fp32 values of O (egv_attn_desc::O32)
+            const float* o32 = a.O32 + qrow * a.ldo + ho + fg * 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dl += (float)g0[e] * (float)o0[e] + (float)g1[e] * (float)o1[e];
+            for (int e = 0; e < 8; ++e) dl += qv ? (float)g0[e] * o32[e] + (float)g1[e] * o32[32 + e] : 0.f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl += (float)g0[e] * (float)o0[e] + (float)g1[e] * (float)o1[e];
+        }
         dl = grp_sum(dl);
         const float lse2 = qv ? a.lse[qrow * a.H + h] * LOG2E : 0.f;
-        if (qv && fg == 0 && split == 0) a.delta[qrow * a.H + h] = dl;
+        if (qv && fg == 0 && split == 0 && !(NT == 2 && a.nsplit == 1)) a.delta[qrow * a.H + h] = dl;
 
         f32x4_t o[4];
 #pragma unroll
@@ -378,6 +389,7 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a,
 #pragma unroll
         for (int kk = 0; kk < NT / 2; ++kk) {
             f32x4_t pr[2];
+            [[maybe_unused]] f32x4_t pjv[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int t = 2 * kk + u;
@@ -399,16 +411,47 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a,
                         if (DROP) {
                             if (a.drop_p > 0.f) dpv *= drop_mult(a, (long long)p * a.q.n + q, r0 + key, h);
                         }
-                        acc[r] = pj * (dpv - dl);
-                        if (t == 0 && r == 0) { p_cls = pj; ds_cls = acc[0]; }     // key 0 = the extra key (lanes fg == 0)
+                        if constexpr (NT == 2) {                              // both key tiles first: delta may come from them (below)
+                            pjv[u][r] = key < ntot ? pj : 0.f;
+                            acc[r] = dpv;
+                        } else {
+                            acc[r] = pj * (dpv - dl);
+                            if (t == 0 && r == 0) { p_cls = pj; ds_cls = acc[0]; }     // key 0 = the extra key (lanes fg == 0)
+                        }
                     }
-                    if (tile_partial<NL>(t, ntot)) {                         // uniform: the partial tile zeroes its padding keys
+                    if (NT != 2 && tile_partial<NL>(t, ntot)) {              // uniform: the partial tile zeroes its padding keys
                         asm volatile("" ::: "memory");
 #pragma unroll
                         for (int r = 0; r < 4; ++r) acc[r] = (t * 16 + fg * 4 + r < ntot) ? acc[r] : 0.f;
                     }
+                } else if constexpr (NT == 2) {
+                    pjv[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
                 }
                 pr[u] = acc;
+            }
+            if constexpr (NT == 2) {
+                // <= 32 keys: a query's whole probability row and dP row are in the registers of its four lanes, so
+                //   delta = sum_j P_j dP_j
+                // is formed from the very values dS is formed from (unsplit launches) instead of rowsum(dO o O) with the bf16-rounded O:
+                // that rounding is a COMMON offset under all keys of a row and ends up, times the mean key, in dQ -- the same effect as in
+                // the text -> image attention (egv_attn_desc::O32), measured there as 3-5 x the reference-under-autocast's q / k gradient
+                // error.  The stored delta (read by egv_attn_bwd_dkv) is this one.
+                float dd = dl;
+                if (a.nsplit == 1) {
+                    float sdl = 0.f;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sdl += pjv[u][r] * pr[u][r];
+                    dd = grp_sum(sdl);
+                    if (qv && fg == 0) a.delta[qrow * a.H + h] = dd;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pr[u][r] = pjv[u][r] * (pr[u][r] - dd);
+                p_cls = pjv[0][0];
+                ds_cls = pr[0][0];
             }
             if (pair_live<NL>(kk, ntot)) {                                     // dQ^T += K^T dS^T for this pair of key tiles
                 const bf16x8_t dsf = pack8(pr[0], pr[1]);

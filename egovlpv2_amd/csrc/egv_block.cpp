@@ -245,16 +245,19 @@ struct Plain {
         d.nsplit = 1;
         d.drop_p = drop_p; d.drop_seed = drop_seed;
     }
-    int fwd(const void* q, int ldq, const void* k, const void* v, int ldkv, void* O, float* lse, void* ws, long long wsb, void* st) const {
+    // o32 (bf16 storage, optional): fp32 values of O -- written by the forward, the source of delta in the backward (egv_attn_desc::O32)
+    int fwd(const void* q, int ldq, const void* k, const void* v, int ldkv, void* O, float* lse, void* ws, long long wsb, void* st, float* o32 = nullptr) const {
         egv_attn_desc d;
         fill(d, q, ldq, k, v, ldkv, O, lse);
         d.nsplit = fwd_ns(); d.ws = (float*)ws; d.ws_bytes = wsb;
+        d.O32 = dt == EGV_BF16 ? o32 : nullptr;
         return egv_attn_fwd(dt, &d, st);
     }
     int bwd(const void* q, int ldq, const void* k, const void* v, int ldkv, const void* O, float* lse, const void* dO, void* dq, int lddq,
-            void* dk, void* dv, int lddkv, float* delta, void* ws, long long wsb, void* st) const {
+            void* dk, void* dv, int lddkv, float* delta, void* ws, long long wsb, void* st, const float* o32 = nullptr) const {
         egv_attn_desc d;
         fill(d, q, ldq, k, v, ldkv, const_cast<void*>(O), lse);
+        d.O32 = dt == EGV_BF16 ? const_cast<float*>(o32) : nullptr;
         d.dO = dO; d.dQ = dq; d.dK = dk; d.dV = dv; d.lddq = lddq; d.lddk = d.lddv = lddkv; d.delta = delta;
         d.nsplit = fwd_ns(); d.ws = (float*)ws; d.ws_bytes = wsb;
         BCHK(egv_attn_bwd_dq(dt, &d, st));
@@ -709,7 +712,7 @@ enum { TW_Q = 0, TW_K, TW_V, TW_AO, TW_FC1, TW_FC2, TW_CQ, TW_CK, TW_CV, TW_CO }
 enum { TL_ATT = 0, TL_OUT };
 
 struct TLayout {
-    size_t q, k, v, ctx, lse, a0, a0d, cq, ck, cv, cctx, lse_c, pg, a_pre, stats0, a, pre, act, f0, f_pre, stats1, hid16, a16;
+    size_t q, k, v, ctx, lse, a0, a0d, cq, ck, cv, cctx, cctx32, lse_c, pg, a_pre, stats0, a, pre, act, f0, f_pre, stats1, hid16, a16;
     size_t total;
 };
 
@@ -738,7 +741,7 @@ TLayout tlayout(const egv_tlayer_desc* d) {
     if (fused || drop || tres32(d)) L.a0 = T(BL * D * es);
     if (fused && drop) L.a0d = T(BL * D * es);
     if (fused) {
-        L.cq = T(BL * D * es); L.ck = T(BS * 2 * D * es); L.cv = L.ck + BS * D * es; L.cctx = T(BL * D * es); L.lse_c = T(BL * H * 4);
+        L.cq = T(BL * D * es); L.ck = T(BS * 2 * D * es); L.cv = L.ck + BS * D * es; L.cctx = T(BL * D * es); L.cctx32 = T(BL * D * 4); L.lse_c = T(BL * H * 4);
         L.pg = T(BL * D * es);
     }
     L.a_pre = T(BL * D * rs); L.stats0 = T(BL * 8); L.a = T(BL * D * rs); L.pre = T(BL * Hd * es); L.act = T(BL * Hd * es);
@@ -863,7 +866,7 @@ extern "C" int egv_tlayer_fwd(const egv_tlayer_desc* d) {
             BCHK(lin_fwd(dt, BS, D, D, d->enc, d->w[TW_CK], d->b[TW_CK], ckp, 0, nullptr, nullptr, nullptr, nullptr, st));
             BCHK(lin_fwd(dt, BS, D, D, d->enc, d->w[TW_CV], d->b[TW_CV], cvp, 0, nullptr, nullptr, nullptr, nullptr, st));
         }
-        BCHK(tp.cross.fwd(sv + L.cq, D, ckp, cvp, mc ? 2 * D : D, sv + L.cctx, (float*)(sv + L.lse_c), aws, tp.awb, st));
+        BCHK(tp.cross.fwd(sv + L.cq, D, ckp, cvp, mc ? 2 * D : D, sv + L.cctx, (float*)(sv + L.lse_c), aws, tp.awb, st, (float*)(sv + L.cctx32)));
         if (!drop && !r32) {
             // alpha_t2i * dense(cctx) + a0 + hidden (roberta.py:486-488)
             BCHK(lin_fwd(dt, BL, D, D, sv + L.cctx, d->w[TW_CO], d->b[TW_CO], sv + L.a_pre, 0, d->alpha, a0x, d->hid, sv + L.pg, st));
@@ -1048,7 +1051,7 @@ extern "C" int egv_tlayer_bwd(const egv_tlayer_desc* d) {
             BCHK(wgrad(BL, D, D, dyg, sv + L.cctx, TW_CO, d->alpha));
             BCHK(lin_dgrad(dt, BL, D, D, dyg, d->w[TW_CO], d->wt[TW_CO], dcctx, d->alpha, nullptr, 0, st));
             BCHK(tp.cross.bwd(sv + L.cq, D, ckp, cvp, ldckv, sv + L.cctx, (float*)const_cast<char*>(sv + L.lse_c), dcctx, dcq, D, dck, dcv, ldckv, delta_c,
-                              aws, tp.awb, st));
+                              aws, tp.awb, st, (const float*)(sv + L.cctx32)));
             BCHK(wgrad(BL, D, D, dcq, a0x, TW_CQ, nullptr));
             BCHK(lin_dgrad(dt, BL, D, D, dcq, d->w[TW_CQ], d->wt[TW_CQ], da0d, nullptr, nullptr, 0, st));
             BCHK(ckv_grads());
@@ -1098,7 +1101,7 @@ extern "C" int egv_tlayer_bwd(const egv_tlayer_desc* d) {
         BCHK(wgrad(BL, D, D, dy_, sv + L.cctx, TW_CO, d->alpha));
         BCHK(lin_dgrad(dt, BL, D, D, dy_, d->w[TW_CO], d->wt[TW_CO], dcctx, d->alpha, nullptr, 0, st));
         BCHK(tp.cross.bwd(sv + L.cq, D, ckp, cvp, ldckv, sv + L.cctx, (float*)const_cast<char*>(sv + L.lse_c), dcctx, dcq, D, dck, dcv, ldckv, delta_c,
-                          aws, tp.awb, st));
+                          aws, tp.awb, st, (const float*)(sv + L.cctx32)));
         BCHK(wgrad(BL, D, D, dcq, a0x, TW_CQ, nullptr));
         BCHK(dgrad_res(BL, D, D, dcq, TW_CQ, da0d, da_pre, nullptr));                       // a0 also feeds the residual
         BCHK(ckv_grads());

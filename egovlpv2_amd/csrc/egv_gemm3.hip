@@ -67,27 +67,27 @@ __device__ __forceinline__ PPTile pp_tile(int t, int tiles_n, int bm) {
 // decides the count of the phase's s_waitcnt.
 enum { PP_PLAIN = 0, PP_LAST = 1, PP_FIRST_CHAIN = 2, PP_FIRST_COLD = 3, PP_SECOND_CHAIN = 4, PP_SECOND_COLD = 5 };
 
-// extra vector-memory operations issued in phase p of a K-tile of kind `kind` (NSP stores per pair of quadrants of a deferred epilogue,
+// extra vector-memory operations issued in phase p of a K-tile of kind `kind` (NSP0 / NSP1 stores for the quadrant pair of A sub-tile 0 / 1 of a deferred epilogue,
 // 1 bias DMA per tile); with a BULK epilogue (residual / GELU' operand kinds) the tile's NST stores are issued between the
 // last K-tile and the next tile's first one
 // (MX-fp8 form: + the K-tile's scale DMA, issued in phase 3 right BEFORE that phase's unit)
-__host__ __device__ constexpr int pp_extra(int kind, int p, int NSP, bool bulk, bool mx = false) {
+__host__ __device__ constexpr int pp_extra(int kind, int p, int NSP0, int NSP1, bool bulk, bool mx = false) {
     const int s = (mx && p == 3) ? 1 : 0;
     if (kind == PP_LAST) return s + (p == 1 ? 1 : 0);
-    if (kind == PP_FIRST_CHAIN && !bulk) return s + ((p & 1) ? 0 : NSP);
+    if (kind == PP_FIRST_CHAIN && !bulk) return s + (p == 0 ? NSP0 : p == 2 ? NSP1 : 0);
     return s;
 }
 __host__ __device__ constexpr int pp_prev_kind(int kind) {
     return kind == PP_FIRST_CHAIN ? PP_LAST : kind == PP_SECOND_CHAIN ? PP_FIRST_CHAIN : kind == PP_SECOND_COLD ? PP_FIRST_COLD : PP_PLAIN;
 }
 // operations younger than the unit staged 4 phases ago, at the wait of phase p: the DMAs of the last 4 phases + the extras
-__host__ __device__ constexpr int pp_nwait(int kind, int p, int NSP, bool bulk, bool mx = false) {
+__host__ __device__ constexpr int pp_nwait(int kind, int p, int NSP0, int NSP1, bool bulk, bool mx = false) {
     int n = 8;
-    for (int q = 0; q <= p; ++q) n += pp_extra(kind, q, NSP, bulk, mx);
+    for (int q = 0; q <= p; ++q) n += pp_extra(kind, q, NSP0, NSP1, bulk, mx);
     if (kind != PP_FIRST_COLD)                      // before a cold first K-tile there is only the prologue (nothing younger)
-        for (int q = p + 1; q < 4; ++q) n += pp_extra(pp_prev_kind(kind), q, NSP, bulk, mx);
+        for (int q = p + 1; q < 4; ++q) n += pp_extra(pp_prev_kind(kind), q, NSP0, NSP1, bulk, mx);
     else if (mx && p < 3) n += 1;                   // ... except the prologue's scale DMA of K-tile 1, issued where a phase 3 would have
-    if (kind == PP_FIRST_CHAIN && bulk) n += 2 * NSP;  // the previous tile's bulk epilogue (all of its stores) sits between the tiles
+    if (kind == PP_FIRST_CHAIN && bulk) n += NSP0 + NSP1;  // the previous tile's bulk epilogue (all of its stores) sits between the tiles
     return n;
 }
 
@@ -95,9 +95,13 @@ __host__ __device__ constexpr int pp_nwait(int kind, int p, int NSP, bool bulk, 
 //   X1K : 0 none, 1 residual res1 added (forward of proj / fc2), 2 activation-derivative operand aux multiplied (dgrad)
 //   PREK: also store the pre-activation (fc1) -- doubles the stores of a tile
 //   ACTK: e.act may be non-zero
-//   IM  : 16-row fragments per A sub-tile and wave row: 4 = 256-row tiles; 3 = 192-row tiles (wave tile 96 x 64, 12 MFMAs per
-//         phase, 12 KB A units) for the N = 768 GEMMs, whose 98 x 3 = 294 tiles of 256 rows leave the second round of a
-//         224-workgroup grid one third full (131 x 3 = 393 tiles of 3/4 the work: 1.5 instead of 2 tile-times)
+//   IM, IM1: 16-row fragments per wave row of A sub-tile 0 (read in phase 0, quadrants (0,0) (0,1)) and of A sub-tile 1 (read in phase
+//         2, quadrants (1,1) (1,0)); each 4, 3 or 2: tile height (IM + IM1) x 32 rows = 256, 224, 192, 160 or 128.  4+4 = 256-row tiles;
+//         3+3 = 192-row tiles (wave tile 96 x 64, 12 MFMAs per phase, 12 KB A units: round 2) for the N = 768 GEMMs, whose 98 x 3 =
+//         294 tiles of 256 rows leave the second round of a 224-workgroup grid one third full; round 5: the launcher picks the height
+//         whose tile count fills the last round of the walk best (M = 25 096 x N = 768 on 256 CUs: 471 tiles of 160 rows = two rounds
+//         of 0.63 instead of 393 tiles of 192 rows = two rounds of 0.75; N = 2304: 1017 tiles of 224 rows = four rounds of 0.875
+//         instead of 882 tiles of 256 rows = four rounds of 1).  A row's result does not depend on the height (same K order).
 //   MX  : MX-fp8 operands (egv_mx.hip): a K-tile is 128 e4m3 elements -- the SAME 128-byte row pieces, staging, swizzle and
 //         fragment reads (v_mfma_scale_f32_16x16x128_f8f6f4 takes k = 16 fg .. +15 in registers 0-3 and 64 + 16 fg .. +15 in
 //         registers 4-7 of lane group fg: exactly the two 16-byte chunks a lane reads for the two bf16 K-halves), half as many
@@ -107,22 +111,36 @@ __host__ __device__ constexpr int pp_nwait(int kind, int p, int NSP, bool bulk, 
 //         bf16-rounded values exactly as egv_quant_mx would quantise C: it is the A operand of the next Linear (fc1 -> fc2 forward,
 //         fc2 -> fc1 data gradient), whose quantiser launch disappears.  A 32-column block of a row is the 8 columns of the four
 //         lanes fr, fr + 16, fr + 32, fr + 48
-template <int X1K, bool PREK, bool ACTK, bool STAMPS = false, int IM = 4, bool MX = false, bool QOUT = false>
+template <int X1K, bool PREK, bool ACTK, bool STAMPS = false, int IM = 4, bool MX = false, bool QOUT = false, int IM1 = IM>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntiles) {
     static_assert(!QOUT || MX, "quantised output only in the MX-fp8 form");
-    static_assert(IM == 4 || IM == 3, "A sub-tile of 4 or 3 fragments");
-    static_assert(!MX || IM == 3, "MX-fp8 form: 192-row tiles only (48-row scale blocks; the 256-row form does not fit 256 registers)");
+    static_assert(IM >= 2 && IM <= 4 && IM1 >= 2 && IM1 <= 4, "A sub-tiles of 4, 3 or 2 fragments");
+    static_assert(!MX || (IM == 3 && IM1 == 3), "MX-fp8 form: 192-row tiles only (48-row scale blocks; the 256-row form does not fit 256 registers)");
     constexpr unsigned int ES = MX ? 1u : 2u;                      // bytes per operand element
-    constexpr int BM = IM * 64, WM = IM * 32, SM = IM * 16;        // tile rows, rows per wave row, rows per A sub-tile and wave row
+    constexpr int IMX = IM > IM1 ? IM : IM1;
+    constexpr int BM = (IM + IM1) * 32, WM = (IM + IM1) * 16;      // tile rows, rows per wave row
+    constexpr int SM0 = IM * 16, SM1 = IM1 * 16;                   // rows per wave row of A sub-tile 0 / 1
+#define PP_IMS(S) ((S) == 0 ? IM : IM1)                            /* fragments of sub-tile S */
+#define PP_AOFF(S) ((S) == 0 ? 0 : IM)                             /* first accumulator row block of sub-tile S */
+#define PP_ROFF(S) ((S) == 0 ? 0 : SM0)                            /* first row (inside a wave row) of sub-tile S */
     // stores per pair of quadrants (one pair_epilogue call): 2 (4 with the saved pre-activation) per 16-row fragment, + 2 code stores
     // and 1 scale store when the output is also emitted in MX-fp8 form
 #ifndef EGV_PP_EXP
 #define EGV_PP_EXP 0
 #endif
-    // EGV_PP_EXP (tools/pp_exp.sh, never in the product build): 1 = the epilogue stores are dropped; 3 = the residual / GELU' operand loads are dropped; 2 = stores dropped and replaced by the same
-    // number of stores trickled one per wave into phases 1 and 3 of the tile's plain K-tiles (counted waits left conservative)
-    constexpr int NSP = (EGV_PP_EXP == 1 || EGV_PP_EXP == 2) ? 0 : (PREK ? 4 : 2) * IM + (QOUT ? 3 * IM : 0);
-    constexpr bool BULK = X1K != 0;                                // residual / GELU' operand: epilogue in one piece at the tile's end
+    // EGV_PP_EXP (tools/pp_exp.sh, never in the product build): 1 = the epilogue stores are dropped; 3 = the residual / GELU' operand loads are dropped
+    // (2, round 4: stores trickled through the next tile's K-tiles -- slower, removed)
+    constexpr int NSP0 = EGV_PP_EXP == 1 ? 0 : (PREK ? 4 : 2) * IM + (QOUT ? 3 * IM : 0);
+    constexpr int NSP1 = EGV_PP_EXP == 1 ? 0 : (PREK ? 4 : 2) * IM1 + (QOUT ? 3 * IM1 : 0);
+#ifndef PP_PLAIN_BULK
+#define PP_PLAIN_BULK 0
+#endif
+    // residual / GELU' operand kinds: epilogue in one piece at the tile's end.  (Round 5 built the GELU' operand kind with the deferred
+    // quadrant-wise epilogue of the plain kinds, the saved pre-activation of a quadrant pair loaded at the head of the load segment that
+    // converts it: SLOWER, fc2 data gradient 154-157 -> 167-171 us -- the wait for those loads sits inside a barrier-locked phase, so the
+    // other wave row idles for a memory latency four times per tile; profiles/round5_experiments.md.)
+    // -DPP_PLAIN_BULK=1 (experiment): the plain kinds with the one-piece epilogue too (within 1 % either way).
+    constexpr bool BULK = X1K != 0 || PP_PLAIN_BULK;
     constexpr unsigned int OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -158,22 +176,19 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int rho = (p * 8 + wave) * 8 + srow;            // 0..127
-            if constexpr (IM == 4) {
-                // A units: rho -> tile row (rho>>6)*128 + sub*64 + (rho&63)
-                const int ra0 = min(tl.m0 + (rho >> 6) * 128 + (rho & 63), g.M - 1);
-                const int ra1 = min(tl.m0 + (rho >> 6) * 128 + 64 + (rho & 63), g.M - 1);
-                soff[0][p] = (unsigned int)(ra0 * g.lda) * ES + schunk;
-                soff[3][p] = (unsigned int)(ra1 * g.lda) * ES + schunk;
-            } else {
-                // 96-row A units: this wave stages rows wave*12 .. +11 -- piece 0 = 8 rows, piece 1 = 4 rows (lanes 0..31 only);
-                // unit row ra -> tile row (ra/48)*96 + sub*48 + ra%48; source chunk (lane&7) ^ (ra&7) (the reads' swizzle)
-                const int ra = min(wave * 12 + p * 8 + srow, 95);
-                const int ra0 = min(tl.m0 + (ra / 48) * 96 + (ra % 48), g.M - 1);
-                const int ra1 = min(tl.m0 + (ra / 48) * 96 + 48 + (ra % 48), g.M - 1);
+            // A unit of sub-tile S (2 x IMS x 16 rows: the sub-tile of both wave rows): unit row ra -> tile row (ra / SMS) * WM + ROFF(S) +
+            // ra % SMS; source chunk (lane & 7) ^ (ra & 7) (the reads' swizzle).  IMS = 4: 128 rows, two pieces of 8 rows per wave;
+            // 3: 96 rows, this wave stages rows wave*12 .. +11 -- piece 0 = 8 rows, piece 1 = 4 rows (lanes 0..31 only); 2: 64 rows,
+            // one piece of 8 rows per wave (piece 1 is a dummy DMA that keeps the count of vector-memory operations per unit)
+            auto a_off = [&](int ims, int roff) -> unsigned int {
+                const int sms = ims * 16;
+                const int ra = ims == 4 ? rho : ims == 3 ? min(wave * 12 + p * 8 + srow, 95) : wave * 8 + srow;
+                const int row = min(tl.m0 + (ra / sms) * WM + roff + (ra % sms), g.M - 1);
                 const unsigned int sch = ((lane & 7) ^ (ra & 7)) * 16;
-                soff[0][p] = (unsigned int)(ra0 * g.lda) * ES + sch;
-                soff[3][p] = (unsigned int)(ra1 * g.lda) * ES + sch;
-            }
+                return (ims == 2 && p == 1) ? 0u : (unsigned int)(row * g.lda) * ES + sch;
+            };
+            soff[0][p] = a_off(IM, 0);
+            soff[3][p] = a_off(IM1, SM0);
             // B units: rho = wc'*32 + j'*16 + q -> column wc'*64 + sub*32 + (q>>2)*8 + j'*4 + (q&3)
             const int wcp = rho >> 5, jp = (rho >> 4) & 1, q = rho & 15;
             const int cb0 = min(tl.n0 + wcp * 64 + (q >> 2) * 8 + jp * 4 + (q & 3), g.N - 1);
@@ -230,10 +245,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
         const unsigned int dst = lds0 + (s_gkt & 1) * PP_BUF + u * PP_UNIT + wave * 1024;
         const void* base = (u == 0 || u == 3) ? g.A : g.B;
         const unsigned int koff = (unsigned int)s_kt * 128u;
-        if (IM == 3 && (u == 0 || u == 3)) {                      // 96-row A unit: 1.5 KiB per wave
+        const int ims = u == 0 ? IM : u == 3 ? IM1 : 4;           // (B units: 128 rows)
+        if (ims == 3) {                                           // 96-row A unit: 1.5 KiB per wave
             const unsigned int dsta = lds0 + (s_gkt & 1) * PP_BUF + u * PP_UNIT + wave * 1536;
             glds(base, (soff[u][0] + koff) & live, __builtin_amdgcn_readfirstlane(dummy_lds + ((dsta - dummy_lds) & live)));
             glds_half(base, (soff[u][1] + koff) & live, __builtin_amdgcn_readfirstlane(dummy_lds + ((dsta + 1024 - dummy_lds) & live)));
+            return;
+        }
+        if (ims == 2) {                                           // 64-row A unit: 1 KiB per wave + a dummy piece (the waits count two operations per unit)
+            glds(base, (soff[u][0] + koff) & live, __builtin_amdgcn_readfirstlane(dummy_lds + ((dst - dummy_lds) & live)));
+            glds(base, 0u, __builtin_amdgcn_readfirstlane(dummy_lds));
             return;
         }
 #pragma unroll
@@ -254,7 +275,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
 
     // ---- fragment read offsets (bytes inside a K-tile buffer)
     const int swz0 = ((0 * 4 + fg) ^ (fr & 7)) * 16, swz1 = ((1 * 4 + fg) ^ (fr & 7)) * 16;
-    const int a_base = (wr * SM + fr) * 128;                      // + i*2048 ; unit U0 (sub 0) / U3 (sub 1)
+    const int a_base0 = (wr * SM0 + fr) * 128;                    // + i*2048 ; unit U0 (sub 0)
+    const int a_base1 = (wr * SM1 + fr) * 128;                    // + i*2048 ; unit U3 (sub 1)
     const int b_base = (wc * 32 + fr) * 128;                      // + j'*2048 ; unit U1 (sub 0) / U2 (sub 1)
 
     // ---- epilogue operands: buffer descriptors (range = whole matrix; offset 2^31 is out of range by construction: such
@@ -293,7 +315,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
         const int ld = out ? g.ldc : e.ldr;
         const int pair_col = wc * 64 + (fr_ >> 3) * 32 + fg_ * 8;
         const unsigned int lane_part = (__umul24((unsigned int)(wr * WM + (fr_ & 7)), (unsigned int)ld) + (unsigned int)pair_col) * 2u;
-        const unsigned int sterm = (unsigned int)((tl.m0 + s * SM + i * 16 + second * 8) * ld + tl.n0) * 2u;
+        const unsigned int sterm = (unsigned int)((tl.m0 + PP_ROFF(s) + i * 16 + second * 8) * ld + tl.n0) * 2u;
         return (tl.n0 + pair_col < g.N) ? lane_part + sterm : OOB;
     };
     // (a, b) of this lane = (t = 0, t = 1) vectors of its row  ->  (first, second) store vectors
@@ -309,7 +331,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
     };
     auto q_off = [&](const PPTile& tl, bool valid, int s, int i, int t, bool out) -> unsigned int {
         const int ld = out ? g.ldc : e.ldr;
-        const unsigned int sterm = (unsigned int)((tl.m0 + s * SM + i * 16) * ld + tl.n0 + t * 32) * 2u;
+        const unsigned int sterm = (unsigned int)((tl.m0 + PP_ROFF(s) + i * 16) * ld + tl.n0 + t * 32) * 2u;
         return (valid && tl.n0 + lane_col < g.N) ? (out ? lane_c : lane_r) + sterm : OOB;
     };
 
@@ -323,8 +345,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
         const unsigned int voff = (unsigned int)min(tb.n0 + lane * 4, g.N - 4) * 4u;
         glds(has_bias ? (const void*)e.bias : g.B, has_bias ? voff : 0u, __builtin_amdgcn_readfirstlane(bias_lds));
     };
-    f32x4_t acc[2 * IM][4];                                       // (s*IM+i, t*2+j'); written by the first MFMAs of every tile
-    bf16x8_t af[IM][2], bf0[2][2], bf1[2][2];
+    f32x4_t acc[IM + IM1][4];                                     // (AOFF(s)+i, t*2+j'); written by the first MFMAs of every tile
+    bf16x8_t af[IMX][2], bf0[2][2], bf1[2][2];
     int sc_a0 = 0, sc_a1 = 0, sc_b = 0;                           // MX: block scales of the K-tile (A sub-tiles 0 / 1: byte i; B: byte t*2+j')
     auto sc_read = [&](int slot, int piece) {                     // this lane's dword of a 256-byte scale piece
         unsigned int l4 = lane;
@@ -333,30 +355,35 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
     };
 
     // convert + store the two quadrants (s, 0), (s, 1) of the finished tile `tl`: 8 full-line stores (16 with the pre-activation)
-    u32x4_t xop2[X1K == 3 ? 2 : 1][X1K == 3 ? IM : 1][2];      // second residual (gated i2t projection: x + gate * y + skip)
-    u32x4_t xop[2][IM][2];                                         // bulk epilogue: residual / GELU' operand vectors (s, i, t) of the tile
+    u32x4_t xop2[X1K == 3 ? 2 : 1][X1K == 3 ? IMX : 1][2];     // second residual (gated i2t projection: x + gate * y + skip)
+    u32x4_t xop[2][IMX][2];                                        // bulk epilogue: residual / GELU' operand vectors (s, i, t) of the tile
     auto pair_epilogue = [&](int s, const PPTile& tl) {           // s compile-time
-        float bias8[2][8];                                        // the finished tile's bias from this wave's LDS slab
-        {
-            const float* bp = bias_slab + wc * 64 + (opaque_lane() >> 4) * 8;
+        // the finished tile's bias from this wave's LDS slab, read where it is added (8 registers live instead of 16 across the pair: the
+        // GELU + saved pre-activation kind spilled 34 registers with the hoisted form)
+        auto bias_t = [&](int t, float (&b8)[8]) {
+            if constexpr (X1K == 2) {                             // a data gradient has no bias (checked by the launcher): x + 0.f == x for every x the sum can be
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(bp + t * 32), b1 = *reinterpret_cast<const f32x4_t*>(bp + t * 32 + 4);
+                for (int k = 0; k < 8; ++k) b8[k] = 0.f;
+            } else {
+                const float* bp = bias_slab + wc * 64 + (opaque_lane() >> 4) * 8 + t * 32;
+                f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(bp), b1 = *reinterpret_cast<const f32x4_t*>(bp + 4);
                 if (!has_bias) b0 = b1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { bias8[t][k] = b0[k]; bias8[t][4 + k] = b1[k]; }
+                for (int k = 0; k < 4; ++k) { b8[k] = b0[k]; b8[4 + k] = b1[k]; }
             }
-        }
+        };
 #pragma unroll
-        for (int i = 0; i < IM; ++i) {
+        for (int i = 0; i < PP_IMS(s); ++i) {
             u32x4_t f, sec;
             if (PREK) {                                           // pre-activation first, in its own pass (register budget)
                 u32x4_t pr[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const f32x4_t a0 = acc[s * IM + i][t * 2 + 0], a1 = acc[s * IM + i][t * 2 + 1];
-                    float pv[8] = {a0[0] + bias8[t][0], a0[1] + bias8[t][1], a0[2] + bias8[t][2], a0[3] + bias8[t][3],
-                                   a1[0] + bias8[t][4], a1[1] + bias8[t][5], a1[2] + bias8[t][6], a1[3] + bias8[t][7]};
+                    const f32x4_t a0 = acc[PP_AOFF(s) + i][t * 2 + 0], a1 = acc[PP_AOFF(s) + i][t * 2 + 1];
+                    float b8[8];
+                    bias_t(t, b8);
+                    float pv[8] = {a0[0] + b8[0], a0[1] + b8[1], a0[2] + b8[2], a0[3] + b8[3],
+                                   a1[0] + b8[4], a1[1] + b8[5], a1[2] + b8[6], a1[3] + b8[7]};
                     if (e.act == 4) {                             // EGV_ACT_GELU_D: the saved tensor is gelu'(x) (one more FMA beside the GELU below)
 #pragma unroll
                         for (int k = 0; k < 8; ++k) { float gg; gelu_pair_fast_f(pv[k], gg, pv[k]); }
@@ -364,7 +391,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                     pr[t] = u32x4_t{pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]), pack_bf16x2(pv[4], pv[5]), pack_bf16x2(pv[6], pv[7])};
                 }
                 pair_swap(pr[0], pr[1], f, sec);
-#if EGV_PP_EXP == 1 || EGV_PP_EXP == 2
+#if EGV_PP_EXP == 1
                 asm volatile("" :: "v"(f), "v"(sec));
 #else
                 __builtin_amdgcn_raw_buffer_store_b128(f, rs_pre, p_off(tl, s, i, 0, false), 0, PP_ST_AUX);
@@ -374,20 +401,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
             u32x4_t o[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                float v[8];
+                float v[8], b8[8];
+                bias_t(t, b8);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    v[k] = acc[s * IM + i][t * 2 + 0][k] + bias8[t][k];            // (sum over K) + bias: the ring kernels' order, bit for bit
-                    v[4 + k] = acc[s * IM + i][t * 2 + 1][k] + bias8[t][4 + k];
+                    v[k] = acc[PP_AOFF(s) + i][t * 2 + 0][k] + b8[k];              // (sum over K) + bias: the ring kernels' order, bit for bit
+                    v[4 + k] = acc[PP_AOFF(s) + i][t * 2 + 1][k] + b8[4 + k];
                 }
-                if (ACTK) {
-                    if (e.act == 1 || e.act == 4) {
+                if (ACTK) {                                       // GELU only (the launcher sends other activations to the ring kernels)
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) v[k] = gelu_fast_f(v[k]);
-                    } else if (e.act) {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) v[k] = apply_act(v[k], e.act);
-                    }
+                    for (int k = 0; k < 8; ++k) v[k] = gelu_fast_f(v[k]);
                 }
                 if (X1K == 3 || has_gate) {                       // (x * 1.0f is x: skipping the multiply changes no bit)
 #pragma unroll
@@ -404,19 +427,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                     for (int k = 0; k < 4; ++k) { v[2 * k] += __uint_as_float(r[k] << 16); v[2 * k + 1] += __uint_as_float(r[k] & 0xffff0000u); }
                 }
                 if (X1K == 2) {
-                    const u32x4_t r = xop[s][i][t];
-                    if (e.dact == 1) {
+                    const u32x4_t r = xop[s][i][t];                 // GELU' only (other derivatives: ring kernels)
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            v[2 * k] *= dgelu_fast_f(__uint_as_float(r[k] << 16));
-                            v[2 * k + 1] *= dgelu_fast_f(__uint_as_float(r[k] & 0xffff0000u));
-                        }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            v[2 * k] *= apply_dact(__uint_as_float(r[k] << 16), e.dact);
-                            v[2 * k + 1] *= apply_dact(__uint_as_float(r[k] & 0xffff0000u), e.dact);
-                        }
+                    for (int k = 0; k < 4; ++k) {
+                        v[2 * k] *= dgelu_fast_f(__uint_as_float(r[k] << 16));
+                        v[2 * k + 1] *= dgelu_fast_f(__uint_as_float(r[k] & 0xffff0000u));
                     }
                 }
                 o[t] = u32x4_t{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
@@ -424,7 +439,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
             if constexpr (QOUT) {
                 const int l = opaque_lane();
                 const int fr_ = l & 15, fg_ = l >> 4;
-                const int row = tl.m0 + wr * WM + s * SM + i * 16 + fr_;
+                const int row = tl.m0 + wr * WM + PP_ROFF(s) + i * 16 + fr_;
                 const int col = tl.n0 + wc * 64 + fg_ * 8;                     // + t * 32
                 int e8[2];
 #pragma unroll
@@ -466,7 +481,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                 }
             }
             pair_swap(o[0], o[1], f, sec);
-#if EGV_PP_EXP == 1 || EGV_PP_EXP == 2
+#if EGV_PP_EXP == 1
             asm volatile("" :: "v"(f), "v"(sec));
 #else
             __builtin_amdgcn_raw_buffer_store_b128(f, rs_c, p_off(tl, s, i, 0, true), 0, PP_ST_AUX);
@@ -496,8 +511,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
 #define PP_PIN() do { if constexpr (MX) __builtin_amdgcn_sched_barrier(0); } while (0)
 #define PP_CAT8(X) __builtin_shufflevector(__builtin_bit_cast(i32x4_t, (X)[0]), __builtin_bit_cast(i32x4_t, (X)[1]), 0, 1, 2, 3, 4, 5, 6, 7)
 #define PP_MX1(S, BF, T, ZERO, I, JP)                                                                                      \
-    acc[(S) * IM + (I)][(T) * 2 + (JP)] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                                \
-        PP_CAT8(BF[JP]), PP_CAT8(af[I]), (ZERO) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[(S) * IM + (I)][(T) * 2 + (JP)], 0, 0, \
+    acc[PP_AOFF(S) + (I)][(T) * 2 + (JP)] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                              \
+        PP_CAT8(BF[JP]), PP_CAT8(af[I]), (ZERO) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[PP_AOFF(S) + (I)][(T) * 2 + (JP)], 0, 0, \
         (T) * 2 + (JP), sc_b, (I), (S) == 0 ? sc_a0 : sc_a1)
 #define PP_MFMA(S, BF, T, ZERO)                                                                                            \
     do {                                                                                                                   \
@@ -510,32 +525,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
             PP_MX1(S, BF, T, ZERO, 2, 0); PP_MX1(S, BF, T, ZERO, 2, 1);                                                    \
             if constexpr (IM == 4) { PP_MX1(S, BF, T, ZERO, IM - 1, 0); PP_MX1(S, BF, T, ZERO, IM - 1, 1); }               \
             _Pragma("unroll") for (int i = 0; i < IM; ++i)                                                                 \
-            _Pragma("unroll") for (int jp = 0; jp < 2; ++jp) asm volatile("" : "+v"(acc[(S) * IM + i][(T) * 2 + jp]));     \
+            _Pragma("unroll") for (int jp = 0; jp < 2; ++jp) asm volatile("" : "+v"(acc[PP_AOFF(S) + i][(T) * 2 + jp]));   \
         } else {                                                                                                           \
         _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                                   \
-        _Pragma("unroll") for (int i = 0; i < IM; ++i)                                                                     \
+        _Pragma("unroll") for (int i = 0; i < PP_IMS(S); ++i)                                                              \
         _Pragma("unroll") for (int jp = 0; jp < 2; ++jp)                                                                   \
-            acc[(S) * IM + i][(T) * 2 + jp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                     \
-                BF[jp][kh], af[i][kh], ((ZERO) && kh == 0) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[(S) * IM + i][(T) * 2 + jp], 0, 0, 0); \
+            acc[PP_AOFF(S) + i][(T) * 2 + jp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                   \
+                BF[jp][kh], af[i][kh], ((ZERO) && kh == 0) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[PP_AOFF(S) + i][(T) * 2 + jp], 0, 0, 0); \
         }                                                                                                                  \
         PP_SETPRIO(0);                                                                                                     \
     } while (0)
-#if EGV_PP_EXP == 2
-#define PP_EXP_TRICKLE(KIND, H)                                                                                            \
-    do {                                                                                                                   \
-        if ((KIND) == PP_PLAIN && ts > 0) {                                                                                \
-            const int slot = exp_kt * 2 + (H);                                                                             \
-            const int per = PREK ? 2 : 1;                                                                                  \
-            if (slot < 4 * IM / 1) {                                                                                       \
-                for (int r = 0; r < per; ++r)                                                                              \
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, bf1[0][0]), r ? rs_pre : rs_c,     \
-                        p_off(prev, (slot / (2 * IM)) & 1, (slot >> 1) % IM, slot & 1, r == 0), 0, 0);                     \
-            }                                                                                                              \
-        }                                                                                                                  \
-    } while (0)
-#else
-#define PP_EXP_TRICKLE(KIND, H) do { } while (0)
-#endif
 #define PP_KTILE(KIND, BUFIDX)                                                                                             \
     do {                                                                                                                   \
         constexpr bool FIRSTK = (KIND) == PP_FIRST_CHAIN || (KIND) == PP_FIRST_COLD;                                       \
@@ -547,7 +546,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
             if (CHAIN && !BULK) pp_wait_vmcnt<6 + (MX ? 1 : 0)>();   /* the bias DMA of LAST phase 1 (this wave's own slab) landed */ \
             if (CHAIN && !BULK) pair_epilogue(0, prev);                                                                             \
             if (CHAIN && !BULK) PP_PIN();                                                                                  \
-            const unsigned char* pa = buf + 0 * PP_UNIT + a_base;                                                          \
+            const unsigned char* pa = buf + 0 * PP_UNIT + a_base0;                                                         \
             const unsigned char* pb = buf + 1 * PP_UNIT + b_base;                                                          \
             _Pragma("unroll") for (int jp = 0; jp < 2; ++jp) {                                                             \
                 bf0[jp][0] = *reinterpret_cast<const bf16x8_t*>(pb + jp * 2048 + swz0);                                    \
@@ -562,7 +561,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                 sc_b = sc_read((BUFIDX) & 3, 4 + wc);                                                                      \
             }                                                                                                              \
             stage_unit(2);                                                                                                 \
-            pp_wait_vmcnt<pp_nwait(KIND, 0, NSP, BULK, MX)>();                                                           \
+            pp_wait_vmcnt<pp_nwait(KIND, 0, NSP0, NSP1, BULK, MX)>();                                                           \
             __builtin_amdgcn_s_barrier();                                                                                  \
             PP_MFMA(0, bf0, 0, FIRSTK);                                                                                 \
             __builtin_amdgcn_s_barrier();                                                                                  \
@@ -570,7 +569,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
         /* ---------------- phase 1: read B sub 1 (U2); stage U3 of kt+1; quadrant 1 = (0,1) */                            \
         {                                                                                                                  \
             if (LASTK) load_bias(cur);                                                                                    \
-            PP_EXP_TRICKLE(KIND, 0);                                                                                       \
             const unsigned char* pb = buf + 2 * PP_UNIT + b_base;                                                          \
             _Pragma("unroll") for (int jp = 0; jp < 2; ++jp) {                                                             \
                 bf1[jp][0] = *reinterpret_cast<const bf16x8_t*>(pb + jp * 2048 + swz0);                                    \
@@ -578,7 +576,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
             }                                                                                                              \
             stage_unit(3);                                                                                                 \
             advance_cursor();                                                                                              \
-            pp_wait_vmcnt<pp_nwait(KIND, 1, NSP, BULK, MX)>();                                                           \
+            pp_wait_vmcnt<pp_nwait(KIND, 1, NSP0, NSP1, BULK, MX)>();                                                           \
             __builtin_amdgcn_s_barrier();                                                                                  \
             PP_MFMA(0, bf1, 1, FIRSTK);                                                                                 \
             __builtin_amdgcn_s_barrier();                                                                                  \
@@ -587,24 +585,23 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
         {                                                                                                                  \
             if (CHAIN && !BULK) pair_epilogue(1, prev);                                                                             \
             if (CHAIN && !BULK) PP_PIN();                                                                                  \
-            const unsigned char* pa = buf + 3 * PP_UNIT + a_base;                                                          \
-            _Pragma("unroll") for (int i = 0; i < IM; ++i) {                                                               \
+            const unsigned char* pa = buf + 3 * PP_UNIT + a_base1;                                                         \
+            _Pragma("unroll") for (int i = 0; i < IM1; ++i) {                                                              \
                 af[i][0] = *reinterpret_cast<const bf16x8_t*>(pa + i * 2048 + swz0);                                       \
                 af[i][1] = *reinterpret_cast<const bf16x8_t*>(pa + i * 2048 + swz1);                                       \
             }                                                                                                              \
             if constexpr (MX) sc_a1 = sc_read((BUFIDX) & 3, wr * 2 + 1);                                                   \
             stage_unit(0);                                                                                                 \
-            pp_wait_vmcnt<pp_nwait(KIND, 2, NSP, BULK, MX)>();                                                           \
+            pp_wait_vmcnt<pp_nwait(KIND, 2, NSP0, NSP1, BULK, MX)>();                                                           \
             __builtin_amdgcn_s_barrier();                                                                                  \
             PP_MFMA(1, bf1, 1, FIRSTK);                                                                                 \
             __builtin_amdgcn_s_barrier();                                                                                  \
         }                                                                                                                  \
         /* ---------------- phase 3: no reads; stage U1 of kt+2; quadrant 3 = (1,0) */                                     \
         {                                                                                                                  \
-            PP_EXP_TRICKLE(KIND, 1);                                                                                       \
             stage_scales();                                                                                                \
             stage_unit(1);                                                                                                 \
-            pp_wait_vmcnt<pp_nwait(KIND, 3, NSP, BULK, MX)>();                                                           \
+            pp_wait_vmcnt<pp_nwait(KIND, 3, NSP0, NSP1, BULK, MX)>();                                                           \
             __builtin_amdgcn_s_barrier();                                                                                  \
             PP_MFMA(1, bf0, 0, FIRSTK);                                                                                 \
             __builtin_amdgcn_s_barrier();                                                                                  \
@@ -613,7 +610,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
 
     PPTile prev = cur, nxt = cur;
     bool have_next = false;
-    [[maybe_unused]] int exp_kt = 0;
     for (int ts = 0; ts < my_tiles; ++ts) {
         have_next = ts + 1 < my_tiles;
         nxt = pp_tile(first + (have_next ? ts + 1 : ts) * G, g.tiles_n, BM);
@@ -637,7 +633,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
             PP_STAMP(1);
             PP_KTILE(PP_SECOND_CHAIN, kb + 1);
         }
-        for (int kt = 2; kt < KT - 1; ++kt) { PP_STAMP(kt); exp_kt = kt - 2; PP_KTILE(PP_PLAIN, kb + kt); }
+        for (int kt = 2; kt < KT - 1; ++kt) { PP_STAMP(kt); PP_KTILE(PP_PLAIN, kb + kt); }
         PP_STAMP(KT - 1);
         PP_KTILE(PP_LAST, kb + KT - 1);
         PP_STAMP(KT);
@@ -645,10 +641,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
         if (BULK) {
             // all 16 operand vectors first (a load issued after a store would wait for it), then convert + store; the stores
             // drain under the next tile's first K-tile (counted in its waits)
+            if constexpr (X1K != 0)
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int i = 0; i < IM; ++i)
+                for (int i = 0; i < PP_IMS(s); ++i)
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
 #if EGV_PP_EXP == 3                                                   // experiment: no operand loads (the VALU work and the stores stay)
@@ -660,12 +657,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
-                    for (int i = 0; i < IM; ++i)
+                    for (int i = 0; i < PP_IMS(s); ++i)
 #pragma unroll
                         for (int t = 0; t < 2; ++t)
                             xop2[s][i][t] = __builtin_amdgcn_raw_buffer_load_b128(rs_x2, q_off(cur, true, s, i, t, false), 0, 0);
             }
-            pp_wait_vmcnt<6 + (MX ? 1 : 0) + (EGV_PP_EXP == 3 ? 0 : (X1K == 3 ? 8 : 4) * IM)>();                // the bias DMA of LAST phase 1 (16 operand loads are younger)
+            pp_wait_vmcnt<6 + (MX ? 1 : 0) + ((EGV_PP_EXP == 3 || X1K == 0) ? 0 : (X1K == 3 ? 4 : 2) * (IM + IM1))>();                // the bias DMA of LAST phase 1 (16 operand loads are younger)
             pair_epilogue(0, cur);
             pair_epilogue(1, cur);
         }
@@ -673,6 +670,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
         cur = nxt;
     }
 #undef PP_KTILE
+#undef PP_IMS
+#undef PP_AOFF
+#undef PP_ROFF
 #undef PP_MFMA
 #undef PP_MX1
 #undef PP_PIN
@@ -718,6 +718,7 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
     if ((long long)g.M * g.lda >= (1LL << 30) || (long long)g.N * g.ldb >= (1LL << 30)) return 0;   // 32-bit byte offsets
     if ((long long)g.M * g.ldc >= (1LL << 30) || (long long)g.M * e.ldr >= (1LL << 30)) return 0;
     if (e.scale != 1.0f) return 0;                                // the bias rides in as the accumulators' initial value
+    if ((e.act && e.act != 1 && e.act != 4) || (e.dact && (e.dact != 1 || e.bias))) return 0;   // epilogues are built for GELU / GELU' (a data gradient: no bias) only
     if (e.res2 && (!e.res1 || e.dact || e.act)) return 0;             // gated two-residual form; e.pre = the saved pre-gate value
     if (e.res1 && !e.res2 && (e.gate || e.dact || e.act || e.pre)) return 0;
     if (e.dact && (e.act || e.pre)) return 0;
@@ -754,19 +755,37 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
         ncu = slack > 0 ? (g_cu_limit >= 8 ? (g_cu_limit / 8) * 8 : 8) : (g_cu_limit >= 8 ? g_cu_limit : 8);
         ncu_soft = ncu + slack < ncu_all ? ncu + slack : ncu_all;
     }
-    // tile height: 192-row tiles where they shorten the walk (rounds x tile work, + 6 % for the smaller tile's lower operand
-    // reuse); only the plain and the residual epilogue kinds are built for them
+    // tile height: the candidate whose walk is shortest -- rounds x (rows + c0), c0 = what a tile costs whatever its height (B loads,
+    // fixed epilogue work: 56 rows' worth, from the measured 6 % penalty of 192- against 256-row tiles).  Built: plain kinds 256 / 224 /
+    // 192 / 160 / 128 rows; residual kinds 256 / 192; gated two-residual 192; the GELU kinds 256 only.
     static const bool allow192 = egv_cfg_on("EGV_PP_BM192", true);
+    static const int mixed_mode = egv_cfg_int("EGV_PP_MIXED", 1);   // 224- / 160- / 128-row tiles (round 5): 1 = grids that plan for the whole chip, 2 = also under a CU limit
+    const bool allow_mixed = mixed_mode >= 2 || (mixed_mode == 1 && !(g_cu_limit > 0 && g_cu_limit < ncu_all));
+    static const double c0 = egv_cfg_f64("EGV_PP_TILE_C0", 56.0);
     const bool kind192 = !e.dact && (!e.pre || e.res2) && !e.act && !stamps;
-    const int t256 = ((g.M + 255) / 256) * g.tiles_n, t192 = ((g.M + 191) / 192) * g.tiles_n;
-    static const double pen192 = egv_cfg_f64("EGV_PP_192_PENALTY", 1.06);
+    const bool kind_plain = kind192 && !e.res1 && !e.res2 && !e.pre;
     auto rounds_of = [&](int t) {
         const int r = (t + ncu - 1) / ncu;
         return ncu_soft > ncu && (t + ncu_soft - 1) / ncu_soft < r ? (t + ncu_soft - 1) / ncu_soft : r;
     };
-    const double c256 = (double)rounds_of(t256), c192 = (double)rounds_of(t192) * 0.75 * pen192;
-    const bool use192 = allow192 && kind192 && t256 >= ncu && c192 < c256;
-    g.tiles_m = use192 ? (g.M + 191) / 192 : (g.M + 255) / 256;
+    const int t256 = ((g.M + 255) / 256) * g.tiles_n;
+    int bm = 256;
+    if (t256 >= ncu) {                                             // (small problems: one partial round of the tallest tile)
+        double best = (double)rounds_of(t256) * (256.0 + c0);
+        const int cand[4] = {224, 192, 160, 128};
+        for (int c = 0; c < 4; ++c) {
+            const int h = cand[c];
+            const bool ok = h == 192 ? (allow192 && kind192) : (allow_mixed && kind_plain);
+            if (!ok) continue;
+            const double cost = (double)rounds_of(((g.M + h - 1) / h) * g.tiles_n) * (h + c0);
+            if (cost < best * 0.999) { best = cost; bm = h; }
+        }
+    }
+    if (const int f = egv_cfg_int("EGV_PP_FORCE_BM", 0)) {         // tests: a given height wherever the kind is built for it (read per call)
+        if ((f == 256) || (f == 192 && kind192) || ((f == 224 || f == 160 || f == 128) && kind_plain)) bm = f;
+    }
+    if (e.res2) bm = 192;                                         // gated two-residual form (i2t projection): built for the 192-row tiles only
+    g.tiles_m = (g.M + bm - 1) / bm;
     const int ntiles = g.tiles_m * g.tiles_n;
     // the smallest grid (multiple of 8: the XCD-aware walk) that keeps the number of rounds: the walk takes as long, and the CUs it
     // does not take serve the companion streams
@@ -779,57 +798,37 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
     int grid = trim ? (((ntiles + rounds - 1) / rounds + 7) / 8) * 8 : ncu;
     if (grid > ncu) grid = ncu;
     if (ntiles < grid) grid = ((ntiles + 7) / 8) * 8;
-#define PP_LAUNCH(X, P, AC)                                                                                              \
+#define PP_GO(X, P, AC, ST, I0, I1)                                                                                      \
     do {                                                                                                                 \
         static bool attr = false;                                                                                        \
         if (!attr) {                                                                                                     \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<X, P, AC>),                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<X, P, AC, ST, I0, false, false, I1>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);                               \
             attr = true;                                                                                                 \
         }                                                                                                                \
         egv_prof_cus_hint = grid;                                                                                        \
-        hipLaunchKernelGGL((gemm_pp_kernel<X, P, AC>), dim3(grid), dim3(512), PP_LDS, st, g, ntiles);                    \
+        hipLaunchKernelGGL((gemm_pp_kernel<X, P, AC, ST, I0, false, false, I1>), dim3(grid), dim3(512), PP_LDS, st, g, ntiles); \
         return 1;                                                                                                        \
     } while (0)
     static const int res_min_k = egv_cfg_int("EGV_PP_RES_MINK", 1536);
-    if (e.res1 && g.K < res_min_k && !(use192 && g.K >= res_min_k / 2)) return 0;   // short-K residual GEMMs on 256-row tiles: the 2-workgroup ring kernel hides their epilogue better
-#define PP_LAUNCH192P(X, P)                                                                                              \
-    do {                                                                                                                 \
-        static bool attr = false;                                                                                        \
-        if (!attr) {                                                                                                     \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<X, P, false, false, 3>),              \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);                               \
-            attr = true;                                                                                                 \
-        }                                                                                                                \
-        egv_prof_cus_hint = grid;                                                                                        \
-        hipLaunchKernelGGL((gemm_pp_kernel<X, P, false, false, 3>), dim3(grid), dim3(512), PP_LDS, st, g, ntiles);       \
-        return 1;                                                                                                        \
-    } while (0)
-#define PP_LAUNCH192(X) PP_LAUNCH192P(X, false)
-    if (e.res2 && !use192) return 0;                              // gated two-residual form (i2t projection): built for the 192-row tiles only
-    if (use192 && e.res2 && e.pre) PP_LAUNCH192P(3, true);
-    if (use192 && e.res2) PP_LAUNCH192(3);
-    if (use192 && e.res1) PP_LAUNCH192(1);
-    if (use192) PP_LAUNCH192(0);
-#undef PP_LAUNCH192
-#undef PP_LAUNCH192P
-    if (e.res1) PP_LAUNCH(1, false, false);
-    if (e.dact) PP_LAUNCH(2, false, false);
-    if (e.pre) PP_LAUNCH(0, true, true);
-    if (e.act) PP_LAUNCH(0, false, true);
+    if (e.res1 && g.K < res_min_k && !(bm == 192 && g.K >= res_min_k / 2)) return 0;   // short-K residual GEMMs on 256-row tiles: the 2-workgroup ring kernel hides their epilogue better
+    if (e.res2 && !(allow192 && kind192)) return 0;
+    if (e.res2 && e.pre) PP_GO(3, true, false, false, 3, 3);
+    if (e.res2) PP_GO(3, false, false, false, 3, 3);
+    if (e.res1 && bm == 192) PP_GO(1, false, false, false, 3, 3);
+    if (e.res1) PP_GO(1, false, false, false, 4, 4);
+    if (e.dact) PP_GO(2, false, false, false, 4, 4);
+    if (e.pre) PP_GO(0, true, true, false, 4, 4);
+    if (e.act) PP_GO(0, false, true, false, 4, 4);
 #ifdef EGV_INSTRUMENT
-    if (stamps) {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<0, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-            attr = true;
-        }
-        hipLaunchKernelGGL((gemm_pp_kernel<0, false, false, true>), dim3(grid), dim3(512), PP_LDS, st, g, ntiles);
-        return 1;
-    }
+    if (stamps) PP_GO(0, false, false, true, 4, 4);
 #endif
-    PP_LAUNCH(0, false, false);
-#undef PP_LAUNCH
+    if (bm == 224) PP_GO(0, false, false, false, 4, 3);
+    if (bm == 192) PP_GO(0, false, false, false, 3, 3);
+    if (bm == 160) PP_GO(0, false, false, false, 3, 2);
+    if (bm == 128) PP_GO(0, false, false, false, 2, 2);
+    PP_GO(0, false, false, false, 4, 4);
+#undef PP_GO
 }
 
 // ---- MX-fp8 form (BASELINE.json configs[4]: "fp8 MFMA weight path") ---------------------------------------------------------
@@ -852,6 +851,7 @@ extern "C" int egv_gemm_mx(int M, int N, int K, const void* Aq, const void* Asca
               "egv_gemm_mx: operand beyond 32-bit byte offsets");
     EGV_CHECK(!(res1 && (dact || act || pre)) && !(dact && (act || pre)) && !(pre && !act), "egv_gemm_mx: epilogue combination not built");
     EGV_CHECK(!dact || aux, "egv_gemm_mx: dact without aux");
+    EGV_CHECK((act == 0 || act == 1 || act == 4) && (dact == 0 || (dact == 1 && !bias)), "egv_gemm_mx: epilogues are built for GELU / GELU' (without bias) only");
     EGV_CHECK((out_q == nullptr) == (out_scales == nullptr), "egv_gemm_mx: out_q and out_scales come together");
     EGV_CHECK(!out_q || (((pre && act) || dact) && (N % 128) == 0 && ldc == N && al16(out_q)),
               "egv_gemm_mx: the quantised output is built for the GELU (saved pre-activation) and the GELU' epilogues, N %% 128 == 0, ldc == N");

@@ -886,7 +886,19 @@ class FrozenInTime(nn.Module):
                     v_rem = ExchangeClipsFn.apply(v_pre, table, rank, bsz, c.seq)
                 plan = [(0, j - lo) if lo <= j < lo + bsz else (1, remote.index(j)) for j in vid_list]
                 data_itm['video'] = None
-                data_itm['_video_prefix'] = SelectClipsFn.apply(plan, c.seq, v_pre, v_rem)
+                pre = SelectClipsFn.apply(plan, c.seq, v_pre, v_rem)
+                x32 = ops.stream32(v_pre)
+                if x32 is not None and SW.on('EGV_ITM_RES32'):
+                    # the fp32 value of the residual stream travels with the gathered clips (this rank's own clips: the fp32 rows of the
+                    # shared prefix; clips fetched from another rank arrive as bf16 tokens and start from those), so that the ITM pass
+                    # continues the stream the way the MLM pass does -- the reference under autocast keeps it in fp32 throughout
+                    with torch.no_grad():
+                        p32 = torch.empty(len(plan) * c.seq, x32.shape[1], dtype=torch.float32, device=x32.device)
+                        for i, (w, j) in enumerate(plan):
+                            src = x32 if w == 0 else v_rem
+                            p32[i * c.seq:(i + 1) * c.seq].copy_(src[j * c.seq:(j + 1) * c.seq])
+                    pre._res32 = p32
+                data_itm['_video_prefix'] = pre
             else:
                 data_itm['video'] = all_video.index_select(0, vid_idx)
             r_itm = self.infer(data_itm, task_names='ITM', ret=ret)

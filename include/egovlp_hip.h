@@ -171,6 +171,12 @@ typedef struct egv_attn_desc {
     int nsplit; float* ws; long long ws_bytes;   /* split of the other-side loop, fp32 partial slabs */
     float drop_p; unsigned int drop_seed;        /* attention-probability dropout (roberta.py:313): P~ = P * keep/(1-p); the mask is a
                                                     counter-based function of (seed, query row, key row, head); 0 = off */
+    float* O32;                                  /* optional (bf16 storage): fp32 values of O, [rows, ldo] with the offsets of O.  egv_attn_fwd
+                                                    writes it (split form and the unsplit MFMA kernel), egv_attn_bwd_dq forms
+                                                    delta = rowsum(dO o O) from it.  A query over thousands of keys (text -> image) has nearly
+                                                    uniform probabilities: dS = P o (dP - delta) is a small difference and the bf16 rounding of
+                                                    O puts a COMMON offset into delta -- 3-5 x the q / k gradient error of the reference
+                                                    under autocast, measured (tools/bf16_grad_error.py); NULL = O itself is used */
 } egv_attn_desc;
 /* nsplit > 1 splits the OTHER side of a launch across workgroups (fp32 partials in ws, combined in a fixed order):
  * needed when one own row meets thousands of other rows (CLS query/key over all S tokens, text<->video cross attention).

@@ -700,6 +700,29 @@ def test_persistent_gemm_bitwise_equals_ring_gemm(ops, N, K, kind):
     assert _rel(big[rows.cuda()], ref) < 6e-3
 
 
+@pytest.mark.parametrize('bm', [256, 224, 192, 160, 128])
+@pytest.mark.parametrize('N,K,bias', [(768, 768, False), (2304, 768, True), (768, 2304, False)])
+def test_persistent_gemm_every_tile_height_is_bitwise_the_same(ops, N, K, bias, bm, monkeypatch):
+    """round 5: the persistent GEMM picks its tile height per call (A sub-tiles of 4 / 3 / 2 fragments: 256, 224, 192, 160 or 128 rows)
+    to fill the last round of its walk.  A row's result must not depend on the height: every forced height (EGV_PP_FORCE_BM) against the
+    height the launcher picks on its own, bit for bit over the WHOLE output at full M (ragged last tile included), plus fp64 on sampled
+    rows."""
+    M = FULL_M
+    x = _rnd((M, K), torch.bfloat16, 1.0, 21).cuda()
+    w = _rnd((N, K), torch.float32, 0.05, 22).cuda()
+    b = _rnd((N,), torch.float32, 0.5, 23).cuda() if bias else None
+    auto = ops.linear(x, w, b)
+    monkeypatch.setenv('EGV_PP_FORCE_BM', str(bm))
+    forced = ops.linear(x, w, b)
+    monkeypatch.delenv('EGV_PP_FORCE_BM')
+    assert torch.equal(auto, forced)
+    rows = torch.cat([torch.arange(0, 8), torch.arange(M // 2 + 100, M // 2 + 108), torch.arange(M - 8, M)])
+    z = x[rows.cuda()].double().cpu() @ w.to(torch.bfloat16).double().cpu().t()
+    if b is not None:
+        z = z + b.double().cpu()
+    assert _rel(forced[rows.cuda()], z) < 6e-3
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('fused', [False, True])
 def test_block_entry_points_match_per_op_composition(ops, dtype, fused, monkeypatch):

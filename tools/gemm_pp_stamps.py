@@ -9,7 +9,7 @@ raw = ctypes.CDLL(LIB_PATH)
 raw.egv_debug_timing.argtypes = [ctypes.c_void_p]
 dev = 'cuda'
 np.set_printoptions(linewidth=200)
-for (M, N, K) in [(100368, 2304, 768), (25096, 2304, 768)]:
+for (M, N, K) in [(100368, 2304, 768), (25096, 2304, 768), (25096, 768, 768), (25096, 768, 3072), (25096, 3072, 768)]:
     x = torch.randn(M, K, device=dev).bfloat16(); w = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
     b = torch.randn(N, device=dev); y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     f = lambda: ops.gemm(x, w, y, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=b)
@@ -18,7 +18,7 @@ for (M, N, K) in [(100368, 2304, 768), (25096, 2304, 768)]:
     buf = torch.zeros(256 * 2 * 4 * 16, dtype=torch.int64, device=dev)
     raw.egv_debug_timing(buf.data_ptr()); f(); torch.cuda.synchronize(); raw.egv_debug_timing(None)
     s = buf.cpu().numpy().reshape(256, 2, 4, 16).astype(np.float64)
-    KT = K // 64
+    KT = min(K // 64, 15)          # the kernel stamps the first 16 K-tile boundaries of a tile
     print(f"M={M} N={N} K={K}")
     for g in range(2):
         for ts in range(4):
