@@ -59,6 +59,8 @@ class VBlockDesc(C.Structure):
         ('flags', i32),
         ('wq', vp * 9), ('wq_s', vp * 9), ('wtq', vp * 9), ('wtq_s', vp * 9),
         ('x32', vp), ('out32', vp),
+        ('next_g', vp), ('next_b', vp), ('next_h', vp), ('next_stats', vp),
+        ('fwd_cus', i32),
     ]
 
 
@@ -90,6 +92,8 @@ BLOCK_NO_JOIN = 1
 BLOCK_RES_F32 = 2
 BLOCK_FP8 = 4
 BLOCK_TAIL = 8
+BLOCK_H3_READY = 16
+BLOCK_HEAD = 32
 
 
 # name -> (restype, argtypes); every symbol declared in include/egovlp_hip.h
@@ -155,7 +159,10 @@ PROTOTYPES = {
     'egv_egonce_fwd': (i32, [vp, vp, vp, i32, f32, i32, i32, vp, vp, vp, vp]),
     'egv_egonce_bwd': (i32, [vp, vp, vp, vp, vp, vp, i32, f32, i32, i32, vp]),
     'egv_adamw_step': (i32, [vp, vp, i32, i32, f32, f32, f32, f32, f32, f32, f32, vp]),
+    'egv_vblock_qkv_s_offset': (i64, [C.POINTER(VBlockDesc)]),
+    'egv_vblock_next_slots': (i32, [C.POINTER(VBlockDesc), C.POINTER(i64), C.POINTER(i64)]),
     'egv_vblock_save_bytes': (i64, [C.POINTER(VBlockDesc)]),
+    'egv_vblock_next_slots': (i32, [C.POINTER(VBlockDesc), C.POINTER(i64), C.POINTER(i64)]),
     'egv_vblock_ws_bytes': (i64, [C.POINTER(VBlockDesc), i32]),
     'egv_vblock_fwd': (i32, [C.POINTER(VBlockDesc)]),
     'egv_vblock_bwd': (i32, [C.POINTER(VBlockDesc)]),

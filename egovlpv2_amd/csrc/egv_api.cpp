@@ -43,7 +43,7 @@ const Switch g_switches[] = {
     {"EGV_PP_LIMIT_SLACK", 16, "CUs a persistent grid may take beyond its CU limit when that removes a round of its tile walk"},
     {"EGV_PP_LIMIT_SLACK_FUSED", 0, "the same inside a fused video block's backward call (its weight-gradient launch stays resident: exact limit)"},
     {"EGV_PP_BM192", 1, "192-row tiles where they shorten the walk"},
-    {"EGV_PP_MIXED", 1, "224- / 160- / 128-row tiles (A sub-tiles of different heights) for the plain kinds where they shorten the walk: 1 = grids planned for the whole chip, 2 = also under a CU limit, 0 = off"},
+    {"EGV_PP_MIXED", 0, "224- / 160- / 128-row tiles (A sub-tiles of different heights) for the plain kinds where they shorten the walk: 1 = grids planned for the whole chip, 2 = also under a CU limit, 0 = off (isolated launches gain 2-7 %, the step nothing: profiles/round5_experiments.md section 4)"},
     {"EGV_PP_FORCE_BM", 0, "tests: tile height of the persistent GEMM wherever the epilogue kind is built for it (0: chosen per call)"},
     {"EGV_PP_TILE_C0", 56, "height-independent cost of a tile of the persistent GEMM, in rows (tile cost = rows + this)"},
     {"EGV_PP_TRIM", 1, "grid trimmed to the smallest size that keeps the round count"},

@@ -368,8 +368,10 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_mfma_kernel(const AttnArgs a,
         const bf16x8_t q1 = ld_frag_global(Q + qrow * a.ldq + hq + 32 + fg * 8, qv);
         const bf16x8_t g0 = ld_frag_global(dO + qrow * a.ldo + ho + fg * 8, qv);
         const bf16x8_t g1 = ld_frag_global(dO + qrow * a.ldo + ho + 32 + fg * 8, qv);
-        const bf16x8_t o0 = ld_frag_global(O + qrow * a.ldo + ho + fg * 8, qv);
-        const bf16x8_t o1 = ld_frag_global(O + qrow * a.ldo + ho + 32 + fg * 8, qv);
+        // (O is only read for delta: not at all where delta comes from the probability rows themselves, below)
+        const bool need_o = !(NT == 2 && a.nsplit == 1) && !a.O32;
+        const bf16x8_t o0 = ld_frag_global(O + qrow * a.ldo + ho + fg * 8, qv && need_o);
+        const bf16x8_t o1 = ld_frag_global(O + qrow * a.ldo + ho + 32 + fg * 8, qv && need_o);
         float dl = 0.f;
         if (a.O32) {                                                          // delta from the fp32 values of O (egv_attn_desc::O32)
             const float* o32 = a.O32 + qrow * a.ldo + ho + fg * 8;

@@ -369,7 +369,8 @@ int vgroup_cus(const egv_vblock_desc* d) {
     // layer's backward kernels (a dozen workgroups each, on the text stream) run on -- with 104 or 108 every CU is owned by a
     // persistent workgroup and the text layer, whose gradient the NEXT video block call waits for, only gets CUs between launches
     // (alternating A/B: 73.3 -> 72.2 ms per step).
-    const int ntile = 2 * tD * tH + 2 * tD * tD + 2 * 3 * tD * tD;
+    // (EGV_BLOCK_HEAD: only the two qkv gradients and the time projection's)
+    const int ntile = (d->flags & EGV_BLOCK_HEAD) ? tD * tD + 2 * 3 * tD * tD : 2 * tD * tH + 2 * tD * tD + 2 * 3 * tD * tD;
     int g = ((2 * ntile + 2) / 3 / 8) * 8;                         // a multiple of 8: so is what it leaves the XCD-aware grids of the calling stream
     const int cap = device_cus() / 2;
     return g > cap ? cap : g;
@@ -395,8 +396,11 @@ long long vgroup_ws_bytes(const egv_vblock_desc* d) {
     egv_wgrad_problem pr[8];
     int n = 0;
     auto add = [&](int N, int K) { pr[n] = egv_wgrad_problem{}; pr[n].N = N; pr[n].K = K; ++n; };
-    add(D, Hd); add(Hd, D); add(D, D); add(3 * D, D); add(D, D); add(3 * D, D);
-    if (d->L > 0) { add(D, D); add(D, D); }
+    if (d->flags & EGV_BLOCK_HEAD) { add(3 * D, D); add(D, D); add(3 * D, D); }
+    else {
+        add(D, Hd); add(Hd, D); add(D, D); add(3 * D, D); add(D, D); add(3 * D, D);
+        if (d->L > 0) { add(D, D); add(D, D); }
+    }
     const long long b = egv_gemm_wgrad_grouped_workspace_bytes(M, n, pr, vgroup_cus(d));
     const long long b0 = egv_gemm_wgrad_grouped_workspace_bytes(M, n, pr, (device_cus() * 7) / 8);     // single-stream mode
     return b > b0 ? b : (b0 > 0 ? b0 : 0);
@@ -405,6 +409,14 @@ long long vgroup_ws_bytes(const egv_vblock_desc* d) {
 }  // namespace
 
 extern "C" long long egv_vblock_save_bytes(const egv_vblock_desc* d) { return (long long)vlayout(d).total; }
+extern "C" long long egv_vblock_qkv_s_offset(const egv_vblock_desc* d) { return d ? (long long)vlayout(d).qkv_s : -1; }
+extern "C" int egv_vblock_next_slots(const egv_vblock_desc* d, long long* stats3_off, long long* h3_off) {
+    if (!d || !stats3_off || !h3_off) { egv_set_error("egv_vblock_next_slots: null argument"); return -1; }
+    const VLayout L = vlayout(d);
+    *stats3_off = (long long)L.stats3;
+    *h3_off = (long long)L.h3;
+    return 0;
+}
 
 extern "C" long long egv_vblock_ws_bytes(const egv_vblock_desc* d, int backward) {
     const size_t es = esz(d->dtype);
@@ -439,7 +451,9 @@ extern "C" int egv_vblock_fwd(const egv_vblock_desc* d) {
     const int dt = d->dtype;
     const int S = 1 + d->F * d->N, M = d->B * S, D = d->D, Hd = d->Hd;
     const bool fused = d->L > 0;
-    if (!(d->x && d->out && d->save && d->ws)) { egv_set_error("egv_vblock_fwd: null buffer"); return -1; }
+    const bool head = (d->flags & EGV_BLOCK_HEAD) != 0;             // stop after the space attention's qkv projection (its slot of `save` is the result)
+    if (!(d->x && (d->out || head) && d->save && d->ws)) { egv_set_error("egv_vblock_fwd: null buffer"); return -1; }
+    if (head && !(d->flags & EGV_BLOCK_RES_F32)) { egv_set_error("egv_vblock_fwd: EGV_BLOCK_HEAD is built for the fp32 residual stream form"); return -1; }
     const VLayout L = vlayout(d);
     if ((long long)L.total > d->save_bytes) { egv_set_error("egv_vblock_fwd: save buffer too small"); return -1; }
     char* sv = (char*)d->save;
@@ -459,6 +473,7 @@ extern "C" int egv_vblock_fwd(const egv_vblock_desc* d) {
         f8.s2 = ws.take((size_t)egv_mx_scale_bytes(M, Hd, 0));
     }
     if (!ws.ok()) { egv_set_error("egv_vblock_fwd: workspace too small"); return -1; }
+    CuLimit fwd_limit(d->fwd_cus > 0 && d->fwd_cus < device_cus() ? d->fwd_cus : 0, 0);   // (exact: the rest of the chip belongs to the other chain)
     static const bool epi_q = egv_cfg_on("EGV_MX_EPI_QUANT", true);
     const bool mlp_chain = epi_q && f8.on && d->wq[VW_FC1] && d->wq_s[VW_FC1] && d->wq[VW_FC2] && d->wq_s[VW_FC2];
     // one Linear over the M video tokens: MX-fp8 when the desc carries the quantised weight, bf16 otherwise
@@ -486,7 +501,7 @@ extern "C" int egv_vblock_fwd(const egv_vblock_desc* d) {
         // exact), d->out32 receives the fp32 output; d->x / d->out / the saved tr, sr are their bf16 roundings -- the backward pass
         // reads those and is unchanged.  The Linears run WITHOUT their residual epilogues; every sum is formed by the kernel that
         // normalises it (egv_sum_layernorm) from the fp32 base and the bf16 Linear outputs.
-        if (dt != EGV_BF16 || f8.on || !d->out32) {
+        if (dt != EGV_BF16 || f8.on || (!d->out32 && !head)) {
             egv_set_error("egv_vblock_fwd: EGV_BLOCK_RES_F32 needs a bf16 block without MX-fp8 operands and an out32 buffer");
             return -1;
         }
@@ -497,12 +512,14 @@ extern "C" int egv_vblock_fwd(const egv_vblock_desc* d) {
             return egv_sum_layernorm(x32, x32 ? nullptr : d->x, d1, d2, dg, dg ? d->alpha : nullptr, s32, s16, y, y ? d->ln_g[ln] : nullptr,
                                      y ? d->ln_b[ln] : nullptr, stats, M, D, d->eps, st);
         };
-        BCHK(sumln(nullptr, nullptr, nullptr, nullptr, nullptr, sv + L.h3, VL_NORM3, (float*)(sv + L.stats3)));
+        if (!(d->flags & EGV_BLOCK_H3_READY))                     // (else the previous block's output pass left norm3(x) and its statistics in place)
+            BCHK(sumln(nullptr, nullptr, nullptr, nullptr, nullptr, sv + L.h3, VL_NORM3, (float*)(sv + L.stats3)));
         BCHK(lin(VW_TQKV, 3 * D, D, sv + L.h3, sv + L.qkv_t, 0, nullptr, nullptr));
         BCHK(dvt.fwd(sv + L.qkv_t, sv + L.tctx, (float*)(sv + L.lse_t), aws, awb, st));
         BCHK(lin(VW_TPROJ, D, D, sv + L.tctx, sv + L.tr, 0, nullptr, nullptr));                    // the projection, then tr = x + it in place
         BCHK(sumln(sv + L.tr, nullptr, nullptr, nullptr, sv + L.tr, sv + L.h1, VL_NORM1, (float*)(sv + L.stats1)));
         BCHK(lin(VW_SQKV, 3 * D, D, sv + L.h1, sv + L.qkv_s, 0, nullptr, nullptr));
+        if (head) return 0;                                        // the caller goes on with the CLS query alone (model.py: _video_block_tail)
         BCHK(dvs.fwd(sv + L.qkv_s, sv + L.sctx, (float*)(sv + L.lse_s), aws, awb, st));
         const void *a1, *ag = nullptr;                                                             // sr = x + a1 (+ alpha * ag)
         if (!fused) {
@@ -520,7 +537,10 @@ extern "C" int egv_vblock_fwd(const egv_vblock_desc* d) {
         BCHK(sumln(a1, nullptr, ag, nullptr, sv + L.sr, sv + L.h2, VL_NORM2, (float*)(sv + L.stats2)));
         BCHK(lin(VW_FC1, Hd, D, sv + L.h2, sv + L.act, mlp_act(dt), nullptr, sv + L.pre));
         BCHK(lin(VW_FC2, D, Hd, sv + L.act, d->out, 0, nullptr, nullptr));                         // the MLP's output, then out = sr + it in place
-        return sumln(a1, d->out, ag, d->out32, d->out, nullptr, 0, nullptr);
+        // the block's output sum, in fp32 and bf16 -- and, when the caller names the next block's norm3 and save slots, that LayerNorm too
+        const bool fold = d->next_h && d->next_g && d->next_b && d->next_stats;
+        return egv_sum_layernorm(x32, x32 ? nullptr : d->x, a1, d->out, ag, ag ? d->alpha : nullptr, d->out32, d->out, fold ? d->next_h : nullptr,
+                                 fold ? d->next_g : nullptr, fold ? d->next_b : nullptr, fold ? d->next_stats : nullptr, M, D, d->eps, st);
     }
     // temporal attention (video_transformer.py:217-218): x + proj(attn(qkv(norm3 x)))
     BCHK(ln_lin(VL_NORM3, d->x, sv + L.h3, (float*)(sv + L.stats3), VW_TQKV, 3 * D, D, sv + L.qkv_t, 0, nullptr));
@@ -560,6 +580,7 @@ extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
     const int S = 1 + d->F * d->N, M = d->B * S, D = d->D, Hd = d->Hd, H = d->H;
     const bool fused = d->L > 0;
     if (!(d->x && d->dout && d->dx && d->save && d->ws)) { egv_set_error("egv_vblock_bwd: null buffer"); return -1; }
+    const bool head = (d->flags & EGV_BLOCK_HEAD) != 0;             // dout = the gradient of the space attention's qkv [M, 3D]; the call starts there
     const VLayout L = vlayout(d);
     const char* sv = (const char*)d->save;
     void* st = d->stream;
@@ -585,6 +606,7 @@ extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
     void* d_sr = ws.take((size_t)M * D * es);
     void* d_sctx = ws.take((size_t)M * D * es);
     void* dqkv_s = ws.take((size_t)M * 3 * D * es);
+    if (head) dqkv_s = const_cast<void*>(d->dout);
     void* dh1 = ws.take((size_t)M * D * es);
     void* d_tr = ws.take((size_t)M * D * es);
     void* d_tctx = ws.take((size_t)M * D * es);
@@ -644,6 +666,7 @@ extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
         return lin_wgrad(dt, rows, N, K, dz, N, x, d->dw[w], d->db[w], gate, wgw, wgb, fk.begin());
     };
 
+    if (!head) {
     // ---- MLP: out = sr + fc2(gelu(pre)), pre = fc1(h2)
     BCHK(wgrad(D, Hd, d->dout, sv + L.act, VW_FC2, nullptr, M));
     if (mlp_chain) {
@@ -685,6 +708,7 @@ extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
     BCHK(wgrad(D, D, d_sproj_out, sv + L.sctx, VW_SPROJ, nullptr, M));
     BCHK(dgrad(VW_SPROJ, D, D, d_sproj_out, d_sctx, nullptr, 0));
     BCHK(dvs.bwd(sv + L.qkv_s, sv + L.sctx, (float*)const_cast<char*>(sv + L.lse_s), d_sctx, dqkv_s, delta_s, aws, awb, st));
+    }   // !head
     BCHK(wgrad(3 * D, D, dqkv_s, sv + L.h1, VW_SQKV, nullptr, M));
     BCHK(dgrad(VW_SQKV, 3 * D, D, dqkv_s, dh1, nullptr, 0));
     BCHK(egv_layernorm_bwd2(dt, dh1, sv + L.tr, (const float*)(sv + L.stats1), d->ln_g[VL_NORM1], nullptr, nullptr, d_tr, d->dln_g[VL_NORM1],
@@ -696,7 +720,8 @@ extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
     BCHK(wgrad(3 * D, D, dqkv_t, sv + L.h3, VW_TQKV, nullptr, M));
     BCHK(dgrad(VW_TQKV, 3 * D, D, dqkv_t, dh3, nullptr, 0));
     // dx = LN3'(dh3) + d_sr + d_tr: x feeds norm3, the time residual and the space residual
-    BCHK(egv_layernorm_bwd2(dt, dh3, d->x, (const float*)(sv + L.stats3), d->ln_g[VL_NORM3], d_sr, d_tr, d->dx, d->dln_g[VL_NORM3],
+    // (EGV_BLOCK_HEAD: the space residual's gradient reaches x through the caller's own graph, not through this call)
+    BCHK(egv_layernorm_bwd2(dt, dh3, d->x, (const float*)(sv + L.stats3), d->ln_g[VL_NORM3], head ? nullptr : d_sr, d_tr, d->dx, d->dln_g[VL_NORM3],
                             d->dln_b[VL_NORM3], M, D, lnw, st));
     const bool tail = side_group && (d->flags & EGV_BLOCK_TAIL);      // no data-gradient chain follows: the launch may have the chip
     if (ngrp) BCHK(egv_gemm_wgrad_grouped(dt, M, ngrp, grp, (side_group && !tail) ? vgroup_cus(d) : (device_cus() * 7) / 8, wgw, wgb, fk.begin()));

@@ -759,7 +759,7 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
     // fixed epilogue work: 56 rows' worth, from the measured 6 % penalty of 192- against 256-row tiles).  Built: plain kinds 256 / 224 /
     // 192 / 160 / 128 rows; residual kinds 256 / 192; gated two-residual 192; the GELU kinds 256 only.
     static const bool allow192 = egv_cfg_on("EGV_PP_BM192", true);
-    static const int mixed_mode = egv_cfg_int("EGV_PP_MIXED", 1);   // 224- / 160- / 128-row tiles (round 5): 1 = grids that plan for the whole chip, 2 = also under a CU limit
+    static const int mixed_mode = egv_cfg_int("EGV_PP_MIXED", 0);   // 224- / 160- / 128-row tiles (round 5): 1 = grids that plan for the whole chip, 2 = also under a CU limit
     const bool allow_mixed = mixed_mode >= 2 || (mixed_mode == 1 && !(g_cu_limit > 0 && g_cu_limit < ncu_all));
     static const double c0 = egv_cfg_f64("EGV_PP_TILE_C0", 56.0);
     const bool kind192 = !e.dact && (!e.pre || e.res2) && !e.act && !stamps;

@@ -1147,6 +1147,14 @@ def _defer_side(params):
     return None if st is None else (st, cur)
 
 
+# CUs the persistent GEMMs of a forward video block call plan for (0: all): set while two block chains run on two streams
+_fwd_cus = [0]
+
+
+def set_forward_cu_limit(n: int):
+    _fwd_cus[0] = int(n)
+
+
 class VideoBlockFn(Function):
     """SpaceTimeBlock.forward (video_transformer.py:214-228).  params = [W, b] x 6 (timeattn.qkv, timeattn.proj, attn.qkv,
     attn.proj, mlp.fc1, mlp.fc2), [gamma, beta] x 3 (norm3, norm1, norm2) and, for a fused block, [W, b] x 3 (qkv_text_i2t,
@@ -1179,6 +1187,7 @@ class VideoBlockFn(Function):
             d.alpha = _p(params[26])
             d.y, d.y_mask = _p(y), _p(y_mask)
         d.stream = _st()
+        d.fwd_cus = _fwd_cus[0]
         return d
 
     @staticmethod
@@ -1195,7 +1204,24 @@ class VideoBlockFn(Function):
             d.flags |= L.BLOCK_RES_F32
             d.x32, d.out32 = _p(x32), _p(out32)
         nsave = lib.egv_vblock_save_bytes(C.byref(d))
-        save = torch.empty(nsave, dtype=torch.uint8, device=x.device)
+        pre_save, nxt = (cfg[11], cfg[12]) if res32 else (None, None)
+        if pre_save is not None and pre_save.numel() == nsave:
+            # the previous block's output pass already left norm3(x) and its statistics in this call's save buffer (LayerNorm fold)
+            save = pre_save
+            d.flags |= L.BLOCK_H3_READY
+        else:
+            save = torch.empty(nsave, dtype=torch.uint8, device=x.device)
+        next_save = None
+        if nxt is not None:
+            # fold the NEXT block's first LayerNorm into this call's output pass: it is written into the save buffer the next call will use
+            g_n, b_n, L_n = nxt
+            dn = L.VBlockDesc()
+            dn.dtype, dn.B, dn.F, dn.N, dn.H, dn.D, dn.Hd, dn.L, dn.eps = d.dtype, d.B, d.F, d.N, d.H, d.D, d.Hd, L_n, d.eps
+            so, ho = L.i64(0), L.i64(0)
+            check(lib.egv_vblock_next_slots(C.byref(dn), C.byref(so), C.byref(ho)), 'egv_vblock_next_slots')
+            next_save = torch.empty(lib.egv_vblock_save_bytes(C.byref(dn)), dtype=torch.uint8, device=x.device)
+            d.next_g, d.next_b = _p(g_n), _p(b_n)
+            d.next_h, d.next_stats = next_save.data_ptr() + ho.value, next_save.data_ptr() + so.value
         ws = workspace(lib.egv_vblock_ws_bytes(C.byref(d), 0), x.device, slot=2)
         d.out, d.save, d.save_bytes, d.ws, d.ws_bytes = _p(out), _p(save), nsave, _p(ws), ws.numel()
         check(lib.egv_vblock_fwd(C.byref(d)), 'egv_vblock_fwd')
@@ -1207,9 +1233,11 @@ class VideoBlockFn(Function):
         _acc_forward(ctx.key, cfg[7], cfg[6] > 0)
         ctx.save_for_backward(x, y, y_mask, save, *params)
         if res32:
-            ctx.mark_non_differentiable(out32)
+            if next_save is None:
+                next_save = torch.empty(0, dtype=torch.uint8, device=x.device)
+            ctx.mark_non_differentiable(out32, next_save)
             ctx.set_materialize_grads(False)             # (no 77 MB zero gradient for out32 in every backward call)
-            return out, out32
+            return out, out32, next_save
         return out
 
     @staticmethod
@@ -1255,6 +1283,145 @@ class VideoBlockFn(Function):
         return (None, dx, dy, None, *_acc_backward(ctx.key, gp, params, 18, side))
 
 
+class VideoHeadFn(Function):
+    """The part of a SpaceTimeBlock every output row depends on -- norm3, time attention + projection + residual, norm1 and the space
+    attention's qkv projection (video_transformer.py:217-219, :120) -- as one C call per direction (EGV_BLOCK_HEAD), for a block whose
+    output is read at the CLS rows only.  Returns qkv_s [M, 3D] (a view of the call's save buffer).  params = [W, b] of timeattn.qkv,
+    timeattn.proj, attn.qkv, then [gamma, beta] of norm3, norm1.  Gradients go to autograd tensor by tensor (two such calls per step)."""
+
+    @staticmethod
+    def _desc(cfg, x, params):
+        B, Fr, N, H, Hd, eps = cfg[:6]
+        d = L.VBlockDesc()
+        d.dtype, d.B, d.F, d.N, d.H, d.D, d.Hd, d.L, d.eps = _dt(x), B, Fr, N, H, x.shape[1], Hd, 0, eps
+        d.x = _p(x)
+        _fill_weights(d, [params[0], params[2], params[4]], x.dtype)   # weight slots 0..2: timeattn.qkv, timeattn.proj, attn.qkv
+        d.b[0], d.b[1], d.b[2] = _p(params[1]), _p(params[3]), _p(params[5])
+        d.ln_g[0], d.ln_b[0] = _p(params[6]), _p(params[7])        # norm3
+        d.ln_g[1], d.ln_b[1] = _p(params[8]), _p(params[9])        # norm1
+        d.flags = L.BLOCK_RES_F32 | L.BLOCK_HEAD
+        d.stream = _st()
+        return d
+
+    @staticmethod
+    def forward(ctx, cfg, x, *params):
+        _need_gpu(x)
+        assert x.dim() == 2 and x.is_contiguous() and x.dtype == torch.bfloat16
+        d = VideoHeadFn._desc(cfg, x, params)
+        x32, pre_save = cfg[6], cfg[7]
+        d.x32 = _p(x32)
+        nsave = lib.egv_vblock_save_bytes(C.byref(d))
+        if pre_save is not None and pre_save.numel() == nsave:
+            save = pre_save
+            d.flags |= L.BLOCK_H3_READY
+        else:
+            save = torch.empty(nsave, dtype=torch.uint8, device=x.device)
+        ws = workspace(lib.egv_vblock_ws_bytes(C.byref(d), 0), x.device, slot=2)
+        d.save, d.save_bytes, d.ws, d.ws_bytes = _p(save), nsave, _p(ws), ws.numel()
+        check(lib.egv_vblock_fwd(C.byref(d)), 'egv_vblock_fwd(head)')
+        off = lib.egv_vblock_qkv_s_offset(C.byref(d))
+        M, D = x.shape
+        qkv = save[off:off + M * 3 * D * 2].view(torch.bfloat16).view(M, 3 * D)
+        ctx.cfg = cfg[:6]
+        ctx.key = ('vh', id(params[0]))
+        _acc_forward(ctx.key, cfg[8], False)
+        ctx.save_for_backward(x, save, *params)
+        return qkv
+
+    @staticmethod
+    def backward(ctx, dqkv):
+        x, save, *params = ctx.saved_tensors
+        d = VideoHeadFn._desc(ctx.cfg, x, params)
+        dqkv = dqkv.contiguous()
+        dx = torch.empty_like(x)
+        gp = _GradPack(params, x.device)
+        nwsb = lib.egv_vblock_ws_bytes(C.byref(d), 1)
+        ws = torch.empty(nwsb, dtype=torch.uint8, device=x.device)
+        d.save, d.save_bytes, d.ws, d.ws_bytes = _p(save), save.numel(), _p(ws), nwsb
+        d.dout, d.dx = _p(dqkv), _p(dx)
+        g = gp.views
+        for i in range(3):
+            d.dw[i], d.db[i] = _p(g[2 * i]), _p(g[2 * i + 1])
+        d.dln_g[0], d.dln_b[0] = _p(g[6]), _p(g[7])
+        d.dln_g[1], d.dln_b[1] = _p(g[8]), _p(g[9])
+        d.stream2 = _side_stream_ptr()
+        side = _defer_side(params) if (d.stream2 and lib.egv_vblock_bwd_defers(C.byref(d))) else None
+        if side is not None:                                 # as VideoBlockFn.backward: the grouped launch outlives the call
+            d.flags |= L.BLOCK_NO_JOIN
+            for t in (ws, save, dqkv, gp.flat):
+                t.record_stream(side[0])
+            _deferred['sides'][side[0].cuda_stream] = side
+            _queue_done()
+        check(lib.egv_vblock_bwd(C.byref(d)), 'egv_vblock_bwd(head)')
+        return (None, dx, *_acc_backward(ctx.key, gp, params, len(params), side))
+
+
+def video_block_head(x, params, B, Fr, N, H, Hd, eps):
+    """params: the 10 tensors VideoHeadFn lists; x carries its fp32 value (`._res32`) and, possibly, a folded norm3 (`._pre_save`)"""
+    pre = None
+    ps = x.__dict__.pop('_pre_save', None)
+    if ps is not None and ps[1] == id(params[6]):
+        pre = ps[0]
+    return VideoHeadFn.apply((B, Fr, N, H, Hd, float(eps), stream32(x), pre, _tracks_grad(params)), x, *params)
+
+
+class ClsAttnFn(Function):
+    """The CLS query of a divided space attention alone: softmax(q_cls K^T / 8) V over ALL S keys of its sample (video_transformer.py:129),
+    straight from the fused qkv matrix [B*S, 3D] -> [B, D].  Forward / backward are the text -> image attention's launches (one query row
+    per sample instead of 32; delta from the fp32 output, egv_attn_desc::O32); the backward writes the whole dqkv matrix: dK | dV of
+    every row, dQ of the CLS rows, zeros in the other rows' dQ."""
+
+    @staticmethod
+    def _views(qkv, B, S, D):
+        q = qkv.view(B, S * 3 * D)[:, :D]                      # row b = the CLS row of sample b (row pitch S * 3D)
+        return q, qkv[:, D:2 * D], qkv[:, 2 * D:]
+
+    @staticmethod
+    def forward(ctx, qkv, B, S, H):
+        _need_gpu(qkv)
+        D = H * 64
+        assert qkv.shape == (B * S, 3 * D) and qkv.is_contiguous()
+        q, k, v = ClsAttnFn._views(qkv, B, S, D)
+        O = torch.empty(B, D, dtype=qkv.dtype, device=qkv.device)
+        O32 = torch.empty(B, D, dtype=torch.float32, device=qkv.device) if qkv.dtype == torch.bfloat16 else None
+        lse = torch.empty(B, H, dtype=torch.float32, device=qkv.device)
+        ns = 1 if S <= 224 else (S + 223) // 224
+        ws, nb = _split_ws(0, B, 1, H, 1, ns, qkv.device)
+        d = _mk_desc(q, k, v, O, lse, B, 1, H, _rowset(1, 0, 0, 1, 1), _rowset(S, 0, 0, 1, S), None, 0.125, nsplit=ns, ws=ws, ws_bytes=nb)
+        d.O32 = _p(O32)
+        check(lib.egv_attn_fwd(_dt(qkv), C.byref(d), _st()), 'egv_attn_fwd(cls only)')
+        ctx.cfg = (B, S, H)
+        ctx.save_for_backward(qkv, O, O32, lse)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        qkv, O, O32, lse = ctx.saved_tensors
+        B, S, H = ctx.cfg
+        D = H * 64
+        dO = dO.contiguous()
+        q, k, v = ClsAttnFn._views(qkv, B, S, D)
+        dqkv = torch.empty_like(qkv)
+        dqkv[:, :D].zero_()                                    # (the other rows' queries took no part)
+        dq, dk, dv = ClsAttnFn._views(dqkv, B, S, D)
+        delta = torch.empty(B, H, dtype=torch.float32, device=qkv.device)
+        qs, ks = _rowset(1, 0, 0, 1, 1), _rowset(S, 0, 0, 1, S)
+        kw = dict(dO=dO, dQ=dq, dK=dk, dV=dv, delta=delta)
+        ns = 1 if S <= 224 else (S + 223) // 224
+        ws, nb = _split_ws(1, B, 1, H, 1, ns, qkv.device)
+        d = _mk_desc(q, k, v, O, lse, B, 1, H, qs, ks, None, 0.125, nsplit=ns, ws=ws, ws_bytes=nb, **kw)
+        d.O32 = _p(O32)
+        check(lib.egv_attn_bwd_dq(_dt(qkv), C.byref(d), _st()), 'egv_attn_bwd_dq(cls only)')
+        ws, nb = _dkv_ws(B, 1, H, S, 1, qkv.device)
+        d = _mk_desc(q, k, v, O, lse, B, 1, H, qs, ks, None, 0.125, nsplit=1, ws=ws, ws_bytes=nb, **kw)
+        check(lib.egv_attn_bwd_dkv(_dt(qkv), C.byref(d), _st()), 'egv_attn_bwd_dkv(cls only)')
+        return dqkv, None, None, None
+
+
+def cls_attention(qkv, B, S, H):
+    return ClsAttnFn.apply(qkv, B, S, H)
+
+
 class StreamRowsFn(Function):
     """first row of every sample of a video residual-stream tensor, read from its fp32 value x32; the gradient goes to x (the
     bf16 tensor autograd tracks), exactly as for x.reshape(B, rows, -1)[:, 0]"""
@@ -1286,17 +1453,30 @@ def stream32(x):
     return getattr(x, '_res32', None)
 
 
-def video_block(x, params, B, Fr, N, H, Hd, eps, y=None, y_mask=None, L=0, fp8=False):
+def video_block(x, params, B, Fr, N, H, Hd, eps, y=None, y_mask=None, L=0, fp8=False, next_ln=None):
     """fp8: the forward / dgrad GEMMs over the video tokens on MX-fp8 operands (bf16 mode only; BASELINE.json configs[4]).
     With EGV_VIDEO_RES32 (bf16 mode) the residual stream is fp32, as under the reference's autocast (trainer_egoclip.py:143): the
     returned bf16 tensor -- the one autograd sees, GEMMs read and the backward pass uses -- carries its fp32 value as `._res32`,
-    which the next block (and the final LayerNorm) picks up."""
+    which the next block (and the final LayerNorm) picks up.
+    next_ln = (gamma, beta, L_next) of the block that will consume the result (its norm3, and whether it is a fused block over L_next
+    text tokens): this call's output pass then also writes that LayerNorm into the save buffer of the next call, which travels with
+    the result as `._pre_save` and is taken by the FIRST video_block call on it (EGV_LN_FOLD; a second consumer normalises itself)."""
     res32 = video_res32(x, fp8)
-    cfg = (B, Fr, N, H, Hd, float(eps), L if y is not None else 0, _tracks_grad(params), bool(fp8), res32, stream32(x) if res32 else None)
+    pre = None
+    if res32:
+        ps = x.__dict__.pop('_pre_save', None)
+        if ps is not None and ps[1] == id(params[12]):
+            pre = ps[0]
+        if next_ln is not None and not SW.on('EGV_LN_FOLD'):
+            next_ln = None
+    cfg = (B, Fr, N, H, Hd, float(eps), L if y is not None else 0, _tracks_grad(params), bool(fp8), res32, stream32(x) if res32 else None,
+           pre, next_ln if res32 else None)
     if not res32:
         return VideoBlockFn.apply(cfg, x, y, y_mask, *params)
-    out, out32 = VideoBlockFn.apply(cfg, x, y, y_mask, *params)
+    out, out32, nsv = VideoBlockFn.apply(cfg, x, y, y_mask, *params)
     out._res32 = out32
+    if nsv.numel():
+        out._pre_save = (nsv, id(next_ln[0]))
     return out
 
 

@@ -90,6 +90,21 @@ def _init_tensor(name: str, shape, gen: torch.Generator, cfg: PathConfig) -> tor
     return t
 
 
+def _gather_clips(plan, rows, sources, dtype=None):
+    """out clip i = sources[plan[i][0]] clip plan[i][1] of flat (clips * rows, d) matrices: ONE gather over the clip axis when every clip
+    comes from the first source (one rank, or no negative drawn from another rank), else one copy per clip"""
+    src0 = sources[0]
+    d = src0.shape[1]
+    dtype = dtype or src0.dtype
+    if all(w == 0 for w, _ in plan) and src0.dtype == dtype:
+        idx = torch.tensor([j for _, j in plan], dtype=torch.int64).to(src0.device, non_blocking=True)
+        return src0.reshape(-1, rows, d).index_select(0, idx).reshape(len(plan) * rows, d)
+    out = torch.empty(len(plan) * rows, d, dtype=dtype, device=src0.device)
+    for i, (w, j) in enumerate(plan):
+        out[i * rows:(i + 1) * rows].copy_(sources[w][j * rows:(j + 1) * rows])
+    return out
+
+
 class SelectClipsFn(torch.autograd.Function):
     """out clip i = sources[plan[i][0]] clip plan[i][1] on flat (clips * rows_per_clip, d) token matrices.  The plan lives on
     the host (the ITM negatives are drawn there), so forward is one copy per clip and backward adds each clip's gradient
@@ -98,9 +113,7 @@ class SelectClipsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan, rows, *sources):
         d = sources[0].shape[1]
-        out = torch.empty(len(plan) * rows, d, dtype=sources[0].dtype, device=sources[0].device)
-        for i, (w, j) in enumerate(plan):
-            out[i * rows:(i + 1) * rows].copy_(sources[w][j * rows:(j + 1) * rows])
+        out = _gather_clips(plan, rows, sources)
         ctx.plan, ctx.rows = plan, rows
         ctx.shapes = [None if s is None else s.shape for s in sources]
         return out
@@ -380,12 +393,54 @@ class FrozenInTime(nn.Module):
             lst = cache[key] = [self.p(n) for n in names]
         return lst
 
-    def _video_block(self, x, i, B, y=None, y_mask=None, L=0):
+    def _video_block(self, x, i, B, y=None, y_mask=None, L=0, next_block=None):
         """SpaceTimeBlock.forward (video_transformer.py:214-228) on the flat (B*S, d) token matrix: one C-ABI call forward, one
-        backward (csrc/egv_block.cpp)."""
+        backward (csrc/egv_block.cpp).  next_block = (index, L_next) of the block that consumes the result next (L_next > 0: a fused
+        block over L_next text tokens): its first LayerNorm is folded into this call's output pass (ops.video_block, EGV_LN_FOLD)."""
         c = self.cfg
+        next_ln = None
+        if next_block is not None and next_block[0] < c.depth:
+            pn = self._block_params('video', next_block[0], next_block[1] > 0)
+            next_ln = (pn[12], pn[13], next_block[1])                       # norm3 weight / bias of the next block
         return ops.video_block(x, self._block_params('video', i, y is not None), B, c.frames, c.n_patches, c.heads, c.dim * c.mlp_ratio,
-                               c.eps_video, y=y, y_mask=y_mask, L=L, fp8=bool(self.__dict__.get('_mx_weights')))
+                               c.eps_video, y=y, y_mask=y_mask, L=L, fp8=bool(self.__dict__.get('_mx_weights')), next_ln=next_ln)
+
+    def _tail_ok(self, x):
+        """may the LAST block of a video pass run in its CLS-only form (_video_block_tail)?  bf16 storage with the fp32 residual stream,
+        no MX-fp8 operands (EGV_CLS_TAIL=0 runs the full block)"""
+        return (SW.on('EGV_CLS_TAIL') and x.dtype == torch.bfloat16 and ops.video_res32(x, bool(self.__dict__.get('_mx_weights')))
+                and self.cfg.dim % 256 == 0)
+
+    def _video_block_tail(self, x, i, B, y=None, y_mask=None, L=0):
+        """SpaceTimeBlock.forward (video_transformer.py:214-228) of a block whose output is only ever read at its CLS rows -- the last
+        block of the video tower (forward_features returns x[:, 0], :392-394) and of the fused stack (self.norm(v)[:, 0], model.py:275).
+        Every output row of a block depends on ALL rows through the space attention's keys and values, i.e. on norm3, the time attention
+        with its projection and residual, norm1 and the K | V part of attn.qkv over all rows (one C call: ops.video_block_head); but
+        the space attention's query, attn.proj, the image-to-text part, norm2 and the MLP act row by row, so for the CLS rows they run
+        on B rows instead of B*S -- 66 % of the block's matrix work (and the gradients of the same share: they are exactly zero for
+        the rows nobody reads) is never issued.  Returns the fp32 CLS rows (B, D), tagged for _video_out_norm."""
+        c = self.cfg
+        fused = y is not None
+        p = self._block_params('video', i, fused)
+        pfx = f'video_model.blocks.{i}'
+        D = c.dim
+        x32 = ops.stream32(x)
+        qkv = ops.video_block_head(x, [p[0], p[1], p[2], p[3], p[4], p[5], p[12], p[13], p[14], p[15]], B, c.frames, c.n_patches, c.heads,
+                                   c.dim * c.mlp_ratio, c.eps_video)
+        ctx = ops.cls_attention(qkv, B, c.seq, c.heads)                                   # the CLS query over all S keys (:129)
+        xc = ops.stream_rows(x, x32, B, c.seq) if x32 is not None else self._cls_rows(x, B, c.seq).float()
+        s = self._lin(ctx, pfx + '.attn.proj')                                            # (B, D)
+        sr = xc + s.float()                                                               # residual from x, not from the time residual (:222)
+        if fused:
+            a = pfx + '.attn'                                                             # image-to-text cross attention (:155-185)
+            kv = self._lin(y, a + '.qkv_text_i2t')
+            q = self._lin(self._ln(s, a + '.norm_i2t_i', c.eps_video), a + '.qkv_i2t')
+            o = ops.plain_attention(q, kv[:, :D], kv[:, D:], B, c.heads, 1, L, 0.125, mask=y_mask)
+            sr = sr + self.p(a + '.alpha_i2t') * self._lin(o, a + '.proj_i2t').float()
+        h2 = ops.CastFn.apply(self._ln(sr, pfx + '.norm2', c.eps_video), self.compute_dtype)
+        out = sr + self._lin(self._lin(h2, pfx + '.mlp.fc1', act='gelu'), pfx + '.mlp.fc2').float()
+        out._cls_rows32 = True
+        return out
 
     def _cls_rows(self, x, B, rows_per_sample):
         return x.reshape(B, rows_per_sample, -1)[:, 0].contiguous()
@@ -394,6 +449,8 @@ class FrozenInTime(nn.Module):
         """LayerNorm of the CLS rows of the video stream (video_model.norm, video_transformer.py:392-394; self.norm, model.py:275).
         With the fp32 residual stream (ops.video_block under EGV_VIDEO_RES32) the rows come from the stream's fp32 value and the
         LayerNorm runs in fp32, as under the reference's autocast; its result is the next Linear's operand either way."""
+        if getattr(x, '_cls_rows32', False):                                # the CLS-only last block hands over the fp32 CLS rows themselves
+            return ops.CastFn.apply(self._ln(x, prefix, eps), self.compute_dtype)
         x32 = ops.stream32(x)
         if x32 is None:
             return self._ln(self._cls_rows(x, B, self.cfg.seq), prefix, eps)
@@ -504,21 +561,25 @@ class FrozenInTime(nn.Module):
         self._prepare_weights()          # (a no-op when the step's copies exist: direct compute_video / Feature_Extraction calls find them too)
         B = video_data.shape[0]
         x = self._patch_tokens(video_data, 'video_model.cls_token')
-        for i in range(self.cfg.depth):
-            x = self._video_block(x, i, B)
+        last = self.cfg.depth - 1
+        for i in range(last):
+            x = self._video_block(x, i, B, next_block=(i + 1, 0))
+        x = self._video_block_tail(x, last, B) if self._tail_ok(x) else self._video_block(x, last, B)
         return self._video_out_norm(x, B, 'video_model.norm', self.cfg.eps_video)
 
     def compute_video(self, video_data):
         """model.py:524-530: SpaceTimeTransformer.forward_features (video_model.cls_token / video_model.norm) -> vid_proj."""
         return self._proj_mlp(self._video_features(video_data), 'vid_proj')
 
-    def _video_prefix(self, video):
+    def _video_prefix(self, video, next_L=0):
         """model.py:211-243 video side: model-level cls_token, pos/temporal embedding and the depth - n_fuse unfused blocks.
-        Depends on the pixels only (no dropout, no text), which is what lets forward() share it between MLM and ITM."""
+        Depends on the pixels only (no dropout, no text), which is what lets forward() share it between MLM and ITM.
+        next_L: text length of the fused stack that consumes the prefix (its first block's LayerNorm rides in the last prefix block)."""
         B = video.shape[0]
+        n_plain = self.cfg.depth - self.cfg.n_fuse
         v = self._patch_tokens(video, 'cls_token')
-        for i in range(self.cfg.depth - self.cfg.n_fuse):
-            v = self._video_block(v, i, B)
+        for i in range(n_plain):
+            v = self._video_block(v, i, B, next_block=(i + 1, next_L if i + 1 == n_plain else 0))
         return v
 
     def _text_prefix(self, input_ids, attention_mask):
@@ -544,7 +605,7 @@ class FrozenInTime(nn.Module):
         if text_prefix is None:
             text_prefix = self._fork_text(lambda: self._text_prefix(input_ids, attention_mask), uses=(input_ids, attention_mask))
         (t, mask), join = text_prefix
-        v = self._video_prefix(video) if video_prefix is None else video_prefix
+        v = self._video_prefix(video, next_L=L) if video_prefix is None else video_prefix
         join()
         overlap = self._overlap()
         for i in range(n_plain, c.depth):
@@ -554,7 +615,14 @@ class FrozenInTime(nn.Module):
                 ev = torch.cuda.Event()
                 ev.record()                                                   # v (and t, joined above) are ready here
             t_new, join = self._fork_text(lambda: self._text_layer(t, mask, i, B, L, enc=v), uses=(v, mask, t), after=ev)
-            v_new = None if (last and not need_video_out) else self._video_block(v, i, B, y=self._text_operand(t), y_mask=mask, L=L)
+            tail = last and need_video_out and self._tail_ok(v)             # (the result is read at the CLS rows only: model.py:275)
+            nxt = None if (i + 1 == c.depth or (i + 2 == c.depth and not need_video_out)) else (i + 1, 0 if (i + 2 == c.depth and self._tail_ok(v)) else L)
+            if last and not need_video_out:
+                v_new = None
+            elif tail:
+                v_new = self._video_block_tail(v, i, B, y=self._text_operand(t), y_mask=mask, L=L)
+            else:
+                v_new = self._video_block(v, i, B, y=self._text_operand(t), y_mask=mask, L=L, next_block=nxt)
             join()
             v, t = v_new, t_new
         return v, t
@@ -773,7 +841,7 @@ class FrozenInTime(nn.Module):
             am = data['text']['attention_mask']
             txt_mlm = txt_mlm_pair if ('EgoNCE' in task_names and txt_mlm_pair is not None) else \
                 self._fork_text(lambda: self._text_prefix(data['text_mlm_ids'], am), uses=(data['text_mlm_ids'], am))
-            v_pre = self._video_prefix(data['video'])                       # overlaps the MLM text prefix
+            v_pre = self._video_prefix(data['video'], next_L=data['text_mlm_ids'].shape[1])   # overlaps the MLM text prefix (its last block also normalises for the MLM pass's first fused block)
             data_mlm = dict(data, _video_prefix=v_pre, _text_prefix=txt_mlm)
 
         def itm_draw():
@@ -893,11 +961,7 @@ class FrozenInTime(nn.Module):
                     # shared prefix; clips fetched from another rank arrive as bf16 tokens and start from those), so that the ITM pass
                     # continues the stream the way the MLM pass does -- the reference under autocast keeps it in fp32 throughout
                     with torch.no_grad():
-                        p32 = torch.empty(len(plan) * c.seq, x32.shape[1], dtype=torch.float32, device=x32.device)
-                        for i, (w, j) in enumerate(plan):
-                            src = x32 if w == 0 else v_rem
-                            p32[i * c.seq:(i + 1) * c.seq].copy_(src[j * c.seq:(j + 1) * c.seq])
-                    pre._res32 = p32
+                        pre._res32 = _gather_clips(plan, c.seq, (x32, v_rem), torch.float32)
                 data_itm['_video_prefix'] = pre
             else:
                 data_itm['video'] = all_video.index_select(0, vid_idx)

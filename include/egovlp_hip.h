@@ -336,8 +336,29 @@ typedef struct egv_vblock_desc {
      * stream's fp32 value at the block input (NULL: x is exact), out32 receives the fp32 output; x / out stay the bf16 roundings
      * (GEMM operands, and all egv_vblock_bwd reads).  The backward pass ignores both fields. */
     const float* x32; float* out32;
+    /* EGV_BLOCK_RES_F32, optional: the NEXT block's first LayerNorm (its norm3, video_transformer.py:217) folded into this call's
+     * output pass -- the kernel that forms out = sr + fc2(..) in fp32 has the whole row in registers and also writes
+     * LayerNorm(out; next_g, next_b) (bf16) to next_h and (mean, rstd) to next_stats: the h3 / stats3 slots of the SAVE BUFFER OF THE
+     * NEXT CALL (egv_vblock_next_slots), which is then made with EGV_BLOCK_H3_READY and skips its own LayerNorm pass over the fp32
+     * stream (one 115 MB pass per block at configs[2]).  Values are those of the separate pass, bit for bit (same kernel, same row). */
+    const float* next_g; const float* next_b; void* next_h; float* next_stats;
+    /* egv_vblock_fwd: CUs the persistent GEMM grids of this call plan for (0: all) -- a caller that runs two independent block
+     * chains on two streams lets each chain's GEMMs take a share of the chip, so that the other chain's HBM-bound kernels
+     * (LayerNorm, attention) find free CUs beside them instead of queueing behind a grid that owns every CU. */
+    int fwd_cus;
 } egv_vblock_desc;
+#define EGV_BLOCK_HEAD 32     /* egv_vblock_fwd / _bwd (EGV_BLOCK_RES_F32 form): only the part of the block every output row depends on -- norm3, the
+                                 time attention with its projection and residual, norm1 and the space attention's qkv projection
+                                 (video_transformer.py:217-219, :120) -- for a block whose output is read at the CLS rows only (the last block
+                                 of a tower: video_transformer.py:392-394, model.py:275): forward stops there, the result is the qkv_s slot of
+                                 `save` (egv_vblock_qkv_s_offset; out / out32 unused); backward takes dout = the gradient of that [M, 3D] matrix
+                                 and returns dx without the space residual's share.  The caller runs the CLS query, the output projection and
+                                 the MLP on B rows (model.py: _video_block_tail) instead of on all M: 66 % of the block's matrix work is dead. */
+#define EGV_BLOCK_H3_READY 16 /* egv_vblock_fwd with EGV_BLOCK_RES_F32: the h3 / stats3 slots of `save` were filled by the previous call (next_h / next_stats) */
 long long egv_vblock_save_bytes(const egv_vblock_desc* d);
+/* byte offsets of the stats3 [M][2] fp32 and h3 [M, D] slots inside a save buffer of this geometry */
+int egv_vblock_next_slots(const egv_vblock_desc* d, long long* stats3_off, long long* h3_off);
+long long egv_vblock_qkv_s_offset(const egv_vblock_desc* d);   /* byte offset of the space attention's qkv [M, 3D] slot inside `save` */
 long long egv_vblock_ws_bytes(const egv_vblock_desc* d, int backward);
 int egv_vblock_fwd(const egv_vblock_desc* d);
 int egv_vblock_bwd(const egv_vblock_desc* d);

@@ -700,6 +700,29 @@ def test_persistent_gemm_bitwise_equals_ring_gemm(ops, N, K, kind):
     assert _rel(big[rows.cuda()], ref) < 6e-3
 
 
+def test_cls_only_attention_vs_fp64(ops):
+    """ops.cls_attention: the CLS query of a divided space attention over ALL S keys, straight from the fused qkv matrix (the last block
+    of a video pass, model.py::_video_block_tail): output and the whole dqkv (dK | dV of every row, dQ of the CLS rows, zeros elsewhere)
+    against fp64 torch; full token geometry (S = 3137), B = 2."""
+    B, S, H = 2, 3137, 12
+    D = H * 64
+    qkv = (_rnd((B * S, 3 * D), torch.float32, 1.0, 41) * 0.5).to(torch.bfloat16).cuda().requires_grad_(True)
+    dO = _rnd((B, D), torch.float32, 1.0, 42).to(torch.bfloat16).cuda()
+    O = ops.cls_attention(qkv, B, S, H)
+    O.backward(dO)
+    x = qkv.detach().double().cpu().reshape(B, S, 3, H, 64).requires_grad_(True)
+    q = x[:, 0, 0]                                                # (B, H, 64)
+    k, v = x[:, :, 1], x[:, :, 2]                                  # (B, S, H, 64)
+    sc = torch.einsum('bhd,bshd->bhs', q, k) * 0.125
+    o = torch.einsum('bhs,bshd->bhd', torch.softmax(sc, -1), v).reshape(B, D)
+    o.backward(dO.double().cpu())
+    assert _rel(O, o.detach()) < 1e-2
+    g, gr = qkv.grad.double().cpu().reshape(B, S, 3, H, 64), x.grad
+    assert _rel(g[:, :, 1:], gr[:, :, 1:]) < 2e-2                  # dK | dV of every row
+    assert _rel(g[:, 0, 0], gr[:, 0, 0]) < 2e-2                    # dQ of the CLS rows
+    assert float(g[:, 1:, 0].abs().max()) == 0.0                   # the other rows' queries took no part
+
+
 @pytest.mark.parametrize('bm', [256, 224, 192, 160, 128])
 @pytest.mark.parametrize('N,K,bias', [(768, 768, False), (2304, 768, True), (768, 2304, False)])
 def test_persistent_gemm_every_tile_height_is_bitwise_the_same(ops, N, K, bias, bm, monkeypatch):

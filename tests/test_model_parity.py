@@ -172,6 +172,72 @@ def _egonce_only_step_vs_golden(m, g, data, noun, verb, dtype, loss_tol):
     assert not bad, bad[:8]
 
 
+def _bf16_gradients_vs_reference_under_autocast(name, cfg, B, L, wseed, bseed, m):
+    """Per-tensor bf16 gradient bounds (round-4 VERDICT: the old rule only looked at the norms of the large tensors).  Yardstick: the
+    REFERENCE ITSELF under bf16 autocast against its own fp32 gradients, per parameter tensor, same weights / batch / pinned ITM draws
+    (tests/golden/autocast_grad_error.json, written by oracle/ref_autocast_error.py --grads from the imported reference).  This build's
+    gradients (m.grad, bf16 mode, the step just run with seed 17) against the oracle's fp32 gradients (pinned to the reference's by
+    tests/test_oracle_golden.py):
+      whole gradient      rel. L2 <= 1.1 x the reference-under-autocast's (measured 0.91 x / 1.03 x on base_f4 / base_f16);
+      parameter classes   (a name with its layer index masked, >= 6 members, e.g. all `attn.qkv.weight`): RMS of the members' relative
+                          errors <= 1.25 x the reference's class RMS -- a well-averaged statistic (measured <= 1.12 x for the weight
+                          matrices; classes of tensors below 4096 elements -- column sums over B = 2 samples -- are measured against
+                          max(class RMS, whole-gradient error) of the reference: 1.6 x their own class RMS occurs on base_f16);
+      every tensor        relative error <= 2 x max(its own reference error, its class RMS) + 5e-3; tensors below 4096 elements
+                          (biases, LayerNorm terms: sums over B = 2 samples that partly cancel) also get the whole-gradient reference
+                          error as a floor inside the max.  A single tensor is ONE realisation of the rounding noise -- the
+                          reference's own realised errors scatter by 2-3 x from tensor to tensor of one class -- so 1.25 x cannot
+                          hold tensor by tensor for 539 tensors even where the mean is 0.9 x (p90 of ours / reference: 1.0-1.2);
+      scalars             (the alpha gates: one number each, |g| from 3e-4 to 0.3, so a relative error means nothing): absolute error
+                          <= 2 x the largest absolute error the reference shows in the class.
+    `.key.bias` tensors are skipped: their true gradient is exactly zero (softmax shift invariance)."""
+    import json
+    import re
+    from collections import defaultdict
+    from oracle import ref_model as O
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'autocast_grad_error.json')))[name]
+    sd, data, noun, verb, oc = oracle_setup(cfg, B, L, wseed, bseed, requires_grad=True)
+    np.random.seed(17)
+    torch.manual_seed(17)
+    oloss, _, _ = O.forward_losses(sd, data, noun, verb, oc, 'EgoNCE_MLM_ITM')
+    oloss.backward()
+    cls = lambda n: re.sub(r'\.\d+\.', '.*.', n)          # noqa: E731
+    rows = []
+    for n, p in m.named_parameters():
+        if n.endswith('.key.bias'):
+            continue
+        a, r = p.grad.double().cpu().reshape(-1), sd[n].grad.double().reshape(-1)
+        ea, gn = float((a - r).norm()), float(r.norm())
+        ra, rn, numel = ref['grad_err'][n]
+        assert abs(gn - rn) <= 1e-3 * rn + 1e-9, (n, gn, rn)          # the oracle's fp32 gradient IS the reference's
+        rows.append((n, cls(n), ea, gn, ra, numel))
+    tot = (sum(r[2] ** 2 for r in rows) / sum(r[3] ** 2 for r in rows)) ** 0.5
+    rtot = (sum(r[4] ** 2 for r in rows) / sum(r[3] ** 2 for r in rows)) ** 0.5
+    assert tot <= 1.1 * rtot, (tot, rtot)
+    by = defaultdict(list)
+    for r in rows:
+        by[r[1]].append(r)
+    crms = {}
+    bad = []
+    for c, rs in by.items():
+        if rs[0][5] == 1:                                             # scalar gates: absolute errors
+            lim = 2.0 * max(r[4] for r in rs)
+            bad += [('scalar', r[0], r[2], lim) for r in rs if r[2] > lim]
+            continue
+        eo = (sum((r[2] / (r[3] + 1e-30)) ** 2 for r in rs) / len(rs)) ** 0.5
+        er = (sum((r[4] / (r[3] + 1e-30)) ** 2 for r in rs) / len(rs)) ** 0.5
+        crms[c] = er
+        if len(rs) >= 6 and eo > 1.25 * max(er, rtot if rs[0][5] < 4096 else 0.0) + 5e-3:
+            bad.append(('class', c, eo, er))
+    for n, c, ea, gn, ra, numel in rows:
+        if numel == 1:
+            continue
+        lim = max(ra / (gn + 1e-30), crms[c], rtot if numel < 4096 else 0.0)
+        if ea / (gn + 1e-30) > 2.0 * lim + 5e-3:
+            bad.append(('tensor', n, ea / (gn + 1e-30), lim))
+    assert not bad, bad[:12]
+
+
 @pytest.mark.parametrize('dtype,tol_e,tol_l', [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 2e-2, 5e-3)])
 def test_base_f4_vs_golden(dtype, tol_e, tol_l):
     """full-depth ViT-B/16 + RoBERTa-base at 4 x 224^2 frames against the reference's own outputs.  (bf16 storage: measured
@@ -207,6 +273,8 @@ def test_base_f4_vs_golden(dtype, tol_e, tol_l):
     rel = (np.abs(gn - g['grad_norms']) / (g['grad_norms'] + 1e-5))[keep]
     kn = [k for k, kk in zip(names, keep) if kk]
     assert (rel < gtol).all(), [(kn[i], float(rel[i])) for i in np.argsort(-rel)[:8]]
+    if dtype == torch.bfloat16:
+        _bf16_gradients_vs_reference_under_autocast('base_f4', cfg, B, L, wseed, bseed, m)
     _egonce_only_step_vs_golden(m, g, data, noun, verb, dtype, tol_loss['EgoNCE'])
 
 
@@ -247,6 +315,8 @@ def test_base_f16_vs_golden(dtype, tol_e, tol_l):
     rel = (np.abs(gn - g['grad_norms']) / (g['grad_norms'] + 1e-5))[keep]
     kn = [k for k, kk in zip(names, keep) if kk]
     assert (rel < gtol).all(), [(kn[i], float(rel[i])) for i in np.argsort(-rel)[:8]]
+    if dtype == torch.bfloat16:
+        _bf16_gradients_vs_reference_under_autocast('base_f16', cfg, B, L, wseed, bseed, m)
     _egonce_only_step_vs_golden(m, g, data, noun, verb, dtype, tol_loss['EgoNCE'])
 
 
@@ -737,3 +807,63 @@ def test_video_fp8_path_vs_dequantised_oracle(geom):
     assert float((g - g0).norm() / g0.norm()) <= 1.25 * g_fmt, (float((g - g0).norm() / g0.norm()), g_fmt)
     cos = lambda a, b: float(torch.dot(a, b) / a.norm() / b.norm())   # noqa: E731
     assert cos(g, g0) >= cos(g1, g0) - 0.01, (cos(g, g0), cos(g1, g0))
+
+
+def test_layernorm_fold_and_clip_gather_are_bitwise_neutral_bf16(monkeypatch):
+    """round 5: with the fp32 video stream a block's output pass also writes the NEXT block's first LayerNorm into that block's save
+    buffer (EGV_LN_FOLD: one HBM pass less per block), and the ITM pass gathers the prefix clips (and their fp32 value) with one launch.
+    Same kernel, same rows, same fp32 values: losses and every gradient of the three-loss step must be bit-identical with the fold
+    on and off; full token geometry, 2 + 2 layers, one fused."""
+    from egovlpv2_amd.config import PathConfig
+    from egovlpv2_amd.synthetic import make_state_dict, make_batch
+    cfg = PathConfig(depth=3, n_fuse=2, frames=4, img=112)
+    sd = make_state_dict(cfg, 7)
+    data, noun, verb = make_batch(cfg, 4, 16, 23)
+    out = {}
+    for fold in ('1', '0'):
+        monkeypatch.setenv('EGV_LN_FOLD', fold)
+        m = _build(cfg, sd, torch.bfloat16)
+        np.random.seed(3)
+        torch.manual_seed(3)
+        loss, ld, ret = _forward(m, data, noun, verb, 'EgoNCE_MLM_ITM')
+        loss.backward()
+        torch.cuda.synchronize()
+        out[fold] = ({k: float(v) for k, v in ld.items()}, {n: p.grad.clone() for n, p in m.named_parameters()})
+    assert out['1'][0] == out['0'][0], (out['1'][0], out['0'][0])
+    for n, g in out['1'][1].items():
+        assert torch.equal(g, out['0'][1][n]), n
+
+
+def test_cls_only_last_block_matches_the_full_block_bf16(monkeypatch):
+    """round 5: the last block of a video pass is read at its CLS rows only (video_transformer.py:392-394, model.py:275), so its
+    space-attention query, attn.proj, image-to-text part and MLP run on B rows (model.py::_video_block_tail, EGV_CLS_TAIL) and the dead
+    66 % of the block's matrix work is not issued.  Same mathematics, other kernels for the B live rows (small-M GEMMs, the one-query
+    attention launches): embeddings, the three losses and every gradient against the full-block form within bf16 rounding."""
+    from egovlpv2_amd.config import PathConfig
+    from egovlpv2_amd.synthetic import make_state_dict, make_batch
+    cfg = PathConfig(depth=3, n_fuse=2, frames=4, img=112)
+    sd = make_state_dict(cfg, 9)
+    data, noun, verb = make_batch(cfg, 4, 16, 29)
+    out = {}
+    for tail in ('1', '0'):
+        monkeypatch.setenv('EGV_CLS_TAIL', tail)
+        m = _build(cfg, sd, torch.bfloat16)
+        with torch.no_grad():
+            r = m.infer(_to_cuda(data), task_names='EgoNCE')
+        np.random.seed(3)
+        torch.manual_seed(3)
+        loss, ld, ret = _forward(m, data, noun, verb, 'EgoNCE_MLM_ITM')
+        loss.backward()
+        torch.cuda.synchronize()
+        out[tail] = (r['video_embeds'].float().cpu(), {k: float(v) for k, v in ld.items()},
+                     {n: p.grad.double().cpu() for n, p in m.named_parameters()})
+    assert rel_err(out['1'][0], out['0'][0]) < 8e-3
+    for k, v in out['0'][1].items():
+        assert abs(out['1'][1][k] - v) <= 5e-3 * abs(v), (k, out['1'][1][k], v)
+    ga = torch.cat([g.reshape(-1) for g in out['1'][2].values()])
+    gb = torch.cat([out['0'][2][n].reshape(-1) for n in out['1'][2]])
+    assert float(torch.dot(ga, gb) / (ga.norm() * gb.norm())) > 0.999
+    assert float((ga - gb).norm() / gb.norm()) < 4e-2
+    worst = max((float((g - out['0'][2][n]).norm() / (out['0'][2][n].norm() + 1e-12)), n) for n, g in out['1'][2].items()
+                if not n.endswith('.key.bias') and out['0'][2][n].norm() > 1e-3 * gb.norm() / len(out['1'][2]) ** 0.5)
+    assert worst[0] < 0.2, worst
