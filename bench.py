@@ -42,20 +42,27 @@ def flops_per_pair(cfg, L, workload):
     return dual if workload == 'dual' else dual + 2 * fused + heads
 
 
-def skipped_flops_per_pair(cfg, L, workload, world):
+def skipped_flops_per_pair(cfg, L, workload, world, tail=True):
     """Forward FLOPs of the reference's algorithm that this build does not execute because they are dead or duplicated:
-    the MLM pass's last video block (output discarded) and the ITM pass's unfused video prefix for clips
+    the MLM pass's last video block (output discarded); the ITM pass's unfused video prefix for clips
     this rank already pushed through the identical prefix in the MLM pass (all of them at world size 1; on average all but
-    the ~B/4 * (W-1)/W hard-negative clips owned by other ranks otherwise)."""
-    if workload == 'dual':
-        return 0.0
+    the ~B/4 * (W-1)/W hard-negative clips owned by other ranks otherwise); round 5: the rows nobody reads of the LAST block of a
+    video pass (EgoNCE tower, ITM stack: only the CLS rows leave it, so attn.proj, the patch queries of the space attention, the
+    image-to-text part and the MLP run on the CLS rows alone -- model._video_block_tail) and the second patch embedding of the same
+    clips (EgoNCE tower and shared prefix embed once)."""
     d, F, N, S = cfg.dim, cfg.frames, cfg.n_patches, cfg.seq
+    # per-row work of a block that only the CLS row needs: attn.proj, the MLP, the patch queries of the space attention
+    tail_rows = (S - 1) * (2 * d * d + 4 * d * 4 * d) + 4 * d * (F * N * (1 + N))
+    tail_i2t = (S - 1) * (4 * d * d + 4 * L * d)                      # fused: qkv_i2t, proj_i2t, the image-to-text attention of the other rows
+    if workload == 'dual':
+        return float(tail_rows) if tail else 0.0
     patch = 2 * F * N * d * (3 * cfg.patch ** 2)
     vblock = 2 * (2 * S * d * 3 * d + 2 * S * d * d) + 4 * d * (F * N * (1 + F) + S) + 4 * d * (F * N * (1 + N) + S) + 4 * S * d * 4 * d
     i2t = 4 * S * d * d + 2 * L * d * 2 * d + 4 * S * L * d
     prefix = patch + (cfg.depth - cfg.n_fuse) * vblock
     shared = 1.0 - 0.25 * (world - 1) / world
-    return (vblock + i2t) + shared * prefix
+    tails = (2 * tail_rows + tail_i2t) if tail else 0.0                # EgoNCE tower's last block + the ITM stack's last (fused) block
+    return (vblock + i2t) + shared * prefix + tails + patch
 
 
 def _cpu_sample(frames, L, workload, threads):
@@ -371,7 +378,9 @@ def main():
         pairs = world * a.batch * a.steps
         value = pairs / dt
         fpp = 3.0 * flops_per_pair(cfg, a.text_len, a.workload)
-        fpx = fpp - 3.0 * skipped_flops_per_pair(cfg, a.text_len, a.workload, world)
+        from egovlpv2_amd import switches as SW
+        tail_on = a.dtype == 'bf16' and not a.fp8 and SW.on('EGV_CLS_TAIL') and SW.on('EGV_VIDEO_RES32')
+        fpx = fpp - 3.0 * skipped_flops_per_pair(cfg, a.text_len, a.workload, world, tail_on)
         out = {"metric": "video-text pairs/sec/node (EgoClip fwd+bwd, 16x224^2, 32 tok)", "value": round(value, 3),
                "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -382,7 +391,8 @@ def main():
                           + f", B={a.batch}/GPU, {a.frames}x224^2, {a.text_len} tok",
                           "global_batch": world * a.batch, "parallelism": f"dp{world}", "drop_rate": a.drop_rate, "timed": "zero_grad + fwd + bwd (+ gradient all-reduce: " + (a.grad_sync if use_dist else "none") + "), weight cast included" + (" + fused AdamW step" if a.optimizer else "")},
                # model_tflops: the reference algorithm's matmul FLOPs per pair x pairs/s; executed_tflops leaves
-               # out the dead MLM video block and the ITM video prefix shared with the MLM pass (same values, computed once)
+               # out what skipped_flops_per_pair lists: the dead MLM video block, the ITM video prefix shared with the MLM pass, the
+               # unread rows of the last block of the EgoNCE tower and of the ITM stack, the second patch embedding
                "model_tflops": round(value * fpp / 1e12, 1), "executed_tflops": round(value * fpx / 1e12, 1),
                "mfma_frac_of_peak": round(value * fpx / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
                "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),

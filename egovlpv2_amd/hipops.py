@@ -1309,6 +1309,7 @@ class VideoHeadFn(Function):
         assert x.dim() == 2 and x.is_contiguous() and x.dtype == torch.bfloat16
         d = VideoHeadFn._desc(cfg, x, params)
         x32, pre_save = cfg[6], cfg[7]
+        B = cfg[0]
         d.x32 = _p(x32)
         nsave = lib.egv_vblock_save_bytes(C.byref(d))
         if pre_save is not None and pre_save.numel() == nsave:
@@ -1322,16 +1323,22 @@ class VideoHeadFn(Function):
         off = lib.egv_vblock_qkv_s_offset(C.byref(d))
         M, D = x.shape
         qkv = save[off:off + M * 3 * D * 2].view(torch.bfloat16).view(M, 3 * D)
+        S = M // B
+        # the CLS rows of the block input in fp32 (the space residual's base, video_transformer.py:222): a second output, so that
+        # their gradient comes back INTO this call's dx instead of as a zero-padded [M, D] tensor autograd has to add
+        xc = (x32 if x32 is not None else x).view(B, S, D)[:, 0].float()
         ctx.cfg = cfg[:6]
         ctx.key = ('vh', id(params[0]))
         _acc_forward(ctx.key, cfg[8], False)
         ctx.save_for_backward(x, save, *params)
-        return qkv
+        return qkv, xc
 
     @staticmethod
-    def backward(ctx, dqkv):
+    def backward(ctx, dqkv, dxc):
         x, save, *params = ctx.saved_tensors
         d = VideoHeadFn._desc(ctx.cfg, x, params)
+        if dqkv is None:
+            dqkv = torch.zeros(x.shape[0], 3 * x.shape[1], dtype=x.dtype, device=x.device)
         dqkv = dqkv.contiguous()
         dx = torch.empty_like(x)
         gp = _GradPack(params, x.device)
@@ -1353,11 +1360,15 @@ class VideoHeadFn(Function):
             _deferred['sides'][side[0].cuda_stream] = side
             _queue_done()
         check(lib.egv_vblock_bwd(C.byref(d)), 'egv_vblock_bwd(head)')
+        if dxc is not None:                                  # the space residual reads x at the CLS rows
+            B = ctx.cfg[0]
+            dx.view(B, x.shape[0] // B, x.shape[1])[:, 0] += dxc.to(dx.dtype)
         return (None, dx, *_acc_backward(ctx.key, gp, params, len(params), side))
 
 
 def video_block_head(x, params, B, Fr, N, H, Hd, eps):
-    """params: the 10 tensors VideoHeadFn lists; x carries its fp32 value (`._res32`) and, possibly, a folded norm3 (`._pre_save`)"""
+    """params: the 10 tensors VideoHeadFn lists; x carries its fp32 value (`._res32`) and, possibly, a folded norm3 (`._pre_save`).
+    Returns (qkv_s [M, 3D] bf16, the fp32 CLS rows of x [B, D])."""
     pre = None
     ps = x.__dict__.pop('_pre_save', None)
     if ps is not None and ps[1] == id(params[6]):
@@ -1583,12 +1594,13 @@ def text_layer(hid, mask, params, B, Lt, H, Hd, eps, enc=None, S=0, drop_p=0.0, 
 IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)     # data_loader/transforms.py:17-18 defaults
 
 
-class PatchTokensFn(Function):
-    """video (B,F,3,H,W) fp32 -> tokens (B, 1+F*N, D): Conv2d(k=s=P) as im2col + MFMA GEMM (+bias), then CLS concat
-    and pos/temporal embedding (video_transformer.py:78-83,356-371)."""
+class PatchEmbedFn(Function):
+    """video (B,F,3,H,W) fp32 / uint8 -> patch embeddings (B*F*N, D): Conv2d(k=s=P) as im2col + MFMA GEMM (+bias)
+    (video_transformer.py:78-83).  A function of the pixels and the conv weights alone: the EgoNCE tower and the shared prefix of the
+    MLM / ITM passes (different CLS tokens, same patches) use ONE call per step (model._patch_tokens keeps the result for the step)."""
 
     @staticmethod
-    def forward(ctx, video, conv_w, conv_b, cls, pos, temporal, dtype):
+    def forward(ctx, video, conv_w, conv_b, dtype):
         _need_gpu(video)
         B, Fr, Cc, Hh, Ww = video.shape
         D = conv_w.shape[0]
@@ -1608,19 +1620,37 @@ class PatchTokensFn(Function):
         w = compute_weight(conv_w, dtype).reshape(D, Kp)
         emb = torch.empty(B * Fr * N, D, dtype=dtype, device=video.device)
         gemm(patches, w, emb, M=B * Fr * N, N=D, K=Kp, lda=Kp, ldb=Kp, ldc=D, bias=conv_b)
-        out = torch.empty(B, 1 + Fr * N, D, dtype=dtype, device=video.device)
+        ctx.cfg = (B * Fr * N, D, Kp)
+        ctx.wshape = conv_w.shape
+        ctx.save_for_backward(patches)
+        return emb
+
+    @staticmethod
+    def backward(ctx, demb):
+        (patches,) = ctx.saved_tensors
+        M, D, Kp = ctx.cfg
+        dw, db = wgrad(demb.contiguous(), patches, M, D, Kp, bias=True)
+        return None, dw.reshape(ctx.wshape), db, None
+
+
+class PatchTokensFn(Function):
+    """patch embeddings (B*F*N, D) -> tokens (B, 1+F*N, D): CLS concat and pos / temporal embedding (video_transformer.py:356-371)."""
+
+    @staticmethod
+    def forward(ctx, emb, cls, pos, temporal, B, Fr, N):
+        D = emb.shape[1]
+        dt = _dt(emb)
+        out = torch.empty(B, 1 + Fr * N, D, dtype=emb.dtype, device=emb.device)
         check(lib.egv_assemble_tokens(dt, _p(emb), _p(cls), _p(pos), _p(temporal), _p(out), B, Fr, N, D, _st()),
               'egv_assemble_tokens')
-        ctx.cfg = (B, Fr, N, D, Kp, dt)
-        ctx.shapes = (conv_w.shape, cls.shape, pos.shape, temporal.shape)
-        ctx.save_for_backward(patches)
+        ctx.cfg = (B, Fr, N, D, dt)
+        ctx.shapes = (cls.shape, pos.shape, temporal.shape)
         return out
 
     @staticmethod
     def backward(ctx, dX):
-        (patches,) = ctx.saved_tensors
-        B, Fr, N, D, Kp, dt = ctx.cfg
-        wshape, cshape, pshape, tshape = ctx.shapes
+        B, Fr, N, D, dt = ctx.cfg
+        cshape, pshape, tshape = ctx.shapes
         dX = dX.contiguous()
         dev = dX.device
         dpatch = torch.empty(B * Fr * N, D, dtype=dX.dtype, device=dev)
@@ -1630,14 +1660,25 @@ class PatchTokensFn(Function):
         ws = workspace(lib.egv_assemble_tokens_bwd_workspace_bytes(Fr, N, D), dev, slot=1)
         check(lib.egv_assemble_tokens_bwd(dt, _p(dX), _p(dpatch), _p(dcls), _p(dpos), _p(dtem), B, Fr, N, D, _p(ws), _st()),
               'egv_assemble_tokens_bwd')
-        M = B * Fr * N
-        dw, db = wgrad(dpatch, patches, M, D, Kp, bias=True)
-        dw = dw.reshape(wshape)
-        return None, dw, db, dcls.reshape(cshape), dpos.reshape(pshape), dtem.reshape(tshape), None
+        return dpatch, dcls.reshape(cshape), dpos.reshape(pshape), dtem.reshape(tshape), None, None, None
 
 
-def patch_tokens(video, conv_w, conv_b, cls, pos, temporal, dtype):
-    return PatchTokensFn.apply(video, conv_w, conv_b, cls, pos, temporal, dtype)
+def patch_embed(video, conv_w, conv_b, dtype):
+    return PatchEmbedFn.apply(video, conv_w, conv_b, dtype)
+
+
+def assemble_tokens(emb, cls, pos, temporal, B, Fr, N):
+    return PatchTokensFn.apply(emb, cls, pos, temporal, B, Fr, N)
+
+
+def patch_tokens(video, conv_w, conv_b, cls, pos, temporal, dtype, emb=None):
+    """emb: the result of patch_embed on the same video and conv weights (computed here when None)"""
+    B, Fr = video.shape[0], video.shape[1]
+    P = conv_w.shape[-1]
+    N = (video.shape[3] // P) * (video.shape[4] // P)
+    if emb is None:
+        emb = patch_embed(video, conv_w, conv_b, dtype)
+    return assemble_tokens(emb, cls, pos, temporal, B, Fr, N)
 
 
 # ---- RoBERTa embeddings --------------------------------------------------------------------------------

@@ -361,9 +361,21 @@ class FrozenInTime(nn.Module):
         """video_transformer.py:353-372 / model.py:211-232: patch embed, CLS concat, pos + temporal embedding."""
         B, Fr = video.shape[0], video.shape[1]
         assert Fr == self.num_frames, (Fr, self.num_frames)                  # video_transformer.py:80
-        x = ops.patch_tokens(video, self.p('video_model.patch_embed.proj.weight'), self.p('video_model.patch_embed.proj.bias'),
-                             self.p(cls_name), self.p('video_model.pos_embed'), self.p('video_model.temporal_embed'),
-                             self.compute_dtype)
+        # The patch embedding (Conv2d as im2col + GEMM) is a function of the pixels and the conv weights alone: the EgoNCE tower
+        # (video_model.cls_token) and the shared prefix of the MLM / ITM passes (model-level cls_token) embed the same clips, so one
+        # call serves both within a step (the reference embeds twice: model.py:224, video_transformer.py:353) and the conv's weight
+        # gradient is formed once, from the sum of both consumers' gradients.  Keyed by the tensor's identity, version and grad mode;
+        # only inside one forward() call (direct compute_video / infer calls embed on their own: their graphs are the caller's).
+        w, b = self.p('video_model.patch_embed.proj.weight'), self.p('video_model.patch_embed.proj.bias')
+        key = (id(video), video._version, video.data_ptr(), torch.is_grad_enabled())
+        memo = self.__dict__.get('_pe_memo')                                # a dict only while forward() runs (its passes share a graph)
+        emb = memo.get(key) if memo is not None else None
+        if emb is None:
+            emb = ops.patch_embed(video, w, b, self.compute_dtype)
+            if memo is not None:
+                memo[key] = emb
+        x = ops.patch_tokens(video, w, b, self.p(cls_name), self.p('video_model.pos_embed'), self.p('video_model.temporal_embed'),
+                             self.compute_dtype, emb=emb)
         return x.reshape(B * self.cfg.seq, self.cfg.dim)
 
     def _block_params(self, kind, i, fused):
@@ -424,11 +436,9 @@ class FrozenInTime(nn.Module):
         p = self._block_params('video', i, fused)
         pfx = f'video_model.blocks.{i}'
         D = c.dim
-        x32 = ops.stream32(x)
-        qkv = ops.video_block_head(x, [p[0], p[1], p[2], p[3], p[4], p[5], p[12], p[13], p[14], p[15]], B, c.frames, c.n_patches, c.heads,
-                                   c.dim * c.mlp_ratio, c.eps_video)
+        qkv, xc = ops.video_block_head(x, [p[0], p[1], p[2], p[3], p[4], p[5], p[12], p[13], p[14], p[15]], B, c.frames, c.n_patches,
+                                       c.heads, c.dim * c.mlp_ratio, c.eps_video)
         ctx = ops.cls_attention(qkv, B, c.seq, c.heads)                                   # the CLS query over all S keys (:129)
-        xc = ops.stream_rows(x, x32, B, c.seq) if x32 is not None else self._cls_rows(x, B, c.seq).float()
         s = self._lin(ctx, pfx + '.attn.proj')                                            # (B, D)
         sr = xc + s.float()                                                               # residual from x, not from the time residual (:222)
         if fused:
@@ -695,6 +705,13 @@ class FrozenInTime(nn.Module):
     def forward(self, data, n_embeds, v_embeds, allgather, n_gpu, args, config, loss_egonce, gpu, return_embeds=True,
                 task_names='EgoNCE_ITM_MLM'):
         """model.py:370-487.  Returns (loss, loss_dict, ret)."""
+        self.__dict__['_pe_memo'] = {}
+        try:
+            return self._forward(data, n_embeds, v_embeds, allgather, n_gpu, args, config, loss_egonce, gpu, return_embeds, task_names)
+        finally:
+            self.__dict__['_pe_memo'] = None
+
+    def _forward(self, data, n_embeds, v_embeds, allgather, n_gpu, args, config, loss_egonce, gpu, return_embeds, task_names):
         ret, loss_dict = {}, {}
         self._begin_step()
         if 'Feature_Extraction' in task_names:                                                   # :375-377

@@ -76,7 +76,7 @@ def main():
     wrap(ops.VideoBlockFn, 'backward', 'vb')
     wrap(ops.TextLayerFn, 'forward', 'tf')
     wrap(ops.TextLayerFn, 'backward', 'tb')
-    for nm in ('PatchTokensFn', 'VocabLinearFn', 'CrossEntropySumFn', 'TextEmbedFn'):
+    for nm in ('PatchEmbedFn', 'PatchTokensFn', 'VocabLinearFn', 'CrossEntropySumFn', 'TextEmbedFn'):
         c = getattr(ops, nm, None)
         if c is not None:
             wrap(c, 'forward', nm + '.f')
