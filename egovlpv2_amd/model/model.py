@@ -431,13 +431,23 @@ class FrozenInTime(nn.Module):
         the space attention's query, attn.proj, the image-to-text part, norm2 and the MLP act row by row, so for the CLS rows they run
         on B rows instead of B*S -- 66 % of the block's matrix work (and the gradients of the same share: they are exactly zero for
         the rows nobody reads) is never issued.  Returns the fp32 CLS rows (B, D), tagged for _video_out_norm."""
+        return self._video_tail_rest(self._video_tail_head(x, i, B), i, B, y=y, y_mask=y_mask, L=L)
+
+    def _video_tail_head(self, x, i, B):
+        """the all-rows part of the CLS-only last block: (qkv_s [M, 3D], fp32 CLS rows of the block input)"""
+        c = self.cfg
+        p = self._block_params('video', i, False)
+        return ops.video_block_head(x, [p[0], p[1], p[2], p[3], p[4], p[5], p[12], p[13], p[14], p[15]], B, c.frames, c.n_patches,
+                                    c.heads, c.dim * c.mlp_ratio, c.eps_video)
+
+    def _video_tail_rest(self, head, i, B, y=None, y_mask=None, L=0):
+        """the B-row part of the CLS-only last block: ~45 launches of a few microseconds on the CLS rows (and three times that in
+        backward); depends on the head through qkv_s and the CLS rows only, so a caller may issue it later and on another stream"""
         c = self.cfg
         fused = y is not None
-        p = self._block_params('video', i, fused)
         pfx = f'video_model.blocks.{i}'
         D = c.dim
-        qkv, xc = ops.video_block_head(x, [p[0], p[1], p[2], p[3], p[4], p[5], p[12], p[13], p[14], p[15]], B, c.frames, c.n_patches,
-                                       c.heads, c.dim * c.mlp_ratio, c.eps_video)
+        qkv, xc = head
         ctx = ops.cls_attention(qkv, B, c.seq, c.heads)                                   # the CLS query over all S keys (:129)
         s = self._lin(ctx, pfx + '.attn.proj')                                            # (B, D)
         sr = xc + s.float()                                                               # residual from x, not from the time residual (:222)
@@ -656,12 +666,7 @@ class FrozenInTime(nn.Module):
             B, L = text_data['input_ids'].shape
             v, t = self._fused_stack(video_data, text_data['input_ids'], text_data['attention_mask'],
                                      video_prefix=data.get('_video_prefix'), text_prefix=data.get('_text_prefix'))
-            vf = self._video_out_norm(v, B, 'norm', c.eps_model_norm)                       # self.norm(v)[:, 0]  (:275)
-            tf = self._lin(self._text_operand(self._cls_rows(t, B, L)), 'cross_modal_text_transform')
-            vf = self._lin(vf, 'cross_modal_video_transform')
-            ct = self._lin(tf, 'cross_modal_text_pooler.dense', act='tanh')
-            cv = self._lin(vf, 'cross_modal_video_pooler.dense', act='tanh')
-            ret.update({'cross_attn_itm_logits': self._lin(torch.cat([ct, cv], dim=-1), 'itm_score.fc')})
+            ret.update({'cross_attn_itm_logits': self._itm_logits(v, t, B, L)})
         if 'MLM' in self.task_names:
             B, L = data['text_mlm_ids'].shape
             logits = self._mlm_logits_padded(video_data, data['text_mlm_ids'], text_data['attention_mask'],
@@ -669,6 +674,16 @@ class FrozenInTime(nn.Module):
             ret.update({'cross_attn_mlm_logits': logits.reshape(B, L, -1)[..., :c.vocab]})
             ret['_mlm_logits_padded'] = logits
         return ret
+
+    def _itm_logits(self, v, t, B, L):
+        """ITM head (model.py:275-293): norm on the video CLS rows, the two cross-modal transforms and poolers, the 2-way score"""
+        c = self.cfg
+        vf = self._video_out_norm(v, B, 'norm', c.eps_model_norm)                           # self.norm(v)[:, 0]  (:275)
+        tf = self._lin(self._text_operand(self._cls_rows(t, B, L)), 'cross_modal_text_transform')
+        vf = self._lin(vf, 'cross_modal_video_transform')
+        ct = self._lin(tf, 'cross_modal_text_pooler.dense', act='tanh')
+        cv = self._lin(vf, 'cross_modal_video_pooler.dense', act='tanh')
+        return self._lin(torch.cat([ct, cv], dim=-1), 'itm_score.fc')
 
     def _mlm_logits_padded(self, video, mlm_ids, attention_mask, video_prefix=None, text_prefix=None):
         """MLM branch of infer (model.py:346-365): fused stack without its dead last video block, then the head"""
@@ -982,11 +997,12 @@ class FrozenInTime(nn.Module):
                 data_itm['_video_prefix'] = pre
             else:
                 data_itm['video'] = all_video.index_select(0, vid_idx)
+            def itm_loss(itm_logits):
+                ce_sum = ops.cross_entropy_sum(ops.CastFn.apply(itm_logits, torch.float32).contiguous(), labels_dev.contiguous(), 2, -100)
+                tot = gather(torch.stack([ce_sum, torch.full_like(ce_sum, float(bsz))]).reshape(1, 2))
+                return tot[:, 0].sum() / tot[:, 1].sum()
             r_itm = self.infer(data_itm, task_names='ITM', ret=ret)
-            itm_logits = r_itm['cross_attn_itm_logits']
-            ce_sum = ops.cross_entropy_sum(ops.CastFn.apply(itm_logits, torch.float32).contiguous(), labels_dev.contiguous(), 2, -100)
-            tot = gather(torch.stack([ce_sum, torch.full_like(ce_sum, float(bsz))]).reshape(1, 2))
-            loss_itm = tot[:, 0].sum() / tot[:, 1].sum()
+            loss_itm = itm_loss(r_itm['cross_attn_itm_logits'])
             loss_dict.update({'loss_itm': loss_itm})
             terms['itm'] = (2.0, loss_itm)
             ret['_itm_labels'] = itm_labels
