@@ -35,6 +35,7 @@ const Switch g_switches[] = {
     {"EGV_ATTN_SPACE_NEW", 1, "space attention on row-major LDS images, egv_attn_space.hip (0: the kernels of egv_attn_mfma.hip)"},
     {"EGV_ATTN_FUSED_CLS", 1, "the group launches also serve the CLS row (per-group partials + one small sum)"},
     {"EGV_ATTN_FUSED_BWD", 1, "one-launch attention backward where a kernel covers the shape (0: dQ + dK/dV kernel pair)"},
+    {"EGV_WGRAD_SMALL_M", 1, "weight gradients over <= 16 rows as an outer product (wgrad_small_m_kernel) instead of a one-K-step MFMA GEMM"},
     {"EGV_WGRAD_PP", 1, "ping-pong 256x256 weight-gradient kernel (0: 256x128 ring kernel)"},
     {"EGV_WGRAD_ITEMS", 224, "(tile, split) items of a one-gradient-per-launch weight gradient: 7/8 of the CUs"},
     {"EGV_GEMM_PP", 1, "persistent ping-pong GEMM for large grids (0: DMA-ring kernels only)"},

@@ -535,7 +535,13 @@ __global__ __launch_bounds__(256) void attn1_dq_kernel(const AttnArgs a) {
     float q[8], go[8], ov[8];
     ld8(Q + qrow * a.ldq + a.qoff + h * HD + sub * 8, q);
     ld8(dO + qrow * a.ldo + a.ooff + h * HD + sub * 8, go);
-    ld8(O + qrow * a.ldo + a.ooff + h * HD + sub * 8, ov);
+    if (a.O32) {                                                   // delta from the fp32 values of O (egv_attn_desc::O32)
+        const float* o32 = a.O32 + qrow * a.ldo + a.ooff + h * HD + sub * 8;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) ov[d] = o32[d];
+    } else {
+        ld8(O + qrow * a.ldo + a.ooff + h * HD + sub * 8, ov);
+    }
     float dl = 0.f;
 #pragma unroll
     for (int d = 0; d < 8; ++d) { dl = fmaf(go[d], ov[d], dl); q[d] *= a.scale; }

@@ -298,7 +298,7 @@ __device__ __forceinline__ float dot8_bf16(const u32x4_t& a, const u32x4_t& b, f
 }
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
                                                           bf16_t* __restrict__ C, int ldc, const float* __restrict__ bias, int act,
-                                                          int M, int N, int K) {
+                                                          int M, int N, int K, bf16_t* __restrict__ pre) {
     const int lane = threadIdx.x & 63;
     const int n0 = (blockIdx.x * 4 + wave_id()) * 4;
     if (n0 >= N) return;
@@ -327,7 +327,11 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restri
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float v = wave_sum(acc[m][c]);
-                if (lane == 0 && n0 + c < N) C[(long long)m * ldc + n0 + c].v = f2bf(apply_act(v + (bias ? bias[n0 + c] : 0.f), act));
+                if (lane == 0 && n0 + c < N) {
+                    const float z = v + (bias ? bias[n0 + c] : 0.f);
+                    if (pre) pre[(long long)m * ldc + n0 + c].v = f2bf(z);       // saved pre-activation (GELU: the MLP's fc1 on the CLS rows)
+                    C[(long long)m * ldc + n0 + c].v = f2bf(act == 1 ? gelu_fast_f(z) : apply_act(z, act));   // GELU: the form of every bf16 kernel
+                }
             }
         }
     }
@@ -360,9 +364,9 @@ extern "C" int egv_gemm(int dtype, int a_trans, int b_trans, int M, int N, int K
     const double abytes = es_ * ((double)M * K + (double)N * K + (double)M * N * (1 + (res1 != nullptr) + (res2 != nullptr) + (pre != nullptr) + (aux != nullptr)));
     void* ph = egv_prof_begin(stream);
     if (dtype == EGV_BF16 && !a_trans && !b_trans && !out_f32 && M <= 16 && N >= 512 && K >= 512 && (K % 8) == 0 && g.a_vec_ok && g.b_vec_ok &&
-        !gate && !res1 && !res2 && !pre && !aux && !dact && scale == 1.0f && (act == 0 || act == 2 || act == 3)) {
+        !gate && !res1 && !res2 && !aux && !dact && scale == 1.0f && (act == 0 || act == 1 || act == 2 || act == 3) && (!pre || (act == 1 && g.e.ldr == ldc))) {
         hipLaunchKernelGGL(gemm_skinny_kernel, dim3((N + 15) / 16), dim3(256), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc,
-                           bias, act, M, N, K);
+                           bias, act, M, N, K, (bf16_t*)pre);
         egv_prof_end(ph, stream, 2.0 * M * N * K, 7, abytes);        // 7 = skinny (<= 16 rows)
         EGV_LAUNCH_CHECK();
         return 0;
@@ -442,6 +446,36 @@ extern "C" long long egv_gemm_wgrad_workspace_bytes(int N, int K, int M) {
 extern "C" int egv_colsum(int dtype, const void* X, int M, int N, int ld, float* out, float scale, const float* gate,
                           void* workspace, void* stream);
 
+// Weight (and bias) gradient of a Linear over a handful of rows (M <= 16: the B CLS rows of the last block of a video pass, the pooled
+// rows of the heads): dW[n, k] = sum_m dY[m, n] X[m, k] is M multiply-adds per output element and N*K*4 bytes of stores -- an outer
+// product, bound by writing dW once.  One thread per (n, four consecutive k): the M x 4 values of X and the M values of dY come from the
+// caches (both operands are a few KB), the sum runs over m in order (deterministic), dbias[n] = sum_m dY[m, n] rides with the k = 0 thread.
+// As a 128 x 128-tile MFMA GEMM the same gradient was 144 tiles whose K loop has one step: 20 launches of 39 us (up to 250 us in the step) per
+// training step, every one of them on the latency-bound chain between two block calls.
+namespace egv {
+__global__ __launch_bounds__(256) void wgrad_small_m_kernel(const bf16_t* __restrict__ dY, int ldy, const bf16_t* __restrict__ X, int ldx,
+                                                            float* __restrict__ dW, float* __restrict__ dbias, int M, int N, int K, float scale,
+                                                            const float* __restrict__ gate) {
+    const int k4n = K >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)N * k4n) return;
+    const int n = (int)(idx / k4n), k = (int)(idx % k4n) * 4;
+    const float sc = scale * (gate ? *gate : 1.0f);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, sb = 0.f;
+    for (int m = 0; m < M; ++m) {
+        const float d = bf2f(dY[(size_t)m * ldy + n].v);
+        const u32x2_t xv = *reinterpret_cast<const u32x2_t*>(X + (size_t)m * ldx + k);
+        a0 = fmaf(d, __uint_as_float(xv[0] << 16), a0);
+        a1 = fmaf(d, __uint_as_float(xv[0] & 0xffff0000u), a1);
+        a2 = fmaf(d, __uint_as_float(xv[1] << 16), a2);
+        a3 = fmaf(d, __uint_as_float(xv[1] & 0xffff0000u), a3);
+        sb += d;
+    }
+    *reinterpret_cast<f32x4_t*>(dW + (size_t)n * K + k) = f32x4_t{a0 * sc, a1 * sc, a2 * sc, a3 * sc};
+    if (dbias && k == 0) dbias[n] = sb * sc;
+}
+}  // namespace egv
+
 // dW[N,K] (fp32) = scale * gate * dY[M,N]^T X[M,K], reduction over M split across blockIdx.z;
 // dbias[N] (fp32, optional) = scale * gate * sum_m dY[m, :]  (fused: the wgrad kernel already streams dY).
 extern "C" int egv_gemm_wgrad(int dtype, int M, int N, int K, const void* dY, int ldy, const void* X, int ldx,
@@ -450,6 +484,16 @@ extern "C" int egv_gemm_wgrad(int dtype, int M, int N, int K, const void* dY, in
     EGV_CHECK(dtype == EGV_F32 || dtype == EGV_BF16, "egv_gemm_wgrad: bad dtype %d", dtype);
     EGV_CHECK(M > 0 && N > 0 && K > 0, "egv_gemm_wgrad: bad shape");
     EGV_CHECK(workspace && workspace_bytes >= egv_gemm_wgrad_workspace_bytes(N, K, M), "egv_gemm_wgrad: workspace too small");
+    static const bool small_m = egv_cfg_on("EGV_WGRAD_SMALL_M", true);
+    if (small_m && dtype == EGV_BF16 && M <= 16 && (K % 4) == 0 && (ldx % 4) == 0 && (reinterpret_cast<uintptr_t>(X) & 7) == 0 && (reinterpret_cast<uintptr_t>(dW) & 15) == 0) {
+        void* ph0 = egv_prof_begin(stream);
+        const long long nthr = (long long)N * (K >> 2);
+        hipLaunchKernelGGL(wgrad_small_m_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, dW, dbias, M, N, K, scale, gate);
+        egv_prof_end(ph0, stream, 2.0 * M * N * K, 9, 2.0 * ((double)M * N + (double)M * K) + 4.0 * N * K);   // 9 = small-M outer product
+        EGV_LAUNCH_CHECK();
+        return 0;
+    }
     bool v2;
     int nz = wgrad_plan(dtype, M, N, K, v2);
     const bool pp = wgrad_use_pp(dtype, M, N, K);

@@ -65,10 +65,13 @@ def test_linear_forms(ops, dtype, shape):
 
 
 @pytest.mark.parametrize('M,N,K,act,bias', [(8, 4096, 4096, 'relu', True), (8, 4096, 768, 'relu', False), (1, 4096, 4096, 'none', True),
-                                            (16, 1000, 1024, 'tanh', True), (13, 520, 2304, 'none', False)])
+                                            (16, 1000, 1024, 'tanh', True), (13, 520, 2304, 'none', False),
+                                            (8, 3072, 768, 'gelu', True), (8, 768, 3072, 'none', True)])
 def test_skinny_linear_bf16(ops, M, N, K, act, bias):
-    """Linear over <= 16 rows (the projection heads, model.py:105-115: gemm_skinny_kernel, one wave per four output columns):
-    forward and gradients against fp64 on the bf16 operands; a row's result does not depend on the other rows of the call (bitwise)"""
+    """Linear over <= 16 rows (the projection heads, model.py:105-115, and the CLS rows of the last block of a video pass:
+    gemm_skinny_kernel, one wave per four output columns, GELU with its saved pre-activation included; the weight gradient as an outer
+    product, wgrad_small_m_kernel): forward and gradients against fp64 on the bf16 operands; a row's result does not depend on the other
+    rows of the call (bitwise)"""
     dtype = torch.bfloat16
     x = _rnd((M, K), dtype, 1.0, 1).cuda().requires_grad_(True)
     w = _rnd((N, K), torch.float32, 0.05, 2).cuda().requires_grad_(True)
@@ -77,7 +80,7 @@ def test_skinny_linear_bf16(ops, M, N, K, act, bias):
     x64 = x.detach().double().cpu().requires_grad_(True)
     w64 = w.detach().to(dtype).double().cpu().requires_grad_(True)
     z = x64 @ w64.t() + (b.detach().double().cpu() if bias else 0.0)
-    y64 = {'relu': torch.relu, 'tanh': torch.tanh, 'none': (lambda t: t)}[act](z)
+    y64 = {'relu': torch.relu, 'tanh': torch.tanh, 'none': (lambda t: t), 'gelu': gelu64}[act](z)
     assert _rel(y, y64) < _tol(dtype)
     dy = _rnd((M, N), dtype, 1.0, 5)
     y.backward(dy.cuda())

@@ -3,7 +3,7 @@ usage: python tools/shapes_md.py <stderr file> > profiles/roundN_gemm_shapes_ins
 import re
 import sys
 
-KIND = {0: 'gemm_kernel bf16 NT', 7: 'gemm_skinny_kernel (<= 16 rows)', 6: 'gemm_kernel fp32 TN', 1: 'gemm_kernel bf16 NN', 4: 'gemm_kernel fp32', 5: 'gemm_kernel fp32 NN', 8: 'gemm_ring_kernel<256x128>',
+KIND = {0: 'gemm_kernel bf16 NT', 7: 'gemm_skinny_kernel (<= 16 rows)', 9: 'wgrad_small_m_kernel (<= 16 rows)', 6: 'gemm_kernel fp32 TN', 1: 'gemm_kernel bf16 NN', 4: 'gemm_kernel fp32', 5: 'gemm_kernel fp32 NN', 8: 'gemm_ring_kernel<256x128>',
         12: 'gemm_pp_kernel (persistent, fwd+dgrad)', 13: 'gemm_ring_kernel<128x128>', 14: 'gemm_wgrad_pp_kernel (one gradient per launch)',
         15: 'gemm_wgrad_group_kernel (all gradients of a block call)', 16: 'gemm_pp_kernel MX-fp8',
         2: 'gemm_kernel bf16 TN', 10: 'gemm_wgrad_ring_kernel', 20: 'attention forward (not a GEMM: GFLOP = QK^T + PV)', 21: 'attention dQ', 22: 'attention dK/dV',
