@@ -98,4 +98,7 @@ int egv_attn_space_bwd(const egv::AttnArgs& a, int B, hipStream_t st);  // one-l
 bool egv_attn_time_fwd_ok(const egv::AttnArgs& a, int B);
 int egv_attn_time_fwd(const egv::AttnArgs& a, int B, hipStream_t st);   // egv_attn_time.hip: forward of those groups incl. the CLS query (partials + combination)
 int egv_attn_time_bwd(const egv::AttnArgs& a, int B, hipStream_t st);   // egv_attn_time.hip: one-launch backward of the <= 16-row groups (time attention)
+int egv_attn_fewkeys_fwd(const egv::AttnArgs& a, int B, hipStream_t st);   // egv_attn_cross.hip: many queries over <= 32 keys (image -> text), 1 if enqueued
+int egv_attn_fewkeys_bwd(const egv::AttnArgs& a, int B, hipStream_t st);   // ... dQ, dK, dV in one launch + the partial sum (a.ws: egv_attn_fewkeys_workspace_bytes)
+extern "C" long long egv_attn_fewkeys_workspace_bytes(int B, int G, int H, int q_n);
 void egv_attn_bwd_cls_reduce_launch(const egv::AttnArgs& a, int B, int self_term, hipStream_t st);

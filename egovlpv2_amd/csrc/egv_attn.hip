@@ -692,6 +692,10 @@ static int egv_attn_fwd_impl(int dtype, const egv_attn_desc* d, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     AttnArgs a = to_args(d);
     if (dtype == EGV_BF16 && a.nsplit == 1) {
+        if (egv_attn_fewkeys_fwd(a, d->B, st)) {    // many queries over <= 32 keys (image -> text cross attention): egv_attn_cross.hip
+            EGV_LAUNCH_CHECK();
+            return 0;
+        }
         if (d->ws && d->ws_bytes >= egv_attn_fwd_extra_workspace_bytes(d->B, d->G, d->H) && egv_attn_time_fwd(a, d->B, st)) {
             EGV_LAUNCH_CHECK();                  // <= 16-row groups (time attention): group rows and the CLS query in one launch + its combination
             return 0;
@@ -839,6 +843,10 @@ static int egv_attn_bwd_fused_impl(int dtype, const egv_attn_desc* d, void* stre
     a.nsplit = 1;
     if (d->ws && d->extra)
         EGV_CHECK(d->ws_bytes >= egv_attn_bwd_fused_workspace_bytes(d->B, d->G, d->H), "egv_attn_bwd_fused: workspace too small");
+    if (!d->extra && d->ws && d->ws_bytes >= egv_attn_fewkeys_workspace_bytes(d->B, d->G, d->H, d->q_n) && egv_attn_fewkeys_bwd(a, d->B, st)) {
+        EGV_LAUNCH_CHECK();                      // many queries over <= 32 keys, mask allowed (egv_attn_cross.hip)
+        return 0;
+    }
     if (!egv_attn_bwd_fused_mfma(a, d->B, st)) return 1;
     EGV_LAUNCH_CHECK();
     return 0;

@@ -1,0 +1,438 @@
+// Attention of MANY queries over FEW keys for gfx950 (bf16, head_dim 64, <= 32 keys): the image-to-text cross attention of a fused
+// SpaceTimeBlock (video_transformer.py:155-185 -- 25 096 video tokens attend to 32 text tokens under the additive text mask), forward
+// in one launch and backward (dQ, dK, dV) in one launch plus a partial sum.
+//
+// The generic kernels (egv_attn_mfma.hip) run this shape as a query-owned dQ launch, a key-owned dK/dV launch split over 15 query
+// chunks and its reduction -- 50 + 44 + 9 us for a problem whose operands are 77 MB of reads and 39 MB of writes.  Here, as in
+// egv_attn_time.hip:
+//   * K and V of one (sample, head) -- 32 rows x 128 bytes each -- are fetched once per wave, straight into MFMA fragment layout
+//     (lane (fr, fg): row fr, 16-byte chunks fg and fg + 4), and stay in registers while the wave walks 32 queries at a time;
+//   * scores are formed on the matrix pipe once per C layout: S^T = K Q^T (lane = query: the softmax statistics and
+//     dQ^T = K^T dS^T) and S = Q K^T (lane = key: dV^T = dO^T P, dK^T = Q^T dS); the C layout of a first product IS the B operand
+//     of the second with the reduction index permuted ([tile 0 rows fg*4..+3 | tile 1 rows fg*4..+3]), and the transposed A
+//     operands come from row-major LDS images through ds_read_b64_tr_b16 in the same permutation;
+//   * all keys of a row sit in the two tiles, so delta = sum_j P_j dP_j is formed from the products themselves (no O read, no
+//     common rounding offset: DESIGN.md section 4);
+//   * dK^T / dV^T accumulate in registers over the wave's queries, are summed over the workgroup's four waves through LDS and leave
+//     as ONE fp32 partial per workgroup; a second small launch sums the partials in a fixed order (deterministic, no atomics).
+// Rows past the end of a sample and keys past k_n are read as zeros through the buffer descriptors (out-of-range offsets); padding
+// queries carry lse = +inf, padding keys a mask of -inf.
+#include "egv_attn.h"
+#include <cstdlib>
+
+namespace egv {
+
+namespace {
+typedef __attribute__((ext_vector_type(4))) short x_s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short x_s16x8_t;
+constexpr int XP = 144;                          // row pitch (bytes) of the LDS images: 64 bf16 + 16 B pad
+constexpr int X_IMG = 32 * XP;                   // one 32-row operand image
+constexpr int X_STAGE = 16 * XP;                 // output staging image of a wave (16 rows)
+constexpr int X_NW = 4;                          // waves per workgroup
+constexpr int X_WLDS = 2 * X_IMG + X_STAGE + 256;   // backward, per wave: dO and Q images, staging, lse / delta of the 32 queries
+constexpr int X_RED_PITCH = 68;                  // float pitch of the cross-wave sum (conflict-free f32x4 rows)
+constexpr int X_BWD_LDS = X_IMG + X_NW * X_WLDS; // + the K image shared by the workgroup
+constexpr int X_FWD_LDS = X_IMG + X_NW * X_STAGE;
+static_assert(32 * X_RED_PITCH * 4 <= X_WLDS, "a wave's area holds one 32 x 64 fp32 matrix for the cross-wave sum");
+constexpr float X_LOG2E = 1.4426950408889634f;
+constexpr float X_LN2 = 0.6931471805599453f;
+constexpr unsigned int X_OOB = 0x80000000u;
+
+__device__ __forceinline__ float x_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ bf16x8_t x_bf(u32x4_t v) { return __builtin_bit_cast(bf16x8_t, v); }
+__device__ __forceinline__ bf16x8_t x_pack8(const f32x4_t& a, const f32x4_t& b) {
+    u32x4_t v = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+__device__ __forceinline__ float x_grp_sum(float v) {        // over the four lane groups of a column (lanes l, l^16, l^32, l^48)
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+__device__ __forceinline__ float x_grp_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ f32x4_t x_mfma(bf16x8_t a, bf16x8_t b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+// A operand of a second-stage product for head dims dt*16 .. +15 over 32 rows of a row-major image:
+// [X^T[d][rows fg*4 .. +3] | X^T[d][rows 16 + fg*4 .. +3]]
+__device__ __forceinline__ bf16x8_t x_afrag(const unsigned char* img, int dt, int fr, int fg) {
+    const unsigned char* p = img + (fg * 4 + (fr >> 2)) * XP + (dt * 16 + (fr & 3) * 4) * 2;
+    const x_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) x_s16x4_t*)(p));
+    const x_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) x_s16x4_t*)(p + 16 * XP));
+    const x_s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+__device__ __forceinline__ void x_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// o[dt] (C layout: column = row fr of the output, head dims dt*16 + fg*4 .. +3) -> 16 rows x 128 contiguous bytes through the wave's
+// staging image: a store instruction writes 16 rows x 64 contiguous bytes
+__device__ __forceinline__ void x_store_rows(unsigned char* img, __amdgpu_buffer_rsrc_t r, unsigned int off, const f32x4_t (&o)[4], float s,
+                                             int fr, int fg) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const u32x2_t pk = {pack_bf16x2(o[dt][0] * s, o[dt][1] * s), pack_bf16x2(o[dt][2] * s, o[dt][3] * s)};
+        *reinterpret_cast<u32x2_t*>(img + fr * XP + dt * 32 + fg * 8) = pk;
+    }
+    x_wave_sync();
+    const u32x4_t lo = *reinterpret_cast<const u32x4_t*>(img + fr * XP + fg * 16), hi = *reinterpret_cast<const u32x4_t*>(img + fr * XP + 64 + fg * 16);
+    __builtin_amdgcn_raw_buffer_store_b128(lo, r, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(hi, r, off + (off == X_OOB ? 0u : 64u), 0, 0);
+}
+}  // namespace
+
+// grid: (workgroups per (sample, group, head), B*G*H); a workgroup's wave w takes the 32-query tiles (it * 4 + w), it < iters
+__global__ __launch_bounds__(256) void attn_fewkeys_fwd_kernel(const AttnArgs a, int iters, unsigned int q_bytes, unsigned int kv_bytes,
+                                                               unsigned int o_bytes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, w = wave_id();
+    const int fr = lane & 15, fg = lane >> 4;
+    const int h = blockIdx.y % a.H, pg = blockIdx.y / a.H, b = pg / a.G, g = pg % a.G;
+    unsigned char* sV = smem;
+    unsigned char* sS = smem + X_IMG + w * X_STAGE;
+    const int nq = a.q.n, nk = a.k.n;
+    const float sc2 = a.scale * X_LOG2E;
+    const int krow0 = (int)(b * a.k.bs + a.k.base + g * a.k.gs), qrow0 = (int)(b * a.q.bs + a.q.base + g * a.q.gs);
+
+    auto mk = [&](const void* p, unsigned int bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000); };
+    const __amdgpu_buffer_rsrc_t rQ = mk(a.Q, q_bytes), rK = mk(a.K, kv_bytes), rV = mk(a.V, kv_bytes), rO = mk(a.O, o_bytes);
+    auto ld = [&](__amdgpu_buffer_rsrc_t r, unsigned int off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); };
+
+    u32x4_t k[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int key = kt * 16 + fr;
+        const unsigned int off = key < nk ? (unsigned int)((krow0 + key) * a.ldk + a.koff + h * HD + fg * 8) * 2u : X_OOB;
+        k[kt][0] = ld(rK, off);
+        k[kt][1] = ld(rK, off + 64);
+    }
+    if (w < 2) {                                                    // the V image: waves 0 and 1 bring one 16-row tile each
+        const int key = w * 16 + fr;
+        const unsigned int off = key < nk ? (unsigned int)((krow0 + key) * a.ldv + a.voff + h * HD + fg * 8) * 2u : X_OOB;
+        const u32x4_t v0 = ld(rV, off), v1 = ld(rV, off + 64);
+        *reinterpret_cast<u32x4_t*>(sV + key * XP + fg * 16) = v0;
+        *reinterpret_cast<u32x4_t*>(sV + key * XP + 64 + fg * 16) = v1;
+    }
+    float mq[2][4];                                                 // additive mask (log2 domain) of the lane's keys kt*16 + fg*4 + r
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = kt * 16 + fg * 4 + r;
+            mq[kt][r] = key < nk ? (a.mask ? a.mask[(long long)b * a.mask_ld + key] * X_LOG2E : 0.f) : -INFINITY;
+        }
+    __syncthreads();
+    bf16x8_t av[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) av[dt] = x_afrag(sV, dt, fr, fg);
+
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    const int q_begin = blockIdx.x * (X_NW * iters * 32);
+    for (int it = 0; it < iters; ++it) {
+        const int q0 = q_begin + (it * X_NW + w) * 32;
+        if (q0 >= nq) break;
+        u32x4_t q[2][2];
+        unsigned int oo[2];
+        int rows[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int qi = q0 + t * 16 + fr;
+            const bool valid = qi < nq;
+            rows[t] = valid ? qrow0 + qi : -1;
+            const unsigned int oq = valid ? (unsigned int)((qrow0 + qi) * a.ldq + a.qoff + h * HD + fg * 8) * 2u : X_OOB;
+            oo[t] = valid ? (unsigned int)((qrow0 + qi) * a.ldo + a.ooff + h * HD + fg * 8) * 2u : X_OOB;
+            q[t][0] = ld(rQ, oq);
+            q[t][1] = ld(rQ, oq + 64);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4_t s0 = x_mfma(x_bf(k[0][1]), x_bf(q[t][1]), x_mfma(x_bf(k[0][0]), x_bf(q[t][0]), zero));     // keys 0..15 x the tile's queries
+            f32x4_t s1 = x_mfma(x_bf(k[1][1]), x_bf(q[t][1]), x_mfma(x_bf(k[1][0]), x_bf(q[t][0]), zero));     // keys 16..31
+            float m = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s0[r] = fmaf(s0[r], sc2, mq[0][r]);
+                s1[r] = fmaf(s1[r], sc2, mq[1][r]);
+                m = fmaxf(m, fmaxf(s0[r], s1[r]));
+            }
+            m = x_grp_max(m);
+            if (m == -INFINITY) m = 0.f;                              // (a row whose keys are all masked out by -inf: zeros, not NaN)
+            f32x4_t p0, p1;
+            float l = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p0[r] = x_exp2(s0[r] - m);
+                p1[r] = x_exp2(s1[r] - m);
+                l += p0[r] + p1[r];
+            }
+            l = x_grp_sum(l);
+            const bf16x8_t bP = x_pack8(p0, p1);
+            f32x4_t o[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = x_mfma(av[dt], bP, zero);
+            x_store_rows(sS, rO, oo[t], o, l > 0.f ? 1.0f / l : 0.f, fr, fg);
+            if (a.lse && rows[t] >= 0 && fg == 0) a.lse[(long long)rows[t] * a.H + h] = m * X_LN2 + __logf(l);
+        }
+    }
+}
+
+// grid as above; part: fp32 partial dK^T-then-dV^T sums, [problem][workgroup][dK | dV][32 keys][64]
+__global__ __launch_bounds__(256) void attn_fewkeys_bwd_kernel(const AttnArgs a, int iters, unsigned int q_bytes, unsigned int kv_bytes,
+                                                               unsigned int o_bytes, unsigned int dq_bytes, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, w = wave_id();
+    const int fr = lane & 15, fg = lane >> 4;
+    const int h = blockIdx.y % a.H, pg = blockIdx.y / a.H, b = pg / a.G, g = pg % a.G;
+    unsigned char* sK = smem;
+    unsigned char* sG = smem + X_IMG + w * X_WLDS;                  // dO rows of the wave's 32 queries
+    unsigned char* sQ = sG + X_IMG;
+    unsigned char* sS = sQ + X_IMG;
+    float* sL = reinterpret_cast<float*>(sS + X_STAGE);             // lse (log2 domain) of the 32 queries, then their delta
+    float* sD = sL + 32;
+    const int nq = a.q.n, nk = a.k.n;
+    const float sc2 = a.scale * X_LOG2E;
+    const int krow0 = (int)(b * a.k.bs + a.k.base + g * a.k.gs), qrow0 = (int)(b * a.q.bs + a.q.base + g * a.q.gs);
+
+    auto mk = [&](const void* p, unsigned int bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000); };
+    const __amdgpu_buffer_rsrc_t rQ = mk(a.Q, q_bytes), rK = mk(a.K, kv_bytes), rV = mk(a.V, kv_bytes), rG = mk(a.dO, o_bytes);
+    const __amdgpu_buffer_rsrc_t rDQ = mk(a.dQ, dq_bytes);
+    auto ld = [&](__amdgpu_buffer_rsrc_t r, unsigned int off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); };
+
+    u32x4_t k[2][2], v[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int key = kt * 16 + fr;
+        const unsigned int ok_ = key < nk ? (unsigned int)((krow0 + key) * a.ldk + a.koff + h * HD + fg * 8) * 2u : X_OOB;
+        const unsigned int ov_ = key < nk ? (unsigned int)((krow0 + key) * a.ldv + a.voff + h * HD + fg * 8) * 2u : X_OOB;
+        k[kt][0] = ld(rK, ok_);
+        k[kt][1] = ld(rK, ok_ + 64);
+        v[kt][0] = ld(rV, ov_);
+        v[kt][1] = ld(rV, ov_ + 64);
+    }
+    if (w < 2) {                                                    // the K image (for K^T): waves 0 and 1 write one tile each
+        *reinterpret_cast<u32x4_t*>(sK + (w * 16 + fr) * XP + fg * 16) = w == 0 ? k[0][0] : k[1][0];
+        *reinterpret_cast<u32x4_t*>(sK + (w * 16 + fr) * XP + 64 + fg * 16) = w == 0 ? k[0][1] : k[1][1];
+    }
+    float mq[2][4], mkk[2];                                         // additive mask (log2 domain): lane = query layout, lane = key layout
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = kt * 16 + fg * 4 + r;
+            mq[kt][r] = key < nk ? (a.mask ? a.mask[(long long)b * a.mask_ld + key] * X_LOG2E : 0.f) : -INFINITY;
+        }
+        const int key = kt * 16 + fr;
+        mkk[kt] = key < nk ? (a.mask ? a.mask[(long long)b * a.mask_ld + key] * X_LOG2E : 0.f) : -INFINITY;
+    }
+    __syncthreads();
+
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t dk[2][4], dv[2][4];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dk[kt][dt] = zero; dv[kt][dt] = zero; }
+
+    const int q_begin = blockIdx.x * (X_NW * iters * 32);
+    for (int it = 0; it < iters; ++it) {
+        const int q0 = q_begin + (it * X_NW + w) * 32;
+        if (q0 >= nq) break;                                        // (wave-uniform; the wave still takes part in the sum below)
+        u32x4_t q[2][2], gq[2][2];
+        float lse2[2];
+        unsigned int odq[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int qi = q0 + t * 16 + fr;
+            const bool valid = qi < nq;
+            const int row = qrow0 + qi;
+            const unsigned int oq = valid ? (unsigned int)(row * a.ldq + a.qoff + h * HD + fg * 8) * 2u : X_OOB;
+            const unsigned int og = valid ? (unsigned int)(row * a.ldo + a.ooff + h * HD + fg * 8) * 2u : X_OOB;
+            odq[t] = valid ? (unsigned int)(row * a.lddq + a.dqoff + h * HD + fg * 8) * 2u : X_OOB;
+            q[t][0] = ld(rQ, oq);
+            q[t][1] = ld(rQ, oq + 64);
+            gq[t][0] = ld(rG, og);
+            gq[t][1] = ld(rG, og + 64);
+            lse2[t] = valid ? a.lse[(long long)row * a.H + h] * X_LOG2E : INFINITY;    // padding queries: exp2(s - inf) = 0
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            *reinterpret_cast<u32x4_t*>(sQ + (t * 16 + fr) * XP + fg * 16) = q[t][0];
+            *reinterpret_cast<u32x4_t*>(sQ + (t * 16 + fr) * XP + 64 + fg * 16) = q[t][1];
+            *reinterpret_cast<u32x4_t*>(sG + (t * 16 + fr) * XP + fg * 16) = gq[t][0];
+            *reinterpret_cast<u32x4_t*>(sG + (t * 16 + fr) * XP + 64 + fg * 16) = gq[t][1];
+        }
+        // ================= lane = query: S^T[key][query] -> delta, dQ^T = K^T dS^T =================
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4_t s[2], d[2], ds[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                s[kt] = x_mfma(x_bf(k[kt][1]), x_bf(q[t][1]), x_mfma(x_bf(k[kt][0]), x_bf(q[t][0]), zero));
+                d[kt] = x_mfma(x_bf(v[kt][1]), x_bf(gq[t][1]), x_mfma(x_bf(v[kt][0]), x_bf(gq[t][0]), zero));
+            }
+            float dl = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = x_exp2(fmaf(s[kt][r], sc2, mq[kt][r] - lse2[t]));
+                    s[kt][r] = p;
+                    dl = fmaf(p, d[kt][r], dl);
+                }
+            dl = x_grp_sum(dl);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ds[kt][r] = s[kt][r] * (d[kt][r] - dl);
+            if (fg == 0) { sL[t * 16 + fr] = lse2[t]; sD[t * 16 + fr] = dl; }
+            const bf16x8_t bP = x_pack8(ds[0], ds[1]);
+            f32x4_t dq[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dq[dt] = x_mfma(x_afrag(sK, dt, fr, fg), bP, zero);
+            x_store_rows(sS, rDQ, odq[t], dq, a.scale, fr, fg);
+        }
+        x_wave_sync();
+        // ================= lane = key: S[query][key] -> dV^T = dO^T P, dK^T = Q^T dS =================
+        bf16x8_t bV[2], bK[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x4_t p2[2], ds2[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const f32x4_t s = x_mfma(x_bf(q[t][1]), x_bf(k[kt][1]), x_mfma(x_bf(q[t][0]), x_bf(k[kt][0]), zero));
+                const f32x4_t d = x_mfma(x_bf(gq[t][1]), x_bf(v[kt][1]), x_mfma(x_bf(gq[t][0]), x_bf(v[kt][0]), zero));
+                const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(sL + t * 16 + fg * 4), dl4 = *reinterpret_cast<const f32x4_t*>(sD + t * 16 + fg * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {                        // query t*16 + fg*4 + r (padding queries: lse = +inf -> p = 0)
+                    const float p = x_exp2(fmaf(s[r], sc2, mkk[kt] - l4[r]));
+                    p2[t][r] = p;
+                    ds2[t][r] = p * (d[r] - dl4[r]);
+                }
+            }
+            bV[kt] = x_pack8(p2[0], p2[1]);
+            bK[kt] = x_pack8(ds2[0], ds2[1]);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const bf16x8_t ag = x_afrag(sG, dt, fr, fg), aq = x_afrag(sQ, dt, fr, fg);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                dv[kt][dt] = x_mfma(ag, bV[kt], dv[kt][dt]);
+                dk[kt][dt] = x_mfma(aq, bK[kt], dk[kt][dt]);
+            }
+        }
+        x_wave_sync();                                               // the images are rewritten by the next trip
+    }
+
+    // ---- sum of the four waves' dK^T, then dV^T (lane (fr, fg): key kt*16 + fr, head dims dt*16 + fg*4 .. +3), one partial per workgroup
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem + X_IMG + w * X_WLDS);
+    float* dst = part + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 2 * 32 * HD;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<f32x4_t*>(red + (kt * 16 + fr) * X_RED_PITCH + dt * 16 + fg * 4) = pass == 0 ? dk[kt][dt] : dv[kt][dt];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int e = threadIdx.x + j * 256, key = e >> 4, c4 = e & 15;
+            f32x4_t s = zero;
+#pragma unroll
+            for (int ww = 0; ww < X_NW; ++ww)
+                s += *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(smem + X_IMG + ww * X_WLDS) + key * X_RED_PITCH + c4 * 4);
+            *reinterpret_cast<f32x4_t*>(dst + pass * 32 * HD + key * HD + c4 * 4) = s;
+        }
+        __syncthreads();
+    }
+}
+
+// one workgroup per (sample, group, head): dK = scale * sum of the partials, dV = their sum, in workgroup order
+__global__ __launch_bounds__(256) void attn_fewkeys_reduce_kernel(const AttnArgs a, int nwg, const float* __restrict__ part) {
+    const int h = blockIdx.x % a.H, pg = blockIdx.x / a.H, b = pg / a.G, g = pg % a.G;
+    const long long krow0 = b * a.k.bs + a.k.base + g * a.k.gs;
+    const float* src = part + (long long)blockIdx.x * nwg * 2 * 32 * HD;
+    for (int e = threadIdx.x; e < 1024; e += 256) {
+        const int pass = e >> 9, key = (e & 511) >> 4, c4 = e & 15;
+        f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+        for (int wg = 0; wg < nwg; ++wg) s += *reinterpret_cast<const f32x4_t*>(src + ((long long)wg * 2 + pass) * 32 * HD + key * HD + c4 * 4);
+        if (key >= a.k.n) continue;
+        const float sc = pass == 0 ? a.scale : 1.0f;
+        const u32x2_t pk = {pack_bf16x2(s[0] * sc, s[1] * sc), pack_bf16x2(s[2] * sc, s[3] * sc)};
+        bf16_t* out = reinterpret_cast<bf16_t*>(pass == 0 ? a.dK : a.dV);
+        const long long off = (krow0 + key) * (pass == 0 ? a.lddk : a.lddv) + (pass == 0 ? a.dkoff : a.dvoff) + h * HD + c4 * 4;
+        *reinterpret_cast<u32x2_t*>(out + off) = pk;
+    }
+}
+
+}  // namespace egv
+using namespace egv;
+
+namespace {
+int fewkeys_iters() {
+    static const int it = egv_cfg_int("EGV_ATTN_FEWKEYS_ITERS", 2);
+    return it < 1 ? 1 : (it > 64 ? 64 : it);
+}
+bool fewkeys_shape_ok(const AttnArgs& a, int B, bool bwd) {
+    static const bool on = egv_cfg_on("EGV_ATTN_FEWKEYS", true);
+    auto ok8 = [](int x) { return (x % 8) == 0; };
+    if (!on || a.extra || a.drop_p > 0.f || a.nsplit > 1 || a.O32) return false;
+    if (a.k.n < 1 || a.k.n > 32 || a.q.n < 128 || a.q.is != 1 || a.k.is != 1) return false;
+    if (!(ok8(a.ldq) && ok8(a.ldk) && ok8(a.ldv) && ok8(a.ldo) && ok8(a.qoff) && ok8(a.koff) && ok8(a.voff) && ok8(a.ooff))) return false;
+    if (a.mask && a.mask_ld < a.k.n) return false;
+    if (bwd) {
+        if (!a.dO || !a.lse || !a.dQ || !a.dK || !a.dV || !ok8(a.lddq) || !ok8(a.dqoff)) return false;
+        if ((a.lddk % 4) || (a.lddv % 4) || (a.dkoff % 4) || (a.dvoff % 4)) return false;
+    } else if (!a.O) return false;
+    // 32-bit byte offsets: the row sets must describe matrices of < 2 GB (rows of the last sample / group included)
+    const long long qrows = (long long)(B - 1) * a.q.bs + a.q.base + (long long)(a.G - 1) * a.q.gs + a.q.n;
+    const long long krows = (long long)(B - 1) * a.k.bs + a.k.base + (long long)(a.G - 1) * a.k.gs + a.k.n;
+    const long long ldq_max = a.ldq > a.ldo ? a.ldq : a.ldo, ldk_max = a.ldk > a.ldv ? a.ldk : a.ldv;
+    if (qrows * ldq_max * 2 >= (1LL << 31) || krows * ldk_max * 2 >= (1LL << 31)) return false;
+    if (bwd && qrows * a.lddq * 2 >= (1LL << 31)) return false;
+    return true;
+}
+inline long long q_rows(const AttnArgs& a, int B) { return (long long)(B - 1) * a.q.bs + a.q.base + (long long)(a.G - 1) * a.q.gs + a.q.n; }
+inline long long k_rows(const AttnArgs& a, int B) { return (long long)(B - 1) * a.k.bs + a.k.base + (long long)(a.G - 1) * a.k.gs + a.k.n; }
+}  // namespace
+
+// workgroups per (sample, group, head) and the bytes of the backward's partial sums
+int egv_attn_fewkeys_nwg(int q_n) {
+    const int per = X_NW * fewkeys_iters() * 32;
+    return (q_n + per - 1) / per;
+}
+extern "C" long long egv_attn_fewkeys_workspace_bytes(int B, int G, int H, int q_n) {
+    return (long long)B * G * H * egv_attn_fewkeys_nwg(q_n) * 2 * 32 * HD * 4;
+}
+
+// 1 if enqueued
+int egv_attn_fewkeys_fwd(const AttnArgs& a, int B, hipStream_t st) {
+    if (!fewkeys_shape_ok(a, B, false)) return 0;
+    const long long qr = q_rows(a, B), kr = k_rows(a, B);
+    const int nwg = egv_attn_fewkeys_nwg(a.q.n);
+    const long long kvb = kr * (a.ldk > a.ldv ? a.ldk : a.ldv) * 2;
+    hipLaunchKernelGGL(attn_fewkeys_fwd_kernel, dim3(nwg, B * a.G * a.H), dim3(256), X_FWD_LDS, st, a, fewkeys_iters(), (unsigned int)(qr * a.ldq * 2),
+                       (unsigned int)kvb, (unsigned int)(qr * a.ldo * 2));
+    return 1;
+}
+
+// 1 if enqueued (dQ, dK, dV; a.ws: >= egv_attn_fewkeys_workspace_bytes, checked by the caller)
+int egv_attn_fewkeys_bwd(const AttnArgs& a, int B, hipStream_t st) {
+    if (!a.ws || !fewkeys_shape_ok(a, B, true)) return 0;
+    const long long qr = q_rows(a, B), kr = k_rows(a, B);
+    const int nwg = egv_attn_fewkeys_nwg(a.q.n);
+    const long long kvb = kr * (a.ldk > a.ldv ? a.ldk : a.ldv) * 2;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fewkeys_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, X_BWD_LDS);
+        attr = true;
+    }
+    hipLaunchKernelGGL(attn_fewkeys_bwd_kernel, dim3(nwg, B * a.G * a.H), dim3(256), X_BWD_LDS, st, a, fewkeys_iters(), (unsigned int)(qr * a.ldq * 2),
+                       (unsigned int)kvb, (unsigned int)(qr * a.ldo * 2), (unsigned int)(qr * a.lddq * 2), a.ws);
+    hipLaunchKernelGGL(attn_fewkeys_reduce_kernel, dim3(B * a.G * a.H), dim3(256), 0, st, a, nwg, a.ws);
+    return 1;
+}

@@ -225,11 +225,13 @@ struct Plain {
     unsigned int drop_seed;
     const float* mask;                              // [B, nk] additive fp32 or NULL
     int fwd_ns() const { return nk <= 224 ? 1 : (nk + 223) / 224; }
+    bool mask_ok_fused() const { return drop_p <= 0.f && nq >= 128; }
     int dkv_ns() const { return nq <= 224 ? 1 : (nq + 223) / 224; }
     long long ws_bytes() const {
         long long a = egv_attn_split_workspace_bytes(0, B, 1, H, nq, fwd_ns()), b = egv_attn_split_workspace_bytes(1, B, 1, H, nq, fwd_ns()),
                   c = egv_attn_bwd_dkv_workspace_bytes(B, 1, H, nk, dkv_ns());
         long long m = a > b ? a : b;
+        if (nk <= 32 && egv_attn_fewkeys_workspace_bytes(B, 1, H, nq) > m) m = egv_attn_fewkeys_workspace_bytes(B, 1, H, nq);
         return m > c ? m : c;
     }
     void fill(egv_attn_desc& d, const void* q, int ldq, const void* k, const void* v, int ldkv, void* O, float* lse) const {
@@ -260,6 +262,10 @@ struct Plain {
         d.O32 = dt == EGV_BF16 ? const_cast<float*>(o32) : nullptr;
         d.dO = dO; d.dQ = dq; d.dK = dk; d.dV = dv; d.lddq = lddq; d.lddk = d.lddv = lddkv; d.delta = delta;
         d.nsplit = fwd_ns(); d.ws = (float*)ws; d.ws_bytes = wsb;
+        if (nk <= 32 && mask_ok_fused()) {                          // many queries over <= 32 keys: one launch (egv_attn_cross.hip)
+            const int r = egv_attn_bwd_fused(dt, &d, st);
+            if (r <= 0) return r;
+        }
         BCHK(egv_attn_bwd_dq(dt, &d, st));
         d.nsplit = dkv_ns();
         return egv_attn_bwd_dkv(dt, &d, st);

@@ -885,6 +885,15 @@ class PlainAttnFn(Function):
         delta = torch.empty(B * nq, H, dtype=torch.float32, device=q.device)
         qs, ks = _rowset(nq, 0, 0, 1, nq), _rowset(nk, 0, 0, 1, nk)
         kw = dict(mask=mask, dO=dO, dQ=dq, dK=dk, dV=dv, delta=delta, drop_p=drop_p, drop_seed=drop_seed)
+        if q.dtype == torch.bfloat16 and nk <= 32 and nq >= 128 and drop_p <= 0.0:
+            # many queries over few keys (image -> text): dQ, dK, dV in one launch + a fixed-order partial sum (egv_attn_cross.hip)
+            nb = lib.egv_attn_fewkeys_workspace_bytes(B, 1, H, nq)
+            ws = torch.empty(nb // 4, dtype=torch.float32, device=q.device)
+            d = _mk_desc(q, k, v, O, lse, B, 1, H, qs, ks, None, scale, nsplit=1, ws=ws, ws_bytes=nb, **kw)
+            rc = lib.egv_attn_bwd_fused(_dt(q), C.byref(d), _st())
+            if rc != 1:
+                check(rc, 'egv_attn_bwd_fused(few keys)')
+                return dq, dk, dv, None, None, None, None, None, None, None, None, None
         ns = 1 if nk <= 224 else (nk + 223) // 224
         ws, nb = _split_ws(1, B, 1, H, nq, ns, q.device)
         d = _mk_desc(q, k, v, O, lse, B, 1, H, qs, ks, None, scale, nsplit=ns, ws=ws, ws_bytes=nb, **kw)

@@ -29,10 +29,36 @@ from .. import hipops as ops
 from .. import switches as SW
 
 
+def allreduce_bf16_wire(flat, group=None):
+    """Sum over the ranks of an fp32 buffer, in place, MOVED as bf16 and ACCUMULATED in fp32 on arrival (half the bytes of the fp32
+    all-reduce on the per-link-bound xGMI ring): every rank sends shard q of its buffer, rounded to bf16, to rank q (all-to-all); rank q
+    adds the `world` copies of its shard in fp32, in rank order, rounds the sum once and all-gathers it.  Every rank ends with the
+    same bits (the shard's owner forms the sum; nobody else does), so replicas do not drift apart.  Error: two bf16 roundings per
+    element (2^-9 relative each) instead of none -- an OPTION (FlatGradSync(wire='bf16')); fp32 stays the default until a node has
+    measured both."""
+    world = dist.get_world_size(group)
+    n = flat.numel()
+    per = -(-n // world)
+    send = torch.zeros(world * per, dtype=torch.bfloat16, device=flat.device)
+    send[:n].copy_(flat)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    part = recv.view(world, per).float().sum(0).to(torch.bfloat16)
+    dist.all_gather_into_tensor(send, part, group=group)
+    flat.copy_(send[:n])
+    return flat
+
+
 class FlatGradSync:
-    def __init__(self, model, group=None):
+    def __init__(self, model, group=None, wire=None):
+        """wire: 'fp32' (default; in-place all-reduce of the flat buffers) or 'bf16' (allreduce_bf16_wire: bf16 on the links, fp32
+        accumulation on arrival); EGV_SYNC_WIRE overrides the default."""
         self.model = model
         self.group = group
+        self.wire = wire or os.environ.get('EGV_SYNC_WIRE', 'fp32')
+        if self.wire not in ('fp32', 'bf16'):
+            raise ValueError(f"FlatGradSync: wire must be 'fp32' or 'bf16', not {self.wire!r}")
+        self._side = None
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         # EGV_SYNC_FORCE=1 (test aid): issue the collectives even in a one-rank group, to run the RCCL code path on a 1-GPU box
         self.comm = self.world > 1 or (SW.on('EGV_SYNC_FORCE') and dist.is_available() and dist.is_initialized())
@@ -45,7 +71,22 @@ class FlatGradSync:
         self._packed.update(id(p) for p in params)
         self._flats.append((flat, params))
         if self.comm:
-            self._works.append(dist.all_reduce(flat, group=self.group, async_op=True))
+            self._reduce(flat)
+
+    def _reduce(self, t):
+        if self.wire == 'fp32':
+            self._works.append(dist.all_reduce(t, group=self.group, async_op=True))
+        elif t.is_cuda:
+            # cast / exchange / sum / gather on a side stream ordered after the stream the buffer is complete on; the calling stream
+            # joins it once, at the end of backward
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                allreduce_bf16_wire(t.view(-1), self.group)
+            t.record_stream(self._side)
+        else:
+            allreduce_bf16_wire(t.view(-1), self.group)
 
     def backward(self, loss):
         """backward of loss / world with the gradient all-reduces issued as the block buffers complete; returns after every
@@ -58,9 +99,14 @@ class FlatGradSync:
             (loss * (1.0 / self.world)).backward()
             if self.comm:
                 rest = [p.grad for p in self.model.parameters() if p.grad is not None and id(p) not in self._packed]
-                self._works += [dist.all_reduce(g, group=self.group, async_op=True) for g in rest]
+                for g in rest:
+                    if not g.is_contiguous():
+                        raise RuntimeError("FlatGradSync: a parameter gradient outside the block buffers is not contiguous")
+                    self._reduce(g)
                 for w in self._works:
                     w.wait()
+                if self._side is not None:
+                    torch.cuda.current_stream().wait_stream(self._side)
             # The collectives ran IN PLACE on the flat buffers: that reaches p.grad only if autograd kept the views it was handed
             # (AccumulateGrad steals a gradient by reference when .grad is None, nothing else holds it and no hook is
             # registered).  A copy made instead would hold the un-reduced local values: check, do not assume.

@@ -200,6 +200,10 @@ int egv_attn_bwd_dkv(int dtype, const egv_attn_desc* d, void* stream);
  * the one-query egv_attn_bwd_dq and the one-key egv_attn_bwd_dkv launches of the CLS row. */
 long long egv_attn_bwd_fused_workspace_bytes(int B, int G, int H);
 int egv_attn_bwd_fused(int dtype, const egv_attn_desc* d, void* stream);
+/* Many queries over <= 32 keys (the image-to-text cross attention, video_transformer.py:155-185: q_n >= 128, unit row strides, additive
+ * key mask allowed, no extra row / dropout): egv_attn_fwd takes a one-launch kernel for it, and egv_attn_bwd_fused one launch for dQ, dK, dV
+ * plus a fixed-order sum of per-workgroup partials when d->ws holds >= egv_attn_fewkeys_workspace_bytes (d->delta is not read). */
+long long egv_attn_fewkeys_workspace_bytes(int B, int G, int H, int q_n);
 /* The same for launches whose groups are one 16-row tile (the 17-row time attention), on the dQ + dK/dV kernel pair: when
  * egv_attn_bwd_pair_covers_extra returns 1 for a descriptor with d->ws set, egv_attn_bwd_dq and egv_attn_bwd_dkv leave the extra
  * row's gradients as per-group partials and egv_attn_bwd_extra_reduce(self_term = 1) sums them (adding the extra-query x

@@ -115,3 +115,41 @@ def test_negative_clip_token_exchange_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _wire_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from egovlpv2_amd.trainer.grad_sync import allreduce_bf16_wire
+    ok = True
+    for n in (1, 7, 4096, 100003):                                    # ragged sizes: the last shard is padded
+        locals_ = [torch.randn(n, generator=torch.Generator().manual_seed(7 * n + r)) * (1 + r) for r in range(world)]
+        flat = locals_[rank].clone()
+        allreduce_bf16_wire(flat)
+        # what the option promises: each element = bf16(sum over ranks, in rank order, of bf16(local)), the same bits on every rank
+        want = torch.stack([t.to(torch.bfloat16).float() for t in locals_]).sum(0).to(torch.bfloat16).float()
+        ok = ok and torch.equal(flat, want)
+        exact = torch.stack(locals_).sum(0)
+        ok = ok and float((flat - exact).norm() / exact.norm()) < 2 ** -7
+        both = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        ok = ok and all(torch.equal(b, flat) for b in both)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_bf16_wire_gradient_sum_world2():
+    """trainer/grad_sync.py::allreduce_bf16_wire (FlatGradSync(wire='bf16'), SURVEY.md 8e): bf16 on the links, fp32 accumulation on
+    arrival, identical bits on every rank."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29300 + (os.getpid() % 250)
+    procs = [ctx.Process(target=_wire_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]

@@ -283,6 +283,48 @@ def test_plain_attention(ops, dtype, nq, nk, masked, nsplit):
     assert _rel(kv.grad, kv64.grad) < _tol(dtype, True)
 
 
+@pytest.mark.parametrize('nq,nk,masked', [(3137, 32, True), (200, 20, True), (128, 32, False), (1000, 7, False)])
+def test_many_queries_few_keys_attention_bf16(ops, nq, nk, masked, monkeypatch):
+    """image -> text cross attention shapes (video_transformer.py:155-185) on the one-launch kernels of egv_attn_cross.hip, against fp64:
+    full size per sample (3137 queries, 32 keys, text mask), ragged query and key counts, no mask."""
+    B, H = 2, 3
+    D = H * 64
+    q = _rnd((B * nq, D), torch.bfloat16, 1.0, 11).cuda().requires_grad_(True)
+    kv = _rnd((B * nk, 2 * D), torch.bfloat16, 1.0, 12).cuda().requires_grad_(True)
+    mask = None
+    if masked:
+        m = torch.ones(B, nk)
+        m[0, nk // 2:] = 0
+        m[1, -1] = 0
+        mask = ((1 - m) * -10000.0).cuda()
+    o = ops.plain_attention(q, kv[:, :D], kv[:, D:], B, H, nq, nk, 0.125, mask=mask)
+    q64 = q.detach().double().cpu().requires_grad_(True)
+    kv64 = kv.detach().double().cpu().requires_grad_(True)
+    qh = q64.reshape(B, nq, H, 64).transpose(1, 2)
+    kh = kv64[:, :D].reshape(B, nk, H, 64).transpose(1, 2)
+    vh = kv64[:, D:].reshape(B, nk, H, 64).transpose(1, 2)
+    s = (qh @ kh.transpose(-1, -2)) * 0.125
+    if masked:
+        s = s + mask.double().cpu().view(B, 1, 1, nk)
+    o64 = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B * nq, D)
+    assert _rel(o, o64) < _tol(torch.bfloat16)
+    do = _rnd((B * nq, D), torch.bfloat16, 1.0, 13)
+    o.backward(do.cuda())
+    o64.backward(do.double())
+    assert _rel(q.grad, q64.grad) < _tol(torch.bfloat16, True)
+    assert _rel(kv.grad, kv64.grad) < _tol(torch.bfloat16, True)
+    # rows of one sample must not leak into the next: the last query rows of sample 0 and the first of sample 1, row by row
+    for r in (nq - 1, nq, B * nq - 1):
+        assert _rel(o[r], o64[r]) < 2 * _tol(torch.bfloat16)
+        assert _rel(q.grad[r], q64.grad[r]) < 3 * _tol(torch.bfloat16, True)
+    # deterministic: a second backward pass gives the same bits (fixed-order partial sums, no atomics)
+    g1 = kv.grad.clone()
+    kv.grad = None
+    q.grad = None
+    ops.plain_attention(q, kv[:, :D], kv[:, D:], B, H, nq, nk, 0.125, mask=mask).backward(do.cuda())
+    assert torch.equal(g1, kv.grad)
+
+
 def _attn_keep_mult(ops, dtype, B, H, nq, nk, p, seed):
     """Recover the kernels' dropout multiplier M[b,h,q,k] (0 or 1/(1-p)): with Q = K = 0 the probabilities are uniform, and
     with V = identity on a 64-key chunk O[q, d] = M[q, chunk*64 + d] / nk.  The mask is a function of indices only."""

@@ -211,6 +211,18 @@ def _nccl_worker(port, q):
             assert table == [sorted({j for j in ids if j >= bsz})], table
             assert torch.equal(flat, ref) and torch.equal(g, t)
         out['table'] = 'ok'
+        # (b) the bf16-wire gradient sum (grad_sync.allreduce_bf16_wire) on RCCL's all-to-all / all-gather, from a side stream as
+        # FlatGradSync(wire='bf16') issues it: with one rank the result is the bf16 rounding of the buffer
+        from egovlpv2_amd.trainer.grad_sync import allreduce_bf16_wire
+        flat = torch.randn((1 << 20) + 3, device='cuda')
+        want = flat.to(torch.bfloat16).float()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            allreduce_bf16_wire(flat)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert torch.equal(flat, want)
+        out['wire'] = 'ok'
         q.put(('ok', out))
         dist.destroy_process_group()
     except Exception:

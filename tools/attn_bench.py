@@ -35,3 +35,19 @@ try:
     lib.egv_debug_attn(0)
 except Exception:
     pass
+
+# image -> text cross attention of a fused block (25 096 queries over 32 masked text keys): EGV_ATTN_FEWKEYS=0/1, EGV_ATTN_FEWKEYS_ITERS
+L = 32
+q = torch.randn(B * S, H * 64, device='cuda').bfloat16().requires_grad_(True)
+kv = torch.randn(B * L, 2 * H * 64, device='cuda').bfloat16().requires_grad_(True)
+mask = torch.zeros(B, L, device='cuda')
+mask[:, 20:] = -10000.0
+D = H * 64
+f = lambda: ops.plain_attention(q.detach(), kv.detach()[:, :D], kv.detach()[:, D:], B, H, S, L, 0.125, mask=mask)
+t_f = timeit(f)
+o = ops.plain_attention(q, kv[:, :D], kv[:, D:], B, H, S, L, 0.125, mask=mask)
+def fb():
+    q.grad = None; kv.grad = None
+    o.backward(do, retain_graph=True)
+t_b = timeit(fb)
+print(f"i2t FEWKEYS={os.environ.get('EGV_ATTN_FEWKEYS', '1')} ITERS={os.environ.get('EGV_ATTN_FEWKEYS_ITERS', '2')}: fwd {t_f:7.1f} us   bwd {t_b:7.1f} us (incl. the autograd glue of a per-op call)", flush=True)

@@ -3,7 +3,7 @@ import subprocess, sys, re, os
 unit = sys.argv[1]
 src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'egovlpv2_amd', 'csrc')
 extra = sys.argv[2:]
-if unit in ('egv_attn_mfma', 'egv_attn_time', 'egv_attn_space'):
+if unit in ('egv_attn_mfma', 'egv_attn_time', 'egv_attn_space', 'egv_attn_cross'):
     extra += ['-mllvm', '-amdgpu-mfma-vgpr-form']
 cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I../../include', '-Wno-unused-value', '-Rpass-analysis=kernel-resource-usage',
        '-c', unit + '.hip', '-o', '/tmp/kres_%s.o' % unit] + extra
