@@ -139,7 +139,7 @@ def main():
     ap.add_argument('--grad-sync', default='flat', choices=['flat', 'ddp'],
                     help='world > 1: flat = all-reduce of the per-block flat gradient buffers as they complete (trainer/grad_sync.py); '
                          'ddp = torch DistributedDataParallel as in the reference')
-    ap.add_argument('--grad-wire', default='fp32', choices=['fp32', 'bf16'],
+    ap.add_argument('--grad-wire', default=None, choices=['fp32', 'bf16'],
                     help='--grad-sync flat: fp32 = in-place all-reduce (default), bf16 = bf16 on the links with fp32 accumulation on arrival '
                          '(grad_sync.allreduce_bf16_wire; half the bytes, two bf16 roundings per gradient element)')
     a = ap.parse_args()
@@ -392,7 +392,7 @@ def main():
                "config": {"workload": (("configs[2] full fusion EgoNCE+MLM+ITM" if a.arch == 'base16' else "full fusion EgoNCE+MLM+ITM") if a.workload == 'full' else "configs[1] dual encoder EgoNCE")
                           + (f", ViT-B/16 TimeSformer + RoBERTa-base" if a.arch == 'base16' else ", configs[4] geometry: ViT-L/14 TimeSformer + RoBERTa-large width, bf16 weights")
                           + f", B={a.batch}/GPU, {a.frames}x224^2, {a.text_len} tok",
-                          "global_batch": world * a.batch, "parallelism": f"dp{world}", "drop_rate": a.drop_rate, "timed": "zero_grad + fwd + bwd (+ gradient all-reduce: " + ((a.grad_sync + ("/bf16 wire" if a.grad_wire == "bf16" and a.grad_sync == "flat" else "")) if use_dist else "none") + "), weight cast included" + (" + fused AdamW step" if a.optimizer else "")},
+                          "global_batch": world * a.batch, "parallelism": f"dp{world}", "drop_rate": a.drop_rate, "timed": "zero_grad + fwd + bwd (+ gradient all-reduce: " + ((a.grad_sync + ("/bf16 wire" if getattr(gsync, "wire", "") == "bf16" else "")) if use_dist else "none") + "), weight cast included" + (" + fused AdamW step" if a.optimizer else "")},
                # model_tflops: the reference algorithm's matmul FLOPs per pair x pairs/s; executed_tflops leaves
                # out what skipped_flops_per_pair lists: the dead MLM video block, the ITM video prefix shared with the MLM pass, the
                # unread rows of the last block of the EgoNCE tower and of the ITM stack, the second patch embedding

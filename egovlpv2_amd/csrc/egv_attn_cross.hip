@@ -7,10 +7,13 @@
 // egv_attn_time.hip:
 //   * K and V of one (sample, head) -- 32 rows x 128 bytes each -- are fetched once per wave, straight into MFMA fragment layout
 //     (lane (fr, fg): row fr, 16-byte chunks fg and fg + 4), and stay in registers while the wave walks 32 queries at a time;
-//   * scores are formed on the matrix pipe once per C layout: S^T = K Q^T (lane = query: the softmax statistics and
-//     dQ^T = K^T dS^T) and S = Q K^T (lane = key: dV^T = dO^T P, dK^T = Q^T dS); the C layout of a first product IS the B operand
-//     of the second with the reduction index permuted ([tile 0 rows fg*4..+3 | tile 1 rows fg*4..+3]), and the transposed A
-//     operands come from row-major LDS images through ds_read_b64_tr_b16 in the same permutation;
+//   * scores are formed on the matrix pipe in the lane = query layout, S^T = K Q^T: the softmax statistics, delta and
+//     dQ^T = K^T dS^T (the C layout of the first product IS the B operand of the second with the reduction index permuted:
+//     [tile 0 rows fg*4..+3 | tile 1 rows fg*4..+3]; the transposed A operands come from row-major LDS images through
+//     ds_read_b64_tr_b16 in the same permutation).  P and dS then go once, as bf16, through two small LDS images [query][key]
+//     whose transposing reads are the B operands of dV^T = dO^T P and dK^T = Q^T dS -- the scores are not formed a second time
+//     in the lane = key layout (as egv_attn_time.hip does for its 16 x 17 groups): with 32 keys per query the second softmax
+//     pass was 40 % of the kernel's vector-ALU work, and the kernel is bound by exactly that;
 //   * all keys of a row sit in the two tiles, so delta = sum_j P_j dP_j is formed from the products themselves (no O read, no
 //     common rounding offset: DESIGN.md section 4);
 //   * dK^T / dV^T accumulate in registers over the wave's queries, are summed over the workgroup's four waves through LDS and leave
@@ -29,7 +32,9 @@ constexpr int XP = 144;                          // row pitch (bytes) of the LDS
 constexpr int X_IMG = 32 * XP;                   // one 32-row operand image
 constexpr int X_STAGE = 16 * XP;                 // output staging image of a wave (16 rows)
 constexpr int X_NW = 4;                          // waves per workgroup
-constexpr int X_WLDS = 2 * X_IMG + X_STAGE + 256;   // backward, per wave: dO and Q images, staging, lse / delta of the 32 queries
+constexpr int XPP = 96;                          // row pitch of the P / dS images (32 bf16 + 32 B: conflict-free transposing reads)
+constexpr int X_PIMG = 32 * XPP;
+constexpr int X_WLDS = 2 * X_IMG + X_STAGE + 2 * X_PIMG;   // backward, per wave: dO and Q images, staging, P and dS of the 32 queries
 constexpr int X_RED_PITCH = 68;                  // float pitch of the cross-wave sum (conflict-free f32x4 rows)
 constexpr int X_BWD_LDS = X_IMG + X_NW * X_WLDS; // + the K image shared by the workgroup
 constexpr int X_FWD_LDS = X_IMG + X_NW * X_STAGE;
@@ -59,6 +64,14 @@ __device__ __forceinline__ bf16x8_t x_afrag(const unsigned char* img, int dt, in
     const unsigned char* p = img + (fg * 4 + (fr >> 2)) * XP + (dt * 16 + (fr & 3) * 4) * 2;
     const x_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) x_s16x4_t*)(p));
     const x_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) x_s16x4_t*)(p + 16 * XP));
+    const x_s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+// B operand of dV^T / dK^T for keys kt*16 .. +15 from a [query][key] image: [X[q rows fg*4 .. +3][key] | X[q rows 16 + fg*4 .. +3][key]]
+__device__ __forceinline__ bf16x8_t x_bfrag(const unsigned char* img, int kt, int fr, int fg) {
+    const unsigned char* p = img + (fg * 4 + (fr >> 2)) * XPP + (kt * 16 + (fr & 3) * 4) * 2;
+    const x_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) x_s16x4_t*)(p));
+    const x_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) x_s16x4_t*)(p + 16 * XPP));
     const x_s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8_t, v);
 }
@@ -115,14 +128,18 @@ __global__ __launch_bounds__(256) void attn_fewkeys_fwd_kernel(const AttnArgs a,
         *reinterpret_cast<u32x4_t*>(sV + key * XP + fg * 16) = v0;
         *reinterpret_cast<u32x4_t*>(sV + key * XP + 64 + fg * 16) = v1;
     }
-    float mq[2][4];                                                 // additive mask (log2 domain) of the lane's keys kt*16 + fg*4 + r
+    // additive mask (log2 domain) of the lane's keys kt*16 + fg*4 + r: descriptor loads, all in flight together (a conditional
+    // global load per key compiles to a branch and a full wait each: ten serial round trips before the first query)
+    const __amdgpu_buffer_rsrc_t rM = mk(a.mask ? (const void*)(a.mask + (long long)b * a.mask_ld) : (const void*)a.K, a.mask ? (unsigned int)nk * 4u : 0u);
+    float mq[2][4];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = kt * 16 + fg * 4 + r;
-            mq[kt][r] = key < nk ? (a.mask ? a.mask[(long long)b * a.mask_ld + key] * X_LOG2E : 0.f) : -INFINITY;
-        }
+        for (int r = 0; r < 4; ++r) mq[kt][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rM, (unsigned int)(kt * 16 + fg * 4 + r) * 4u, 0, 0));
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mq[kt][r] = kt * 16 + fg * 4 + r < nk ? mq[kt][r] * X_LOG2E : -INFINITY;
     __syncthreads();
     bf16x8_t av[4];
 #pragma unroll
@@ -180,7 +197,7 @@ __global__ __launch_bounds__(256) void attn_fewkeys_fwd_kernel(const AttnArgs a,
 
 // grid as above; part: fp32 partial dK^T-then-dV^T sums, [problem][workgroup][dK | dV][32 keys][64]
 __global__ __launch_bounds__(256) void attn_fewkeys_bwd_kernel(const AttnArgs a, int iters, unsigned int q_bytes, unsigned int kv_bytes,
-                                                               unsigned int o_bytes, unsigned int dq_bytes, float* __restrict__ part) {
+                                                               unsigned int o_bytes, unsigned int dq_bytes, unsigned int lse_bytes, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, w = wave_id();
     const int fr = lane & 15, fg = lane >> 4;
@@ -189,8 +206,8 @@ __global__ __launch_bounds__(256) void attn_fewkeys_bwd_kernel(const AttnArgs a,
     unsigned char* sG = smem + X_IMG + w * X_WLDS;                  // dO rows of the wave's 32 queries
     unsigned char* sQ = sG + X_IMG;
     unsigned char* sS = sQ + X_IMG;
-    float* sL = reinterpret_cast<float*>(sS + X_STAGE);             // lse (log2 domain) of the 32 queries, then their delta
-    float* sD = sL + 32;
+    unsigned char* sP = sS + X_STAGE;                               // P and dS of the wave's 32 queries, [query][key] bf16
+    unsigned char* sDS = sP + X_PIMG;
     const int nq = a.q.n, nk = a.k.n;
     const float sc2 = a.scale * X_LOG2E;
     const int krow0 = (int)(b * a.k.bs + a.k.base + g * a.k.gs), qrow0 = (int)(b * a.q.bs + a.q.base + g * a.q.gs);
@@ -215,17 +232,19 @@ __global__ __launch_bounds__(256) void attn_fewkeys_bwd_kernel(const AttnArgs a,
         *reinterpret_cast<u32x4_t*>(sK + (w * 16 + fr) * XP + fg * 16) = w == 0 ? k[0][0] : k[1][0];
         *reinterpret_cast<u32x4_t*>(sK + (w * 16 + fr) * XP + 64 + fg * 16) = w == 0 ? k[0][1] : k[1][1];
     }
-    float mq[2][4], mkk[2];                                         // additive mask (log2 domain): lane = query layout, lane = key layout
+    // additive mask (log2 domain) of the lane's keys kt*16 + fg*4 + r.  Descriptor loads, all in flight together (no mask: a
+    // zero-length descriptor reads zeros)
+    const __amdgpu_buffer_rsrc_t rM = mk(a.mask ? (const void*)(a.mask + (long long)b * a.mask_ld) : (const void*)a.K, a.mask ? (unsigned int)nk * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rL = mk(a.lse, lse_bytes);
+    float mq[2][4];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
+    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = kt * 16 + fg * 4 + r;
-            mq[kt][r] = key < nk ? (a.mask ? a.mask[(long long)b * a.mask_ld + key] * X_LOG2E : 0.f) : -INFINITY;
-        }
-        const int key = kt * 16 + fr;
-        mkk[kt] = key < nk ? (a.mask ? a.mask[(long long)b * a.mask_ld + key] * X_LOG2E : 0.f) : -INFINITY;
-    }
+        for (int r = 0; r < 4; ++r) mq[kt][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rM, (unsigned int)(kt * 16 + fg * 4 + r) * 4u, 0, 0));
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mq[kt][r] = kt * 16 + fg * 4 + r < nk ? mq[kt][r] * X_LOG2E : -INFINITY;
     __syncthreads();
 
     const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
@@ -236,6 +255,27 @@ __global__ __launch_bounds__(256) void attn_fewkeys_bwd_kernel(const AttnArgs a,
         for (int dt = 0; dt < 4; ++dt) { dk[kt][dt] = zero; dv[kt][dt] = zero; }
 
     const int q_begin = blockIdx.x * (X_NW * iters * 32);
+    // the wave's operands of one trip: Q and dO rows of 32 queries in fragment layout, their lse, the dQ store offsets.  The NEXT trip's
+    // loads are issued before this trip's arithmetic (the kernel is bound by the latency of a trip, two waves per SIMD)
+    struct Trip { u32x4_t q[2][2], g[2][2]; float lse2[2]; unsigned int odq[2]; };
+    auto fetch = [&](int q0, Trip& tr) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int qi = q0 + t * 16 + fr;
+            const bool valid = qi < nq;
+            const int row = qrow0 + qi;
+            const unsigned int oq = valid ? (unsigned int)(row * a.ldq + a.qoff + h * HD + fg * 8) * 2u : X_OOB;
+            const unsigned int og = valid ? (unsigned int)(row * a.ldo + a.ooff + h * HD + fg * 8) * 2u : X_OOB;
+            tr.odq[t] = valid ? (unsigned int)(row * a.lddq + a.dqoff + h * HD + fg * 8) * 2u : X_OOB;
+            tr.q[t][0] = ld(rQ, oq);
+            tr.q[t][1] = ld(rQ, oq + 64);
+            tr.g[t][0] = ld(rG, og);
+            tr.g[t][1] = ld(rG, og + 64);
+            tr.lse2[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rL, valid ? (unsigned int)(row * a.H + h) * 4u : X_OOB, 0, 0));   // (no branch, no wait)
+        }
+    };
+    Trip nx;
+    if (q_begin + w * 32 < nq) fetch(q_begin + w * 32, nx);
     for (int it = 0; it < iters; ++it) {
         const int q0 = q_begin + (it * X_NW + w) * 32;
         if (q0 >= nq) break;                                        // (wave-uniform; the wave still takes part in the sum below)
@@ -244,18 +284,11 @@ __global__ __launch_bounds__(256) void attn_fewkeys_bwd_kernel(const AttnArgs a,
         unsigned int odq[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int qi = q0 + t * 16 + fr;
-            const bool valid = qi < nq;
-            const int row = qrow0 + qi;
-            const unsigned int oq = valid ? (unsigned int)(row * a.ldq + a.qoff + h * HD + fg * 8) * 2u : X_OOB;
-            const unsigned int og = valid ? (unsigned int)(row * a.ldo + a.ooff + h * HD + fg * 8) * 2u : X_OOB;
-            odq[t] = valid ? (unsigned int)(row * a.lddq + a.dqoff + h * HD + fg * 8) * 2u : X_OOB;
-            q[t][0] = ld(rQ, oq);
-            q[t][1] = ld(rQ, oq + 64);
-            gq[t][0] = ld(rG, og);
-            gq[t][1] = ld(rG, og + 64);
-            lse2[t] = valid ? a.lse[(long long)row * a.H + h] * X_LOG2E : INFINITY;    // padding queries: exp2(s - inf) = 0
+            q[t][0] = nx.q[t][0]; q[t][1] = nx.q[t][1]; gq[t][0] = nx.g[t][0]; gq[t][1] = nx.g[t][1];
+            lse2[t] = nx.odq[t] != X_OOB ? nx.lse2[t] * X_LOG2E : INFINITY;      // padding queries: exp2(s - inf) = 0
+            odq[t] = nx.odq[t];
         }
+        if (it + 1 < iters && q0 + X_NW * 32 < nq) fetch(q0 + X_NW * 32, nx);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             *reinterpret_cast<u32x4_t*>(sQ + (t * 16 + fr) * XP + fg * 16) = q[t][0];
@@ -286,33 +319,25 @@ __global__ __launch_bounds__(256) void attn_fewkeys_bwd_kernel(const AttnArgs a,
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ds[kt][r] = s[kt][r] * (d[kt][r] - dl);
-            if (fg == 0) { sL[t * 16 + fr] = lse2[t]; sD[t * 16 + fr] = dl; }
             const bf16x8_t bP = x_pack8(ds[0], ds[1]);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {                         // row t*16 + fr, keys kt*16 + fg*4 .. +3
+                const u32x4_t dsv = __builtin_bit_cast(u32x4_t, bP);
+                *reinterpret_cast<u32x2_t*>(sP + (t * 16 + fr) * XPP + (kt * 16 + fg * 4) * 2) = u32x2_t{pack_bf16x2(s[kt][0], s[kt][1]), pack_bf16x2(s[kt][2], s[kt][3])};
+                *reinterpret_cast<u32x2_t*>(sDS + (t * 16 + fr) * XPP + (kt * 16 + fg * 4) * 2) = u32x2_t{dsv[kt * 2], dsv[kt * 2 + 1]};
+            }
             f32x4_t dq[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) dq[dt] = x_mfma(x_afrag(sK, dt, fr, fg), bP, zero);
             x_store_rows(sS, rDQ, odq[t], dq, a.scale, fr, fg);
         }
         x_wave_sync();
-        // ================= lane = key: S[query][key] -> dV^T = dO^T P, dK^T = Q^T dS =================
+        // ================= dV^T = dO^T P, dK^T = Q^T dS: P and dS of the 32 queries from their images, lane = key =================
         bf16x8_t bV[2], bK[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-            f32x4_t p2[2], ds2[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const f32x4_t s = x_mfma(x_bf(q[t][1]), x_bf(k[kt][1]), x_mfma(x_bf(q[t][0]), x_bf(k[kt][0]), zero));
-                const f32x4_t d = x_mfma(x_bf(gq[t][1]), x_bf(v[kt][1]), x_mfma(x_bf(gq[t][0]), x_bf(v[kt][0]), zero));
-                const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(sL + t * 16 + fg * 4), dl4 = *reinterpret_cast<const f32x4_t*>(sD + t * 16 + fg * 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {                        // query t*16 + fg*4 + r (padding queries: lse = +inf -> p = 0)
-                    const float p = x_exp2(fmaf(s[r], sc2, mkk[kt] - l4[r]));
-                    p2[t][r] = p;
-                    ds2[t][r] = p * (d[r] - dl4[r]);
-                }
-            }
-            bV[kt] = x_pack8(p2[0], p2[1]);
-            bK[kt] = x_pack8(ds2[0], ds2[1]);
+            bV[kt] = x_bfrag(sP, kt, fr, fg);
+            bK[kt] = x_bfrag(sDS, kt, fr, fg);
         }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
@@ -351,22 +376,29 @@ __global__ __launch_bounds__(256) void attn_fewkeys_bwd_kernel(const AttnArgs a,
     }
 }
 
-// one workgroup per (sample, group, head): dK = scale * sum of the partials, dV = their sum, in workgroup order
+// four workgroups per (sample, group, head), one float4 of dK or dV per thread: dK = scale * sum of the partials, dV = their sum, in
+// workgroup order (eight loads in flight)
 __global__ __launch_bounds__(256) void attn_fewkeys_reduce_kernel(const AttnArgs a, int nwg, const float* __restrict__ part) {
-    const int h = blockIdx.x % a.H, pg = blockIdx.x / a.H, b = pg / a.G, g = pg % a.G;
+    const int prob = blockIdx.x >> 2;
+    const int h = prob % a.H, pg = prob / a.H, b = pg / a.G, g = pg % a.G;
     const long long krow0 = b * a.k.bs + a.k.base + g * a.k.gs;
-    const float* src = part + (long long)blockIdx.x * nwg * 2 * 32 * HD;
-    for (int e = threadIdx.x; e < 1024; e += 256) {
-        const int pass = e >> 9, key = (e & 511) >> 4, c4 = e & 15;
-        f32x4_t s = {0.f, 0.f, 0.f, 0.f};
-        for (int wg = 0; wg < nwg; ++wg) s += *reinterpret_cast<const f32x4_t*>(src + ((long long)wg * 2 + pass) * 32 * HD + key * HD + c4 * 4);
-        if (key >= a.k.n) continue;
-        const float sc = pass == 0 ? a.scale : 1.0f;
-        const u32x2_t pk = {pack_bf16x2(s[0] * sc, s[1] * sc), pack_bf16x2(s[2] * sc, s[3] * sc)};
-        bf16_t* out = reinterpret_cast<bf16_t*>(pass == 0 ? a.dK : a.dV);
-        const long long off = (krow0 + key) * (pass == 0 ? a.lddk : a.lddv) + (pass == 0 ? a.dkoff : a.dvoff) + h * HD + c4 * 4;
-        *reinterpret_cast<u32x2_t*>(out + off) = pk;
+    const int e = (blockIdx.x & 3) * 256 + threadIdx.x;             // float4 index over [dK | dV][32 keys][16]
+    const int pass = e >> 9, key = (e & 511) >> 4, c4 = e & 15;
+    if (key >= a.k.n) return;
+    const float* src = part + (long long)prob * nwg * 2 * 32 * HD + pass * 32 * HD + key * HD + c4 * 4;
+    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+    for (int w0 = 0; w0 < nwg; w0 += 8) {
+        f32x4_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4_t*>(src + (long long)(w0 + u < nwg ? w0 + u : w0) * 2 * 32 * HD);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (w0 + u < nwg) s += v[u];
     }
+    const float sc = pass == 0 ? a.scale : 1.0f;
+    const u32x2_t pk = {pack_bf16x2(s[0] * sc, s[1] * sc), pack_bf16x2(s[2] * sc, s[3] * sc)};
+    bf16_t* out = reinterpret_cast<bf16_t*>(pass == 0 ? a.dK : a.dV);
+    const long long off = (krow0 + key) * (pass == 0 ? a.lddk : a.lddv) + (pass == 0 ? a.dkoff : a.dvoff) + h * HD + c4 * 4;
+    *reinterpret_cast<u32x2_t*>(out + off) = pk;
 }
 
 }  // namespace egv
@@ -374,7 +406,7 @@ using namespace egv;
 
 namespace {
 int fewkeys_iters() {
-    static const int it = egv_cfg_int("EGV_ATTN_FEWKEYS_ITERS", 2);
+    static const int it = egv_cfg_int("EGV_ATTN_FEWKEYS_ITERS", 4);
     return it < 1 ? 1 : (it > 64 ? 64 : it);
 }
 bool fewkeys_shape_ok(const AttnArgs& a, int B, bool bwd) {
@@ -432,7 +464,7 @@ int egv_attn_fewkeys_bwd(const AttnArgs& a, int B, hipStream_t st) {
         attr = true;
     }
     hipLaunchKernelGGL(attn_fewkeys_bwd_kernel, dim3(nwg, B * a.G * a.H), dim3(256), X_BWD_LDS, st, a, fewkeys_iters(), (unsigned int)(qr * a.ldq * 2),
-                       (unsigned int)kvb, (unsigned int)(qr * a.ldo * 2), (unsigned int)(qr * a.lddq * 2), a.ws);
-    hipLaunchKernelGGL(attn_fewkeys_reduce_kernel, dim3(B * a.G * a.H), dim3(256), 0, st, a, nwg, a.ws);
+                       (unsigned int)kvb, (unsigned int)(qr * a.ldo * 2), (unsigned int)(qr * a.lddq * 2), (unsigned int)(qr * a.H * 4), a.ws);
+    hipLaunchKernelGGL(attn_fewkeys_reduce_kernel, dim3(B * a.G * a.H * 4), dim3(256), 0, st, a, nwg, a.ws);
     return 1;
 }

@@ -36,6 +36,7 @@ SWITCHES = {
     'EGV_ITM_DRAW_EARLY': ('1', 'ITM negatives drawn before the MLM pass is enqueued'),
     'EGV_ITM_FIRST': ('0', 'create the ITM pass before the MLM pass (default: the reference order)'),
     'EGV_EXCHANGE_HOST_TABLE': ('0', 'exchange the ITM request table through a host (gloo) all-gather also on RCCL'),
+    'EGV_SYNC_WIRE': ('fp32', 'flat gradient sync: fp32 = in-place all-reduce, bf16 = bf16 on the links with fp32 accumulation on arrival (grad_sync.allreduce_bf16_wire)'),
     'EGV_SYNC_FORCE': ('0', 'run the flat gradient all-reduces at world size 1 (test aid)'),
     'EGV_ALLOW_UNSAFE_CHECKPOINT': ('0', 'allow full unpickling of a checkpoint whose safe load fails'),
 }

@@ -20,8 +20,6 @@ of a flat buffer become p.grad by reference while the collective may still be ru
 """
 from __future__ import annotations
 
-import os
-
 import torch
 import torch.distributed as dist
 
@@ -52,10 +50,10 @@ def allreduce_bf16_wire(flat, group=None):
 class FlatGradSync:
     def __init__(self, model, group=None, wire=None):
         """wire: 'fp32' (default; in-place all-reduce of the flat buffers) or 'bf16' (allreduce_bf16_wire: bf16 on the links, fp32
-        accumulation on arrival); EGV_SYNC_WIRE overrides the default."""
+        accumulation on arrival); None: the switch EGV_SYNC_WIRE."""
         self.model = model
         self.group = group
-        self.wire = wire or os.environ.get('EGV_SYNC_WIRE', 'fp32')
+        self.wire = wire or SW.value('EGV_SYNC_WIRE')
         if self.wire not in ('fp32', 'bf16'):
             raise ValueError(f"FlatGradSync: wire must be 'fp32' or 'bf16', not {self.wire!r}")
         self._side = None
