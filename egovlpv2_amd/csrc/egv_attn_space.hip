@@ -36,7 +36,7 @@ struct SpaceArgs {
     int H, G, n, nb;
     int bs, base, gs, is, cls_bs;               // row(b, g, i) = b*bs + base + g*gs + i*is; CLS row = b*cls_bs
     float scale;
-    unsigned int qkv_bytes, o_bytes, dqkv_bytes;
+    unsigned int qkv_bytes, o_bytes, dqkv_bytes, lse_bytes;
 };
 
 __device__ __forceinline__ float s_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -266,6 +266,7 @@ __global__ __launch_bounds__(64 * SNW, (NT <= 14 ? 4 : 2)) void attn_space_bwd_k
     const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.o), 0, (int)a.o_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dO), 0, (int)a.o_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(a.dqkv, 0, (int)a.dqkv_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc(a.lse, 0, (int)a.lse_bytes, 0x00020000);
     auto ld2 = [&](__amdgpu_buffer_rsrc_t r, unsigned int off, u32x4_t& x0, u32x4_t& x1) {
         x0 = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
         x1 = __builtin_amdgcn_raw_buffer_load_b128(r, off == S_OOB ? S_OOB : off + 64u, 0, 0);
@@ -284,7 +285,11 @@ __global__ __launch_bounds__(64 * SNW, (NT <= 14 ? 4 : 2)) void attn_space_bwd_k
     ld2(rO, foff(w, a.ldo, a.ocol), o0, o1);
     auto lse_of = [&](int t) {                                     // lse (log2 domain) of row t*16 + fr; past the list: +inf -> exp2(s - inf) = 0
         const int row = s_row_of(q, t * 16 + fr);
-        return (row >= 0 && t < nlt) ? a.lse[(long long)row * a.H + q.h] * S_LOG2E : INFINITY;
+        // (a descriptor load: `cond ? a.lse[i] : inf` compiles to a branch around a global load followed by vmcnt(0), which also waits for
+        // the fragment prefetches issued just before it)
+        const bool live = row >= 0 && t < nlt;
+        const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rL, live ? (unsigned int)(row * a.H + q.h) * 4u : S_OOB, 0, 0));
+        return live ? v * S_LOG2E : INFINITY;
     };
     float lse2 = lse_of(w);                                        // (loaded a tile ahead like the fragments: a load waited for inside the
                                                                    // loop would also wait for the prefetches issued before it)
@@ -439,6 +444,7 @@ static bool space_args(const AttnArgs& a, int B, bool backward, SpaceArgs& s) {
         if (dkd < 0 || dvd < 0 || dkd + a.dkoff + a.H * HD > a.lddq || dvd + a.dvoff + a.H * HD > a.lddq || !ok8(dkd) || !ok8(dvd)) return false;
         s.ldd = a.lddq; s.dqcol = a.dqoff; s.dkcol = (int)dkd + a.dkoff; s.dvcol = (int)dvd + a.dvoff;
         s.dqkv_bytes = (unsigned int)(rows * a.lddq * 2);
+        s.lse_bytes = (unsigned int)(rows * a.H * 4);
     }
     return true;
 }

@@ -315,7 +315,12 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restri
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
             if (m < M) {
-                const u32x4_t x = *reinterpret_cast<const u32x4_t*>(A + (long long)m * lda + k0);
+                // agent-scope loads of the <= 16 activation rows every wave of the launch reads (see wgrad_small_m_kernel: plain loads of a
+                // small, freshly recycled buffer from every CU were seen to return a stale line)
+                const unsigned long long* ap = reinterpret_cast<const unsigned long long*>(A + (long long)m * lda + k0);
+                const unsigned long long x01 = __hip_atomic_load(ap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long x23 = __hip_atomic_load(ap + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const u32x4_t x = {(unsigned int)x01, (unsigned int)(x01 >> 32), (unsigned int)x23, (unsigned int)(x23 >> 32)};
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[m][c] = dot8_bf16(x, w[c], acc[m][c]);
             }
@@ -452,6 +457,9 @@ extern "C" int egv_colsum(int dtype, const void* X, int M, int N, int ld, float*
 // caches (both operands are a few KB), the sum runs over m in order (deterministic), dbias[n] = sum_m dY[m, n] rides with the k = 0 thread.
 // As a 128 x 128-tile MFMA GEMM the same gradient was 144 tiles whose K loop has one step: 20 launches of 39 us (up to 250 us in the step) per
 // training step, every one of them on the latency-bound chain between two block calls.
+#ifndef SMALLM_DIAG
+#define SMALLM_DIAG 0
+#endif
 namespace egv {
 __global__ __launch_bounds__(256) void wgrad_small_m_kernel(const bf16_t* __restrict__ dY, int ldy, const bf16_t* __restrict__ X, int ldx,
                                                             float* __restrict__ dW, float* __restrict__ dbias, int M, int N, int K, float scale,
@@ -463,8 +471,19 @@ __global__ __launch_bounds__(256) void wgrad_small_m_kernel(const bf16_t* __rest
     const float sc = scale * (gate ? *gate : 1.0f);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, sb = 0.f;
     for (int m = 0; m < M; ++m) {
+#if SMALLM_DIAG == 2    // plain cached loads (the form that read stale lines)
         const float d = bf2f(dY[(size_t)m * ldy + n].v);
         const u32x2_t xv = *reinterpret_cast<const u32x2_t*>(X + (size_t)m * ldx + k);
+#else
+        // Agent-scope loads (they do not hit in the CU's vector L1).  With plain loads one wave in ~10^5 of this launch -- 16 384 short
+        // workgroups that all read the same 128 KB, spread over every CU while persistent kernels of the other streams hold the CUs --
+        // got ONE stale 128-byte line of x (the address's previous content within the step): 10-30 wrong elements in one row of a
+        // 16.7 M-element gradient in one run out of three, inputs identical in memory before and after (tools/repro_check.py;
+        // profiles/round5_experiments.md section 11).  The operands are 128 KB: the L1 is worth nothing here.
+        const float d = bf2f(__hip_atomic_load(reinterpret_cast<const unsigned short*>(dY) + (size_t)m * ldy + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const unsigned long long xq = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(X + (size_t)m * ldx + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u32x2_t xv = {(unsigned int)xq, (unsigned int)(xq >> 32)};
+#endif
         a0 = fmaf(d, __uint_as_float(xv[0] << 16), a0);
         a1 = fmaf(d, __uint_as_float(xv[0] & 0xffff0000u), a1);
         a2 = fmaf(d, __uint_as_float(xv[1] << 16), a2);
