@@ -112,19 +112,21 @@ __global__ __launch_bounds__(256) void attn_fewkeys_fwd_kernel(const AttnArgs a,
     auto mk = [&](const void* p, unsigned int bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000); };
     const __amdgpu_buffer_rsrc_t rQ = mk(a.Q, q_bytes), rK = mk(a.K, kv_bytes), rV = mk(a.V, kv_bytes), rO = mk(a.O, o_bytes);
     auto ld = [&](__amdgpu_buffer_rsrc_t r, unsigned int off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); };
+    // K / V: 8 KB that every workgroup of the (sample, head) reads -- at agent scope (sc1), see wgrad_small_m_kernel in egv_gemm.hip
+    auto ld_kv = [&](__amdgpu_buffer_rsrc_t r, unsigned int off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16); };
 
     u32x4_t k[2][2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
         const int key = kt * 16 + fr;
         const unsigned int off = key < nk ? (unsigned int)((krow0 + key) * a.ldk + a.koff + h * HD + fg * 8) * 2u : X_OOB;
-        k[kt][0] = ld(rK, off);
-        k[kt][1] = ld(rK, off + 64);
+        k[kt][0] = ld_kv(rK, off);
+        k[kt][1] = ld_kv(rK, off + 64);
     }
     if (w < 2) {                                                    // the V image: waves 0 and 1 bring one 16-row tile each
         const int key = w * 16 + fr;
         const unsigned int off = key < nk ? (unsigned int)((krow0 + key) * a.ldv + a.voff + h * HD + fg * 8) * 2u : X_OOB;
-        const u32x4_t v0 = ld(rV, off), v1 = ld(rV, off + 64);
+        const u32x4_t v0 = ld_kv(rV, off), v1 = ld_kv(rV, off + 64);
         *reinterpret_cast<u32x4_t*>(sV + key * XP + fg * 16) = v0;
         *reinterpret_cast<u32x4_t*>(sV + key * XP + 64 + fg * 16) = v1;
     }
@@ -216,6 +218,8 @@ __global__ __launch_bounds__(256) void attn_fewkeys_bwd_kernel(const AttnArgs a,
     const __amdgpu_buffer_rsrc_t rQ = mk(a.Q, q_bytes), rK = mk(a.K, kv_bytes), rV = mk(a.V, kv_bytes), rG = mk(a.dO, o_bytes);
     const __amdgpu_buffer_rsrc_t rDQ = mk(a.dQ, dq_bytes);
     auto ld = [&](__amdgpu_buffer_rsrc_t r, unsigned int off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); };
+    // K / V: 8 KB that every workgroup of the (sample, head) reads -- at agent scope (sc1), see wgrad_small_m_kernel in egv_gemm.hip
+    auto ld_kv = [&](__amdgpu_buffer_rsrc_t r, unsigned int off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16); };
 
     u32x4_t k[2][2], v[2][2];
 #pragma unroll
@@ -223,10 +227,10 @@ __global__ __launch_bounds__(256) void attn_fewkeys_bwd_kernel(const AttnArgs a,
         const int key = kt * 16 + fr;
         const unsigned int ok_ = key < nk ? (unsigned int)((krow0 + key) * a.ldk + a.koff + h * HD + fg * 8) * 2u : X_OOB;
         const unsigned int ov_ = key < nk ? (unsigned int)((krow0 + key) * a.ldv + a.voff + h * HD + fg * 8) * 2u : X_OOB;
-        k[kt][0] = ld(rK, ok_);
-        k[kt][1] = ld(rK, ok_ + 64);
-        v[kt][0] = ld(rV, ov_);
-        v[kt][1] = ld(rV, ov_ + 64);
+        k[kt][0] = ld_kv(rK, ok_);
+        k[kt][1] = ld_kv(rK, ok_ + 64);
+        v[kt][0] = ld_kv(rV, ov_);
+        v[kt][1] = ld_kv(rV, ov_ + 64);
     }
     if (w < 2) {                                                    // the K image (for K^T): waves 0 and 1 write one tile each
         *reinterpret_cast<u32x4_t*>(sK + (w * 16 + fr) * XP + fg * 16) = w == 0 ? k[0][0] : k[1][0];
