@@ -142,6 +142,7 @@ PROTOTYPES = {
     'egv_attn_bwd_fused': (i32, [i32, C.POINTER(AttnDesc), vp]),
     'egv_attn_bwd_fused_workspace_bytes': (i64, [i32, i32, i32]),
     'egv_attn_fewkeys_workspace_bytes': (i64, [i32, i32, i32, i32]),
+    'egv_attn_fewq_workspace_bytes': (i64, [i32, i32, i32, i32]),
     'egv_attn_bwd_pair_covers_extra': (i32, [i32, C.POINTER(AttnDesc)]),
     'egv_attn_bwd_extra_reduce': (i32, [i32, C.POINTER(AttnDesc), i32, vp]),
     'egv_im2col': (i32, [i32, vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -33,6 +33,8 @@ struct Switch { const char* name; double def; const char* doc; };
 const Switch g_switches[] = {
     {"EGV_ATTN_FEWKEYS", 1, "one-launch forward / backward of many queries over <= 32 keys (image-to-text cross attention), egv_attn_cross.hip"},
     {"EGV_ATTN_FEWKEYS_ITERS", 4, "... 32-query tiles per wave (a workgroup covers 128 x this many queries and leaves one partial dK / dV)"},
+    {"EGV_ATTN_FEWQ", 1, "one-launch forward / backward of <= 32 queries over many keys (text-to-image cross attention), egv_attn_cross.hip"},
+    {"EGV_ATTN_FEWQ_ITERS", 6, "... 32-key tiles per wave (a workgroup covers 128 x this many keys and leaves one partial state / dQ)"},
     {"EGV_ATTN_TIME_FUSED", 1, "one-launch forward / backward of the <= 16-row attention groups (time attention), egv_attn_time.hip"},
     {"EGV_ATTN_SPACE_NEW", 1, "space attention on row-major LDS images, egv_attn_space.hip (0: the kernels of egv_attn_mfma.hip)"},
     {"EGV_ATTN_FUSED_CLS", 1, "the group launches also serve the CLS row (per-group partials + one small sum)"},

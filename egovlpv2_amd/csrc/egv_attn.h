@@ -101,4 +101,7 @@ int egv_attn_time_bwd(const egv::AttnArgs& a, int B, hipStream_t st);   // egv_a
 int egv_attn_fewkeys_fwd(const egv::AttnArgs& a, int B, hipStream_t st);   // egv_attn_cross.hip: many queries over <= 32 keys (image -> text), 1 if enqueued
 int egv_attn_fewkeys_bwd(const egv::AttnArgs& a, int B, hipStream_t st);   // ... dQ, dK, dV in one launch + the partial sum (a.ws: egv_attn_fewkeys_workspace_bytes)
 extern "C" long long egv_attn_fewkeys_workspace_bytes(int B, int G, int H, int q_n);
+int egv_attn_fewq_fwd(const egv::AttnArgs& a, int B, hipStream_t st);      // egv_attn_cross.hip: <= 32 queries over many keys (text -> image), 1 if enqueued (a.ws: egv_attn_fewq_workspace_bytes)
+int egv_attn_fewq_bwd(const egv::AttnArgs& a, int B, hipStream_t st);      // ... dQ, dK, dV in one launch + the partial sum of dQ
+extern "C" long long egv_attn_fewq_workspace_bytes(int B, int G, int H, int k_n);
 void egv_attn_bwd_cls_reduce_launch(const egv::AttnArgs& a, int B, int self_term, hipStream_t st);

@@ -725,6 +725,11 @@ static int egv_attn_fwd_impl(int dtype, const egv_attn_desc* d, void* stream) {
             return 0;
         }
     }
+    if (dtype == EGV_BF16 && d->ws && d->q_n <= 32 && d->ws_bytes >= egv_attn_fewq_workspace_bytes(d->B, d->G, d->H, d->k_n) &&
+        egv_attn_fewq_fwd(a, d->B, st)) {              // <= 32 queries over many keys (text -> image cross attention): egv_attn_cross.hip
+        EGV_LAUNCH_CHECK();
+        return 0;
+    }
     if (a.nsplit > 1)
         EGV_CHECK(d->ws && d->ws_bytes >= egv_attn_split_workspace_bytes(0, d->B, d->G, d->H, d->q_n, a.nsplit),
                   "egv_attn_fwd: workspace too small");
@@ -845,6 +850,10 @@ static int egv_attn_bwd_fused_impl(int dtype, const egv_attn_desc* d, void* stre
         EGV_CHECK(d->ws_bytes >= egv_attn_bwd_fused_workspace_bytes(d->B, d->G, d->H), "egv_attn_bwd_fused: workspace too small");
     if (!d->extra && d->ws && d->ws_bytes >= egv_attn_fewkeys_workspace_bytes(d->B, d->G, d->H, d->q_n) && egv_attn_fewkeys_bwd(a, d->B, st)) {
         EGV_LAUNCH_CHECK();                      // many queries over <= 32 keys, mask allowed (egv_attn_cross.hip)
+        return 0;
+    }
+    if (!d->extra && d->ws && d->q_n <= 32 && d->ws_bytes >= egv_attn_fewq_workspace_bytes(d->B, d->G, d->H, d->k_n) && egv_attn_fewq_bwd(a, d->B, st)) {
+        EGV_LAUNCH_CHECK();                      // <= 32 queries over many keys, dropout allowed (egv_attn_cross.hip)
         return 0;
     }
     if (!egv_attn_bwd_fused_mfma(a, d->B, st)) return 1;

@@ -405,6 +405,403 @@ __global__ __launch_bounds__(256) void attn_fewkeys_reduce_kernel(const AttnArgs
     *reinterpret_cast<u32x2_t*>(out + off) = pk;
 }
 
+
+// =====================================================================================================================
+// The mirror image: FEW queries (<= 32) over MANY keys -- the text-to-image cross attention of a fused RobertaLayer (roberta.py:241-327:
+// 32 text tokens attend to the 25 096 video tokens of their sample, attention-probability dropout :313, no mask).  Queries (and, in
+// the backward, dO, lse and delta) sit in registers as the B operands of S^T = K Q^T / dP^T = V dO^T; a wave streams 32 keys per trip
+// with K and V rows fetched straight into fragment layout.  Forward: online softmax per query (the running maximum is shared by the
+// four lane groups of a query, so one rescale factor serves its whole output row), O^T += V^T (P o D)^T with V^T from an LDS image;
+// wave states are combined per workgroup and leave as (m, l, o[64]) partials, a second launch combines them and writes O (bf16, and
+// fp32 for the backward's delta), lse.  Backward: dS^T in the lane = query layout gives dQ^T += K^T dS^T (accumulated over the wave's keys,
+// summed like dK / dV above); P o D and dS go through the [query][key] LDS images and come back as the B operands of dV^T = dO^T (P o D),
+// dK^T = Q^T dS, which are stored per key row.  delta = rowsum(dO o O) from the fp32 O.
+namespace {
+constexpr int Y_WLDS_F = X_IMG + 32 * X_RED_PITCH * 4;                      // forward, per wave: V image + (m, l, -, -, o[64]) of 32 queries
+constexpr int Y_FWD_LDS = X_NW * Y_WLDS_F;
+constexpr int Y_WLDS_B = X_IMG + 2 * X_PIMG + X_STAGE;                      // backward, per wave: K image, P o D and dS images, staging
+constexpr int Y_BWD_LDS = 2 * X_IMG + X_NW * Y_WLDS_B;                      // + Q and dO images shared by the workgroup
+static_assert(32 * X_RED_PITCH * 4 <= Y_WLDS_B, "a wave's area holds the 32 x 64 fp32 dQ for the cross-wave sum");
+__device__ __forceinline__ unsigned int y_fmix(unsigned int h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+// drop_mult(a, qrow, krow, h) of egv_attn.h with the query part of the hash (hq) hoisted
+__device__ __forceinline__ float y_drop(unsigned int hq, int krow, float p, float keep) {
+    const unsigned int x = y_fmix(hq ^ ((unsigned int)krow * 0x85EBCA77u + 0x165667B1u));
+    return (float)(x >> 8) * (1.0f / 16777216.0f) >= p ? keep : 0.0f;
+}
+}  // namespace
+
+// grid: (workgroups per problem, B*G*H); wave w of a workgroup takes the 32-key tiles (it * 4 + w), it < iters.
+// part: [problem][workgroup][32 queries][68]: m (log2 domain), l, -, -, o[64] (unnormalised)
+__global__ __launch_bounds__(256) void attn_fewq_fwd_kernel(const AttnArgs a, int iters, unsigned int q_bytes, unsigned int kv_bytes,
+                                                            float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, w = wave_id();
+    const int fr = lane & 15, fg = lane >> 4;
+    const int h = blockIdx.y % a.H, pg = blockIdx.y / a.H, b = pg / a.G, g = pg % a.G;
+    unsigned char* sV = smem + w * Y_WLDS_F;
+    float* sT = reinterpret_cast<float*>(sV + X_IMG);
+    const int nq = a.q.n, nk = a.k.n;
+    const float sc2 = a.scale * X_LOG2E;
+    const int krow0 = (int)(b * a.k.bs + a.k.base + g * a.k.gs), qrow0 = (int)(b * a.q.bs + a.q.base + g * a.q.gs);
+    auto mk = [&](const void* p, unsigned int bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000); };
+    const __amdgpu_buffer_rsrc_t rQ = mk(a.Q, q_bytes), rK = mk(a.K, kv_bytes), rV = mk(a.V, kv_bytes);
+    auto ld = [&](__amdgpu_buffer_rsrc_t r, unsigned int off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); };
+    auto ld_q = [&](__amdgpu_buffer_rsrc_t r, unsigned int off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16); };   // agent scope: every workgroup of the problem reads them
+
+    u32x4_t q[2][2];
+    unsigned int hq[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int qi = t * 16 + fr;
+        const unsigned int off = qi < nq ? (unsigned int)((qrow0 + qi) * a.ldq + a.qoff + h * HD + fg * 8) * 2u : X_OOB;
+        q[t][0] = ld_q(rQ, off);
+        q[t][1] = ld_q(rQ, off + 64);
+        hq[t] = a.drop_seed ^ y_fmix((unsigned int)(pg * nq + qi) * 0x9E3779B1u + (unsigned int)h);
+    }
+    const bool drop = a.drop_p > 0.f;
+    const float keep = drop ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+    f32x4_t o[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[t][dt] = zero;
+
+    struct Trip { u32x4_t k[2][2], v[2][2]; };
+    auto fetch = [&](int key0, Trip& tr) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int key = key0 + kt * 16 + fr;
+            const unsigned int ok_ = key < nk ? (unsigned int)((krow0 + key) * a.ldk + a.koff + h * HD + fg * 8) * 2u : X_OOB;
+            const unsigned int ov_ = key < nk ? (unsigned int)((krow0 + key) * a.ldv + a.voff + h * HD + fg * 8) * 2u : X_OOB;
+            tr.k[kt][0] = ld(rK, ok_);
+            tr.k[kt][1] = ld(rK, ok_ + 64);
+            tr.v[kt][0] = ld(rV, ov_);
+            tr.v[kt][1] = ld(rV, ov_ + 64);
+        }
+    };
+    const int k_begin = blockIdx.x * (X_NW * iters * 32);
+    Trip nx;
+    if (k_begin + w * 32 < nk) fetch(k_begin + w * 32, nx);
+    for (int it = 0; it < iters; ++it) {
+        const int key0 = k_begin + (it * X_NW + w) * 32;
+        if (key0 >= nk) break;
+        u32x4_t k[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            k[kt][0] = nx.k[kt][0]; k[kt][1] = nx.k[kt][1];
+            *reinterpret_cast<u32x4_t*>(sV + (kt * 16 + fr) * XP + fg * 16) = nx.v[kt][0];
+            *reinterpret_cast<u32x4_t*>(sV + (kt * 16 + fr) * XP + 64 + fg * 16) = nx.v[kt][1];
+        }
+        if (it + 1 < iters && key0 + X_NW * 32 < nk) fetch(key0 + X_NW * 32, nx);
+        x_wave_sync();
+        bf16x8_t av[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) av[dt] = x_afrag(sV, dt, fr, fg);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4_t s[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) s[kt] = x_mfma(x_bf(k[kt][1]), x_bf(q[t][1]), x_mfma(x_bf(k[kt][0]), x_bf(q[t][0]), zero));
+            float mt = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s[kt][r] = key0 + kt * 16 + fg * 4 + r < nk ? s[kt][r] * sc2 : -INFINITY;
+                    mt = fmaxf(mt, s[kt][r]);
+                }
+            mt = x_grp_max(mt);                                      // (key0 < nk: at least one live key, the maximum is finite)
+            const float mn = fmaxf(m[t], mt);
+            const float alpha = x_exp2(m[t] - mn);
+            m[t] = mn;
+            float ls = 0.f;
+            f32x4_t pd[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = x_exp2(s[kt][r] - mn);
+                    ls += p;
+                    pd[kt][r] = drop ? p * y_drop(hq[t], key0 + kt * 16 + fg * 4 + r, a.drop_p, keep) : p;
+                }
+            l[t] = fmaf(l[t], alpha, ls);                            // (this lane group's keys; summed over the groups at the end)
+            const bf16x8_t bP = x_pack8(pd[0], pd[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[t][dt] = x_mfma(av[dt], bP, o[t][dt] * alpha);
+        }
+        x_wave_sync();                                               // the V image is rewritten by the next trip
+    }
+    // ---- wave states -> workgroup state -> partial
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float lt = x_grp_sum(l[t]);
+        float* row = sT + (t * 16 + fr) * X_RED_PITCH;
+        if (fg == 0) { row[0] = m[t]; row[1] = lt; }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4_t*>(row + 4 + dt * 16 + fg * 4) = o[t][dt];
+    }
+    __syncthreads();
+    {
+        const int qi = threadIdx.x >> 3, c8 = (threadIdx.x & 7) * 8;
+        float M = -INFINITY;
+#pragma unroll
+        for (int ww = 0; ww < X_NW; ++ww) M = fmaxf(M, reinterpret_cast<const float*>(smem + ww * Y_WLDS_F + X_IMG)[qi * X_RED_PITCH]);
+        float L = 0.f;
+        f32x4_t o0 = zero, o1 = zero;
+#pragma unroll
+        for (int ww = 0; ww < X_NW; ++ww) {
+            const float* row = reinterpret_cast<const float*>(smem + ww * Y_WLDS_F + X_IMG) + qi * X_RED_PITCH;
+            const float f = row[0] == -INFINITY ? 0.f : x_exp2(row[0] - M);
+            L = fmaf(row[1], f, L);
+            o0 += *reinterpret_cast<const f32x4_t*>(row + 4 + c8) * f;
+            o1 += *reinterpret_cast<const f32x4_t*>(row + 4 + c8 + 4) * f;
+        }
+        float* dst = part + (((long long)blockIdx.y * gridDim.x + blockIdx.x) * 32 + qi) * X_RED_PITCH;
+        if (c8 == 0) { dst[0] = M; dst[1] = L; }
+        *reinterpret_cast<f32x4_t*>(dst + 4 + c8) = o0;
+        *reinterpret_cast<f32x4_t*>(dst + 4 + c8 + 4) = o1;
+    }
+}
+
+// one workgroup per problem: O = sum_w o_w 2^(m_w - M) / sum_w l_w 2^(m_w - M), lse; thread = (query, 8 head dims)
+__global__ __launch_bounds__(256) void attn_fewq_combine_kernel(const AttnArgs a, int nwg, const float* __restrict__ part) {
+    const int h = blockIdx.x % a.H, pg = blockIdx.x / a.H, b = pg / a.G, g = pg % a.G;
+    const int qi = threadIdx.x >> 3, c8 = (threadIdx.x & 7) * 8;
+    if (qi >= a.q.n) return;
+    const float* src = part + ((long long)blockIdx.x * nwg * 32 + qi) * X_RED_PITCH;
+    const long long wstride = 32LL * X_RED_PITCH;
+    float M = -INFINITY;
+    for (int wg = 0; wg < nwg; ++wg) M = fmaxf(M, src[wg * wstride]);
+    float L = 0.f;
+    f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
+    for (int wg = 0; wg < nwg; ++wg) {
+        const float* row = src + wg * wstride;
+        const float f = row[0] == -INFINITY ? 0.f : x_exp2(row[0] - M);
+        L = fmaf(row[1], f, L);
+        o0 += *reinterpret_cast<const f32x4_t*>(row + 4 + c8) * f;
+        o1 += *reinterpret_cast<const f32x4_t*>(row + 4 + c8 + 4) * f;
+    }
+    const float inv = 1.0f / L;
+    o0 *= inv; o1 *= inv;
+    const long long row = b * a.q.bs + a.q.base + g * a.q.gs + qi;
+    const long long off = row * a.ldo + a.ooff + h * HD + c8;
+    const u32x4_t pk = {pack_bf16x2(o0[0], o0[1]), pack_bf16x2(o0[2], o0[3]), pack_bf16x2(o1[0], o1[1]), pack_bf16x2(o1[2], o1[3])};
+    *reinterpret_cast<u32x4_t*>(reinterpret_cast<bf16_t*>(a.O) + off) = pk;
+    if (a.O32) {
+        *reinterpret_cast<f32x4_t*>(a.O32 + off) = o0;
+        *reinterpret_cast<f32x4_t*>(a.O32 + off + 4) = o1;
+    }
+    if (a.lse && c8 == 0) a.lse[row * a.H + h] = (M + __log2f(L)) * X_LN2;
+}
+
+// backward: dK, dV per streamed key row, dQ as one fp32 partial per workgroup ([problem][workgroup][32 queries][64])
+__global__ __launch_bounds__(256) void attn_fewq_bwd_kernel(const AttnArgs a, int iters, unsigned int q_bytes, unsigned int kv_bytes,
+                                                            unsigned int o_bytes, unsigned int dkv_bytes, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, w = wave_id();
+    const int fr = lane & 15, fg = lane >> 4;
+    const int h = blockIdx.y % a.H, pg = blockIdx.y / a.H, b = pg / a.G, g = pg % a.G;
+    unsigned char* sQ = smem;                                       // shared: Q and dO rows of the 32 queries
+    unsigned char* sG = smem + X_IMG;
+    unsigned char* sK = smem + 2 * X_IMG + w * Y_WLDS_B;            // per wave: K rows of the trip, P o D, dS, staging
+    unsigned char* sP = sK + X_IMG;
+    unsigned char* sDS = sP + X_PIMG;
+    unsigned char* sS = sDS + X_PIMG;
+    const int nq = a.q.n, nk = a.k.n;
+    const float sc2 = a.scale * X_LOG2E;
+    const int krow0 = (int)(b * a.k.bs + a.k.base + g * a.k.gs), qrow0 = (int)(b * a.q.bs + a.q.base + g * a.q.gs);
+    auto mk = [&](const void* p, unsigned int bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000); };
+    const __amdgpu_buffer_rsrc_t rQ = mk(a.Q, q_bytes), rK = mk(a.K, kv_bytes), rV = mk(a.V, kv_bytes), rG = mk(a.dO, o_bytes), rO = mk(a.O, o_bytes);
+    const __amdgpu_buffer_rsrc_t rDK = mk(a.dK, dkv_bytes), rDV = mk(a.dV, dkv_bytes);
+    auto ld = [&](__amdgpu_buffer_rsrc_t r, unsigned int off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); };
+    auto ld_q = [&](__amdgpu_buffer_rsrc_t r, unsigned int off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16); };
+
+    u32x4_t q[2][2], gq[2][2];
+    float lse2[2], dl[2];
+    unsigned int hq[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int qi = t * 16 + fr;
+        const bool valid = qi < nq;
+        const int row = qrow0 + qi;
+        const unsigned int oq = valid ? (unsigned int)(row * a.ldq + a.qoff + h * HD + fg * 8) * 2u : X_OOB;
+        const unsigned int og = valid ? (unsigned int)(row * a.ldo + a.ooff + h * HD + fg * 8) * 2u : X_OOB;
+        q[t][0] = ld_q(rQ, oq);
+        q[t][1] = ld_q(rQ, oq + 64);
+        gq[t][0] = ld_q(rG, og);
+        gq[t][1] = ld_q(rG, og + 64);
+        hq[t] = a.drop_seed ^ y_fmix((unsigned int)(pg * nq + qi) * 0x9E3779B1u + (unsigned int)h);
+        // delta = rowsum(dO o O): this lane holds head dims fg*8 .. +7 and 32 + fg*8 .. +7 of query qi; O in fp32 when the forward kept it
+        float d = 0.f;
+        float ov[16];
+        if (a.O32) {
+            const float* op = a.O32 + ((long long)(valid ? row : qrow0) * a.ldo + a.ooff + h * HD + fg * 8);
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const f32x4_t v4 = *reinterpret_cast<const f32x4_t*>(op + c * 32 + e * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ov[c * 8 + e * 4 + j] = v4[j];
+                }
+        } else {
+            const u32x4_t o0 = ld_q(rO, og), o1 = ld_q(rO, og + 64);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ov[2 * j] = __uint_as_float(o0[j] << 16); ov[2 * j + 1] = __uint_as_float(o0[j] & 0xffff0000u);
+                ov[8 + 2 * j] = __uint_as_float(o1[j] << 16); ov[8 + 2 * j + 1] = __uint_as_float(o1[j] & 0xffff0000u);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            d = fmaf(__uint_as_float(gq[t][0][j] << 16), ov[2 * j], d);
+            d = fmaf(__uint_as_float(gq[t][0][j] & 0xffff0000u), ov[2 * j + 1], d);
+            d = fmaf(__uint_as_float(gq[t][1][j] << 16), ov[8 + 2 * j], d);
+            d = fmaf(__uint_as_float(gq[t][1][j] & 0xffff0000u), ov[8 + 2 * j + 1], d);
+        }
+        dl[t] = valid ? x_grp_sum(d) : 0.f;
+        lse2[t] = valid ? a.lse[(long long)row * a.H + h] * X_LOG2E : INFINITY;      // (prologue: one round trip per wave)
+    }
+    if (w < 2) {
+        *reinterpret_cast<u32x4_t*>(sQ + (w * 16 + fr) * XP + fg * 16) = w == 0 ? q[0][0] : q[1][0];
+        *reinterpret_cast<u32x4_t*>(sQ + (w * 16 + fr) * XP + 64 + fg * 16) = w == 0 ? q[0][1] : q[1][1];
+    } else {
+        *reinterpret_cast<u32x4_t*>(sG + ((w - 2) * 16 + fr) * XP + fg * 16) = w == 2 ? gq[0][0] : gq[1][0];
+        *reinterpret_cast<u32x4_t*>(sG + ((w - 2) * 16 + fr) * XP + 64 + fg * 16) = w == 2 ? gq[0][1] : gq[1][1];
+    }
+    __syncthreads();
+    const bool drop = a.drop_p > 0.f;
+    const float keep = drop ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t dq[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[t][dt] = zero;
+
+    struct Trip { u32x4_t k[2][2], v[2][2]; unsigned int odk[2], odv[2]; };
+    auto fetch = [&](int key0, Trip& tr) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int key = key0 + kt * 16 + fr;
+            const bool valid = key < nk;
+            const unsigned int ok_ = valid ? (unsigned int)((krow0 + key) * a.ldk + a.koff + h * HD + fg * 8) * 2u : X_OOB;
+            const unsigned int ov_ = valid ? (unsigned int)((krow0 + key) * a.ldv + a.voff + h * HD + fg * 8) * 2u : X_OOB;
+            tr.odk[kt] = valid ? (unsigned int)((krow0 + key) * a.lddk + a.dkoff + h * HD + fg * 8) * 2u : X_OOB;
+            tr.odv[kt] = valid ? (unsigned int)((krow0 + key) * a.lddv + a.dvoff + h * HD + fg * 8) * 2u : X_OOB;
+            tr.k[kt][0] = ld(rK, ok_);
+            tr.k[kt][1] = ld(rK, ok_ + 64);
+            tr.v[kt][0] = ld(rV, ov_);
+            tr.v[kt][1] = ld(rV, ov_ + 64);
+        }
+    };
+    const int k_begin = blockIdx.x * (X_NW * iters * 32);
+    Trip nx;
+    if (k_begin + w * 32 < nk) fetch(k_begin + w * 32, nx);
+    for (int it = 0; it < iters; ++it) {
+        const int key0 = k_begin + (it * X_NW + w) * 32;
+        if (key0 >= nk) break;
+        u32x4_t k[2][2], v[2][2];
+        unsigned int odk[2], odv[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            k[kt][0] = nx.k[kt][0]; k[kt][1] = nx.k[kt][1]; v[kt][0] = nx.v[kt][0]; v[kt][1] = nx.v[kt][1];
+            odk[kt] = nx.odk[kt]; odv[kt] = nx.odv[kt];
+            *reinterpret_cast<u32x4_t*>(sK + (kt * 16 + fr) * XP + fg * 16) = k[kt][0];
+            *reinterpret_cast<u32x4_t*>(sK + (kt * 16 + fr) * XP + 64 + fg * 16) = k[kt][1];
+        }
+        if (it + 1 < iters && key0 + X_NW * 32 < nk) fetch(key0 + X_NW * 32, nx);
+        x_wave_sync();
+        // ---- lane = query: S^T[key][query] -> P o D, dS; dQ^T += K^T dS^T
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4_t s[2], dp[2], ds[2], pd[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                s[kt] = x_mfma(x_bf(k[kt][1]), x_bf(q[t][1]), x_mfma(x_bf(k[kt][0]), x_bf(q[t][0]), zero));
+                dp[kt] = x_mfma(x_bf(v[kt][1]), x_bf(gq[t][1]), x_mfma(x_bf(v[kt][0]), x_bf(gq[t][0]), zero));
+            }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = key0 + kt * 16 + fg * 4 + r;
+                    const float p = key < nk ? x_exp2(fmaf(s[kt][r], sc2, -lse2[t])) : 0.f;     // padding queries: lse = +inf -> 0
+                    const float mu = drop ? y_drop(hq[t], key, a.drop_p, keep) : 1.0f;
+                    pd[kt][r] = p * mu;
+                    ds[kt][r] = p * (mu * dp[kt][r] - dl[t]);
+                }
+            const bf16x8_t bD = x_pack8(ds[0], ds[1]), bP = x_pack8(pd[0], pd[1]);
+            const u32x4_t dsv = __builtin_bit_cast(u32x4_t, bD), pdv = __builtin_bit_cast(u32x4_t, bP);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {                         // row t*16 + fr (query), keys kt*16 + fg*4 .. +3
+                *reinterpret_cast<u32x2_t*>(sP + (t * 16 + fr) * XPP + (kt * 16 + fg * 4) * 2) = u32x2_t{pdv[kt * 2], pdv[kt * 2 + 1]};
+                *reinterpret_cast<u32x2_t*>(sDS + (t * 16 + fr) * XPP + (kt * 16 + fg * 4) * 2) = u32x2_t{dsv[kt * 2], dsv[kt * 2 + 1]};
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dq[t][dt] = x_mfma(x_afrag(sK, dt, fr, fg), bD, dq[t][dt]);
+        }
+        x_wave_sync();
+        // ---- lane = key: dV^T = dO^T (P o D), dK^T = Q^T dS over the 32 queries; one 16-key tile at a time
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const bf16x8_t bV = x_bfrag(sP, kt, fr, fg), bK = x_bfrag(sDS, kt, fr, fg);
+            f32x4_t dvt[4], dkt[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dvt[dt] = x_mfma(x_afrag(sG, dt, fr, fg), bV, zero);
+                dkt[dt] = x_mfma(x_afrag(sQ, dt, fr, fg), bK, zero);
+            }
+            x_store_rows(sS, rDV, odv[kt], dvt, 1.0f, fr, fg);
+            x_store_rows(sS, rDK, odk[kt], dkt, a.scale, fr, fg);
+        }
+        x_wave_sync();                                               // the images are rewritten by the next trip
+    }
+    // ---- dQ^T of the four waves (lane (fr, fg): query t*16 + fr, head dims dt*16 + fg*4 .. +3) -> one partial per workgroup
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem + 2 * X_IMG + w * Y_WLDS_B);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4_t*>(red + (t * 16 + fr) * X_RED_PITCH + dt * 16 + fg * 4) = dq[t][dt];
+    __syncthreads();
+    float* dst = part + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 32 * HD;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int e = threadIdx.x + j * 256, qi = e >> 4, c4 = e & 15;
+        f32x4_t sum = zero;
+#pragma unroll
+        for (int ww = 0; ww < X_NW; ++ww)
+            sum += *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(smem + 2 * X_IMG + ww * Y_WLDS_B) + qi * X_RED_PITCH + c4 * 4);
+        *reinterpret_cast<f32x4_t*>(dst + qi * HD + c4 * 4) = sum;
+    }
+}
+
+// dQ = scale * sum of the workgroup partials in workgroup order; two workgroups per problem, one float4 per thread
+__global__ __launch_bounds__(256) void attn_fewq_reduce_kernel(const AttnArgs a, int nwg, const float* __restrict__ part) {
+    const int prob = blockIdx.x >> 1;
+    const int h = prob % a.H, pg = prob / a.H, b = pg / a.G, g = pg % a.G;
+    const int e = (blockIdx.x & 1) * 256 + threadIdx.x, qi = e >> 4, c4 = e & 15;
+    if (qi >= a.q.n) return;
+    const float* src = part + (long long)prob * nwg * 32 * HD + qi * HD + c4 * 4;
+    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+    for (int w0 = 0; w0 < nwg; w0 += 8) {
+        f32x4_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4_t*>(src + (long long)(w0 + u < nwg ? w0 + u : w0) * 32 * HD);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (w0 + u < nwg) s += v[u];
+    }
+    const u32x2_t pk = {pack_bf16x2(s[0] * a.scale, s[1] * a.scale), pack_bf16x2(s[2] * a.scale, s[3] * a.scale)};
+    const long long row = b * a.q.bs + a.q.base + g * a.q.gs + qi;
+    *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(a.dQ) + row * a.lddq + a.dqoff + h * HD + c4 * 4) = pk;
+}
+
 }  // namespace egv
 using namespace egv;
 
@@ -470,5 +867,62 @@ int egv_attn_fewkeys_bwd(const AttnArgs& a, int B, hipStream_t st) {
     hipLaunchKernelGGL(attn_fewkeys_bwd_kernel, dim3(nwg, B * a.G * a.H), dim3(256), X_BWD_LDS, st, a, fewkeys_iters(), (unsigned int)(qr * a.ldq * 2),
                        (unsigned int)kvb, (unsigned int)(qr * a.ldo * 2), (unsigned int)(qr * a.lddq * 2), (unsigned int)(qr * a.H * 4), a.ws);
     hipLaunchKernelGGL(attn_fewkeys_reduce_kernel, dim3(B * a.G * a.H * 4), dim3(256), 0, st, a, nwg, a.ws);
+    return 1;
+}
+
+// ---- few queries over many keys (text -> image)
+namespace {
+int fewq_iters() {
+    static const int it = egv_cfg_int("EGV_ATTN_FEWQ_ITERS", 6);
+    return it < 1 ? 1 : (it > 64 ? 64 : it);
+}
+bool fewq_shape_ok(const AttnArgs& a, int B, bool bwd) {
+    static const bool on = egv_cfg_on("EGV_ATTN_FEWQ", true);
+    auto ok8 = [](int x) { return (x % 8) == 0; };
+    if (!on || a.extra || a.mask || a.q.n < 1 || a.q.n > 32 || a.k.n < 512 || a.q.is != 1 || a.k.is != 1) return false;
+    if (!(ok8(a.ldq) && ok8(a.ldk) && ok8(a.ldv) && ok8(a.ldo) && ok8(a.qoff) && ok8(a.koff) && ok8(a.voff) && ok8(a.ooff))) return false;
+    if (!a.O || !a.ws) return false;
+    if (bwd) {
+        if (!a.dO || !a.lse || !a.dQ || !a.dK || !a.dV || !ok8(a.lddk) || !ok8(a.lddv) || !ok8(a.dkoff) || !ok8(a.dvoff)) return false;
+        if ((a.lddq % 4) || (a.dqoff % 4) || a.lddk != a.lddv) return false;
+    }
+    const long long qr = q_rows(a, B), kr = k_rows(a, B);
+    const long long ldq_max = a.ldq > a.ldo ? a.ldq : a.ldo, ldk_max = a.ldk > a.ldv ? a.ldk : a.ldv;
+    if (qr * ldq_max * 2 >= (1LL << 31) || kr * ldk_max * 2 >= (1LL << 31)) return false;
+    if (bwd && kr * a.lddk * 2 >= (1LL << 31)) return false;
+    return true;
+}
+}  // namespace
+int egv_attn_fewq_nwg(int k_n) {
+    const int per = X_NW * fewq_iters() * 32;
+    return (k_n + per - 1) / per;
+}
+// bytes of the partials: forward (m, l, o) states, backward dQ sums (the larger of the two: one buffer serves both)
+extern "C" long long egv_attn_fewq_workspace_bytes(int B, int G, int H, int k_n) {
+    return (long long)B * G * H * egv_attn_fewq_nwg(k_n) * 32 * X_RED_PITCH * 4;
+}
+// 1 if enqueued (O, optional O32, lse); a.ws >= egv_attn_fewq_workspace_bytes (checked by the caller)
+int egv_attn_fewq_fwd(const AttnArgs& a, int B, hipStream_t st) {
+    if (!fewq_shape_ok(a, B, false)) return 0;
+    const long long qr = q_rows(a, B), kr = k_rows(a, B);
+    const int nwg = egv_attn_fewq_nwg(a.k.n);
+    hipLaunchKernelGGL(attn_fewq_fwd_kernel, dim3(nwg, B * a.G * a.H), dim3(256), Y_FWD_LDS, st, a, fewq_iters(), (unsigned int)(qr * a.ldq * 2),
+                       (unsigned int)(kr * (a.ldk > a.ldv ? a.ldk : a.ldv) * 2), a.ws);
+    hipLaunchKernelGGL(attn_fewq_combine_kernel, dim3(B * a.G * a.H), dim3(256), 0, st, a, nwg, a.ws);
+    return 1;
+}
+// 1 if enqueued (dQ, dK, dV)
+int egv_attn_fewq_bwd(const AttnArgs& a, int B, hipStream_t st) {
+    if (!fewq_shape_ok(a, B, true)) return 0;
+    const long long qr = q_rows(a, B), kr = k_rows(a, B);
+    const int nwg = egv_attn_fewq_nwg(a.k.n);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fewq_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Y_BWD_LDS);
+        attr = true;
+    }
+    hipLaunchKernelGGL(attn_fewq_bwd_kernel, dim3(nwg, B * a.G * a.H), dim3(256), Y_BWD_LDS, st, a, fewq_iters(), (unsigned int)(qr * a.ldq * 2),
+                       (unsigned int)(kr * (a.ldk > a.ldv ? a.ldk : a.ldv) * 2), (unsigned int)(qr * a.ldo * 2), (unsigned int)(kr * a.lddk * 2), a.ws);
+    hipLaunchKernelGGL(attn_fewq_reduce_kernel, dim3(B * a.G * a.H * 2), dim3(256), 0, st, a, nwg, a.ws);
     return 1;
 }

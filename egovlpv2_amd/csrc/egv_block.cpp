@@ -232,6 +232,7 @@ struct Plain {
                   c = egv_attn_bwd_dkv_workspace_bytes(B, 1, H, nk, dkv_ns());
         long long m = a > b ? a : b;
         if (nk <= 32 && egv_attn_fewkeys_workspace_bytes(B, 1, H, nq) > m) m = egv_attn_fewkeys_workspace_bytes(B, 1, H, nq);
+        if (nq <= 32 && nk >= 512 && egv_attn_fewq_workspace_bytes(B, 1, H, nk) > m) m = egv_attn_fewq_workspace_bytes(B, 1, H, nk);
         return m > c ? m : c;
     }
     void fill(egv_attn_desc& d, const void* q, int ldq, const void* k, const void* v, int ldkv, void* O, float* lse) const {
@@ -262,7 +263,7 @@ struct Plain {
         d.O32 = dt == EGV_BF16 ? const_cast<float*>(o32) : nullptr;
         d.dO = dO; d.dQ = dq; d.dK = dk; d.dV = dv; d.lddq = lddq; d.lddk = d.lddv = lddkv; d.delta = delta;
         d.nsplit = fwd_ns(); d.ws = (float*)ws; d.ws_bytes = wsb;
-        if (nk <= 32 && mask_ok_fused()) {                          // many queries over <= 32 keys: one launch (egv_attn_cross.hip)
+        if ((nk <= 32 && mask_ok_fused()) || (nq <= 32 && nk >= 512 && !mask)) {   // many queries over <= 32 keys, or <= 32 queries over many keys: one launch (egv_attn_cross.hip)
             const int r = egv_attn_bwd_fused(dt, &d, st);
             if (r <= 0) return r;
         }

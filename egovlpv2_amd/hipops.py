@@ -866,6 +866,10 @@ class PlainAttnFn(Function):
         lse = torch.empty(B * nq, H, dtype=torch.float32, device=q.device)
         ns = 1 if nk <= 224 else (nk + 223) // 224             # MFMA kernel per 224-key chunk + combine
         ws, nb = _split_ws(0, B, 1, H, nq, ns, q.device)
+        if q.dtype == torch.bfloat16 and nq <= 32 and nk >= 512 and mask is None:
+            # few queries over many keys (text -> image): one streaming launch + a combination (egv_attn_cross.hip) when the workspace holds its partials
+            nb = max(nb, lib.egv_attn_fewq_workspace_bytes(B, 1, H, nk))
+            ws = workspace(nb, q.device, slot=1)
         d = _mk_desc(q, k, v, O, lse, B, 1, H, _rowset(nq, 0, 0, 1, nq), _rowset(nk, 0, 0, 1, nk), None, scale, mask=mask,
                      nsplit=ns, ws=ws, ws_bytes=nb, drop_p=drop_p, drop_seed=drop_seed)
         check(lib.egv_attn_fwd(_dt(q), C.byref(d), _st()), 'egv_attn_fwd')
@@ -885,9 +889,12 @@ class PlainAttnFn(Function):
         delta = torch.empty(B * nq, H, dtype=torch.float32, device=q.device)
         qs, ks = _rowset(nq, 0, 0, 1, nq), _rowset(nk, 0, 0, 1, nk)
         kw = dict(mask=mask, dO=dO, dQ=dq, dK=dk, dV=dv, delta=delta, drop_p=drop_p, drop_seed=drop_seed)
-        if q.dtype == torch.bfloat16 and nk <= 32 and nq >= 128 and drop_p <= 0.0:
-            # many queries over few keys (image -> text): dQ, dK, dV in one launch + a fixed-order partial sum (egv_attn_cross.hip)
-            nb = lib.egv_attn_fewkeys_workspace_bytes(B, 1, H, nq)
+        fewk = q.dtype == torch.bfloat16 and nk <= 32 and nq >= 128 and drop_p <= 0.0
+        fewq = q.dtype == torch.bfloat16 and nq <= 32 and nk >= 512 and mask is None
+        if fewk or fewq:
+            # many queries over few keys (image -> text) or few queries over many keys (text -> image): dQ, dK, dV in one launch + a
+            # fixed-order partial sum (egv_attn_cross.hip)
+            nb = lib.egv_attn_fewkeys_workspace_bytes(B, 1, H, nq) if fewk else lib.egv_attn_fewq_workspace_bytes(B, 1, H, nk)
             ws = torch.empty(nb // 4, dtype=torch.float32, device=q.device)
             d = _mk_desc(q, k, v, O, lse, B, 1, H, qs, ks, None, scale, nsplit=1, ws=ws, ws_bytes=nb, **kw)
             rc = lib.egv_attn_bwd_fused(_dt(q), C.byref(d), _st())

@@ -204,6 +204,11 @@ int egv_attn_bwd_fused(int dtype, const egv_attn_desc* d, void* stream);
  * key mask allowed, no extra row / dropout): egv_attn_fwd takes a one-launch kernel for it, and egv_attn_bwd_fused one launch for dQ, dK, dV
  * plus a fixed-order sum of per-workgroup partials when d->ws holds >= egv_attn_fewkeys_workspace_bytes (d->delta is not read). */
 long long egv_attn_fewkeys_workspace_bytes(int B, int G, int H, int q_n);
+/* The mirror image, <= 32 queries over >= 512 keys (text-to-image cross attention, roberta.py:241-327: no mask, dropout allowed): with
+ * d->ws >= egv_attn_fewq_workspace_bytes egv_attn_fwd runs one streaming launch + a combination (O, optional O32, lse), and
+ * egv_attn_bwd_fused one launch for dK, dV (stored per key) and dQ (fixed-order sum of per-workgroup partials); delta comes from O32
+ * when it is set, else from O. */
+long long egv_attn_fewq_workspace_bytes(int B, int G, int H, int k_n);
 /* The same for launches whose groups are one 16-row tile (the 17-row time attention), on the dQ + dK/dV kernel pair: when
  * egv_attn_bwd_pair_covers_extra returns 1 for a descriptor with d->ws set, egv_attn_bwd_dq and egv_attn_bwd_dkv leave the extra
  * row's gradients as per-group partials and egv_attn_bwd_extra_reduce(self_term = 1) sums them (adding the extra-query x

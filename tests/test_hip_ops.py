@@ -252,7 +252,7 @@ def test_divided_attention(ops, dtype, mode, Fr, N):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('nq,nk,masked,nsplit', [(16, 16, True, 1), (32, 197, False, 1), (300, 32, True, 4), (5, 70, False, 1)])
+@pytest.mark.parametrize('nq,nk,masked,nsplit', [(16, 16, True, 1), (32, 197, False, 1), (300, 32, True, 4), (5, 70, False, 1), (32, 3137, False, 1), (20, 1000, False, 1)])
 def test_plain_attention(ops, dtype, nq, nk, masked, nsplit):
     B, H = 2, 3
     D = H * 64
@@ -342,7 +342,7 @@ def _attn_keep_mult(ops, dtype, B, H, nq, nk, p, seed):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('nq,nk,masked,nsplit', [(32, 32, True, 1), (32, 300, False, 1), (300, 32, True, 4)])
+@pytest.mark.parametrize('nq,nk,masked,nsplit', [(32, 32, True, 1), (32, 300, False, 1), (300, 32, True, 4), (32, 1100, False, 1), (9, 600, False, 1)])
 def test_plain_attention_dropout(ops, dtype, nq, nk, masked, nsplit):
     """roberta.py:313 attention-probability dropout inside the kernels: forward and all three gradients against torch
     math using the very mask the kernels generate (recovered through the forward itself)."""

@@ -51,3 +51,16 @@ def fb():
     o.backward(do, retain_graph=True)
 t_b = timeit(fb)
 print(f"i2t FEWKEYS={os.environ.get('EGV_ATTN_FEWKEYS', '1')} ITERS={os.environ.get('EGV_ATTN_FEWKEYS_ITERS', '2')}: fwd {t_f:7.1f} us   bwd {t_b:7.1f} us (incl. the autograd glue of a per-op call)", flush=True)
+
+# text -> image cross attention of a fused text layer (32 queries over 25 096 video keys, dropout 0.1): EGV_ATTN_FEWQ=0/1, EGV_ATTN_FEWQ_ITERS
+qt = torch.randn(B * L, H * 64, device='cuda').bfloat16().requires_grad_(True)
+kvv = torch.randn(B * S, 2 * H * 64, device='cuda').bfloat16().requires_grad_(True)
+dot = torch.randn(B * L, H * 64, device='cuda').bfloat16()
+f = lambda: ops.plain_attention(qt.detach(), kvv.detach()[:, :D], kvv.detach()[:, D:], B, H, L, S, 0.125, drop_p=0.1, drop_seed=7)
+t_f = timeit(f)
+o = ops.plain_attention(qt, kvv[:, :D], kvv[:, D:], B, H, L, S, 0.125, drop_p=0.1, drop_seed=7)
+def fb():
+    qt.grad = None; kvv.grad = None
+    o.backward(dot, retain_graph=True)
+t_b = timeit(fb)
+print(f"t2i FEWQ={os.environ.get('EGV_ATTN_FEWQ', '1')} ITERS={os.environ.get('EGV_ATTN_FEWQ_ITERS', '6')}: fwd {t_f:7.1f} us   bwd {t_b:7.1f} us (incl. the autograd glue of a per-op call)", flush=True)
