@@ -18,6 +18,10 @@ GROUPS = [('gemm_pp_kernel', r'gemm_pp_kernel'), ('gemm_ring_kernel<256x128>', r
           ('attn_time_bwd (round 4: one-launch backward)', r'attn_time_bwd_kernel'),
           ('attn_space_fwd (round 4: row-major LDS images)', r'attn_space_fwd_kernel'),
           ('attn_space_bwd (round 4: two-phase one-launch backward)', r'attn_space_bwd_kernel'),
+          ('attn_fewkeys_fwd (round 5: image -> text, 25 096 queries over 32 keys)', r'attn_fewkeys_fwd_kernel'),
+          ('attn_fewkeys_bwd (round 5)', r'attn_fewkeys_bwd_kernel'),
+          ('attn_fewq_fwd (round 5: text -> image, 32 queries over 25 096 keys)', r'attn_fewq_fwd_kernel'),
+          ('attn_fewq_bwd (round 5)', r'attn_fewq_bwd_kernel'),
           ('sum_ln (round 4: fp32 residual sums + LayerNorm of the video tower)', r'sum_ln_kernel'), ('layernorm_fwd', r'layernorm_fwd_kernel'), ('layernorm_bwd', r'layernorm_bwd(_bf16)?_kernel'), ('reduce_slabs', r'reduce_slabs_kernel')]
 
 
