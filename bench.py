@@ -285,7 +285,6 @@ def main():
     if use_events and rank == 0:
         kinds = {-1: 'launch declined by a one-pass attention entry point (no kernel ran: the caller took another path)', 0: 'gemm_kernel<bf16,NT> (generic 128x128)', 1: 'gemm_kernel<bf16,NN> (generic)', 2: 'gemm_kernel<bf16,TN> (generic)', 7: 'gemm_skinny_kernel (bf16 NT, <= 16 rows: projection heads)', 9: 'wgrad_small_m_kernel (outer product, <= 16 rows)',
                  4: 'gemm_kernel<f32,NT>', 5: 'gemm_kernel<f32,NN>', 6: 'gemm_kernel<f32,TN>',
-                 11: 'gemm_small_kernel (bf16 NT, <= 768 rows: text-side Linears, 64x64 tiles of independent waves)',
                  8: 'gemm_ring_kernel<256x128> (NT fwd+dgrad, DMA ring)', 10: 'gemm_wgrad_ring_kernel (TN wgrad, 256x128 DMA ring)',
                  12: 'gemm_pp_kernel (NT fwd+dgrad, persistent ping-pong 256x256)', 13: 'gemm_ring_kernel<128x128> (NT, text-side grids)',
                  14: 'gemm_wgrad_pp_kernel (TN wgrad, ping-pong 256x256, one launch per gradient)',

@@ -8,7 +8,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -Wno-unused-va
 if [ -n "$EGV_INSTRUMENT" ]; then FLAGS="$FLAGS -DEGV_INSTRUMENT"; rm -f build/*.o; fi
 mkdir -p build
 pids=()
-for f in egv_gemm.hip egv_gemm2.hip egv_gemm3.hip egv_gemm4.hip egv_gemm5.hip egv_gemm6.hip egv_mx.hip egv_norm.hip egv_attn.hip egv_attn_mfma.hip egv_attn_time.hip egv_attn_space.hip egv_attn_cross.hip egv_misc.hip egv_optim.hip; do
+for f in egv_gemm.hip egv_gemm2.hip egv_gemm3.hip egv_gemm4.hip egv_gemm5.hip egv_mx.hip egv_norm.hip egv_attn.hip egv_attn_mfma.hip egv_attn_time.hip egv_attn_space.hip egv_attn_cross.hip egv_misc.hip egv_optim.hip; do
   o=build/${f%.hip}.o
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ egv_common.h -nt "$o" ] || [ egv_attn.h -nt "$o" ] || [ egv_gemm.h -nt "$o" ] || [ egv_wgrad_core.h -nt "$o" ] || [ ../../include/egovlp_hip.h -nt "$o" ]; then
     # attention: keep MFMA accumulators in VGPRs (they feed the softmax VALU code directly; the default AGPR form costs an
@@ -27,5 +27,5 @@ for f in egv_api.cpp egv_block.cpp; do
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT build/egv_gemm.o build/egv_gemm2.o build/egv_gemm3.o build/egv_gemm4.o build/egv_gemm5.o build/egv_gemm6.o build/egv_mx.o build/egv_norm.o build/egv_attn.o build/egv_attn_mfma.o build/egv_attn_time.o build/egv_attn_space.o build/egv_attn_cross.o build/egv_misc.o build/egv_optim.o build/egv_api.o build/egv_block.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT build/egv_gemm.o build/egv_gemm2.o build/egv_gemm3.o build/egv_gemm4.o build/egv_gemm5.o build/egv_mx.o build/egv_norm.o build/egv_attn.o build/egv_attn_mfma.o build/egv_attn_time.o build/egv_attn_space.o build/egv_attn_cross.o build/egv_misc.o build/egv_optim.o build/egv_api.o build/egv_block.o
 echo "built $OUT"

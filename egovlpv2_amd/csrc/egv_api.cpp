@@ -37,14 +37,11 @@ const Switch g_switches[] = {
     {"EGV_ATTN_FEWQ_ITERS", 6, "... 32-key tiles per wave (a workgroup covers 128 x this many keys and leaves one partial state / dQ)"},
     {"EGV_ATTN_TIME_FUSED", 1, "one-launch forward / backward of the <= 16-row attention groups (time attention), egv_attn_time.hip"},
     {"EGV_ATTN_SPACE_NEW", 1, "space attention on row-major LDS images, egv_attn_space.hip (0: the kernels of egv_attn_mfma.hip)"},
-    {"EGV_SPACE_BWD_REV", 1, "space-attention backward: the key tiles of its second phase go to the waves from the last one down (the query tiles of the first phase from the first one up): same bits, evener SIMD shares"},
     {"EGV_ATTN_FUSED_CLS", 1, "the group launches also serve the CLS row (per-group partials + one small sum)"},
     {"EGV_ATTN_FUSED_BWD", 1, "one-launch attention backward where a kernel covers the shape (0: dQ + dK/dV kernel pair)"},
     {"EGV_WGRAD_SMALL_M", 1, "weight gradients over <= 16 rows as an outer product (wgrad_small_m_kernel) instead of a one-K-step MFMA GEMM"},
     {"EGV_WGRAD_PP", 1, "ping-pong 256x256 weight-gradient kernel (0: 256x128 ring kernel)"},
     {"EGV_WGRAD_ITEMS", 224, "(tile, split) items of a one-gradient-per-launch weight gradient: 7/8 of the CUs"},
-    {"EGV_GEMM_SMALL_M", 768, "most rows for which a bf16 Linear takes the small-grid kernel (64 x 64 tiles of independent waves, four K-slices from K = 2048: egv_gemm6.hip; 0: off, the 128 x 128 ring kernel)"},
-    {"EGV_GEMM_SMALL_SPLITK", 2048, "... shortest K that is cut into four K-slices (summed inside the launch in slice order)"},
     {"EGV_GEMM_PP", 1, "persistent ping-pong GEMM for large grids (0: DMA-ring kernels only)"},
     {"EGV_PP_STAMPS", 0, "instrumentation build only: per-K-tile cycle stamps of the persistent GEMM"},
     {"EGV_PP_CUS", 0, "cap of the persistent GEMM's grid (0: all CUs)"},

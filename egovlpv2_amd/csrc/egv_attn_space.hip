@@ -35,7 +35,6 @@ struct SpaceArgs {
     int qcol, kcol, vcol, ocol, dqcol, dkcol, dvcol;   // first column (elements, from the tensor's base) of head 0
     int H, G, n, nb;
     int bs, base, gs, is, cls_bs;               // row(b, g, i) = b*bs + base + g*gs + i*is; CLS row = b*cls_bs
-    int rev;                                    // backward: phase B hands out the key tiles from the last wave down (EGV_SPACE_BWD_REV)
     float scale;
     unsigned int qkv_bytes, o_bytes, dqkv_bytes, lse_bytes;
 };
@@ -349,17 +348,14 @@ __global__ __launch_bounds__(64 * SNW, (NT <= 14 ? 4 : 2)) void attn_space_bwd_k
         lse2 = nlse2;
     }
     // ================= phase B: queries in LDS, every wave's key tiles -> dK, dV (lane = key) =================
-    // 13 tiles over 8 waves: in phase A waves 0-4 took two query tiles; the key tiles go out from the other end (waves 7-3 take
-    // two), so that the SIMDs of a CU end up with more even shares (which wave computes a tile does not change its bits)
-    const int kw = a.rev ? SNW - 1 - w : w;
     u32x4_t k0, k1, v0, v1;
-    ld2(rQ, foff(kw, a.ld, a.kcol), k0, k1);
-    ld2(rQ, foff(kw, a.ld, a.vcol), v0, v1);
+    ld2(rQ, foff(w, a.ld, a.kcol), k0, k1);
+    ld2(rQ, foff(w, a.ld, a.vcol), v0, v1);
     __syncthreads();                                               // every wave is done with the key images; sL / sD are complete
     s_stage<NT>(im0, rQ, a.ld, a.qcol + q.h * HD, q, tid);
     s_stage<NT>(im1, rG, a.ldo, a.ocol + q.h * HD, q, tid);
     __syncthreads();
-    for (int kt = kw; kt < nlt; kt += SNW) {
+    for (int kt = w; kt < nlt; kt += SNW) {
         u32x4_t nk0, nk1, nv0, nv1;
         ld2(rQ, foff(kt + SNW, a.ld, a.kcol), nk0, nk1);
         ld2(rQ, foff(kt + SNW, a.ld, a.vcol), nv0, nv1);
@@ -439,8 +435,6 @@ static bool space_args(const AttnArgs& a, int B, bool backward, SpaceArgs& s) {
     s.H = a.H; s.G = a.G; s.n = a.q.n; s.nb = B;
     s.bs = (int)a.q.bs; s.base = (int)a.q.base; s.gs = (int)a.q.gs; s.is = (int)a.q.is; s.cls_bs = (int)a.extra_bs;
     s.scale = a.scale;
-    static const int rev = egv_cfg_int("EGV_SPACE_BWD_REV", 1);
-    s.rev = rev;
     s.qkv_bytes = (unsigned int)(rows * a.ldq * 2); s.o_bytes = (unsigned int)(rows * a.ldo * 2);
     if (backward) {
         if (!a.dO || !a.lse || !a.delta || !a.dQ || !a.dK || !a.dV) return false;
@@ -480,10 +474,16 @@ static void launch_space_bwd(const SpaceArgs& s, int nwg, hipStream_t st) {
     }
     hipLaunchKernelGGL((attn_space_bwd_kernel<NT, EXACT>), dim3(nwg), dim3(64 * SNW), lds, st, s);
 }
+// nt == 3: the 33-row groups of the 32-frame time attention (BASELINE.json configs[3]: CLS + 32 frames of one patch position); without
+// its own instance they ran on the five-tile form with run-time row counts (two dead key tiles per query tile).  -DSPACE_NT3=0: that form again
+#ifndef SPACE_NT3
+#define SPACE_NT3 1
+#endif
 #define SPACE_DISPATCH(FN)                                                   \
     do {                                                                     \
         const int nt = (s.n + 1 + 15) / 16;                                  \
         if (nt == 13) FN<13, true>(s, nwg, st);                              \
+        else if (nt == 3 && SPACE_NT3) FN<3, true>(s, nwg, st);              \
         else if (nt == 14) FN<14, true>(s, nwg, st);                         \
         else if (nt == 17) FN<17, true>(s, nwg, st);                         \
         else if (nt == 5) FN<5, true>(s, nwg, st);                           \

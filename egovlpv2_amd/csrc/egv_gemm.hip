@@ -274,7 +274,6 @@ using namespace egv;
 
 void* egv_prof_begin(void* stream);
 void egv_prof_end(void* handle, void* stream, double flops, int kind, double bytes);
-int egv_gemm6_launch(const egv::GemmArgs& g, int a_trans, int b_trans, int out_f32, hipStream_t st);   // egv_gemm6.hip
 
 static inline int vec_ok(const void* p, int ld, int dtype) {
     const int vec = dtype == EGV_BF16 ? 8 : 4;
@@ -374,11 +373,6 @@ extern "C" int egv_gemm(int dtype, int a_trans, int b_trans, int M, int N, int K
         hipLaunchKernelGGL(gemm_skinny_kernel, dim3((N + 15) / 16), dim3(256), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc,
                            bias, act, M, N, K, (bf16_t*)pre);
         egv_prof_end(ph, stream, 2.0 * M * N * K, 7, abytes);        // 7 = skinny (<= 16 rows)
-        EGV_LAUNCH_CHECK();
-        return 0;
-    }
-    if (dtype == EGV_BF16 && egv_gemm6_launch(g, a_trans, b_trans, out_f32, st)) {
-        egv_prof_end(ph, stream, 2.0 * M * N * K, 11, abytes);       // 11 = small-grid kernel (text rows), egv_gemm6.hip
         EGV_LAUNCH_CHECK();
         return 0;
     }

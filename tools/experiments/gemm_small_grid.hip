@@ -1,3 +1,10 @@
+// EXPERIMENT, NOT IN THE PRODUCT BUILD (profiles/round5_experiments.md section 14): built, tested against fp64 (8 shapes x epilogue kinds, row
+// independence, run-to-run bits), measured, removed.  Isolated 7.58 ms per step for the 314 text-side launches against 8.15 ms on the
+// 128 x 128 ring kernel; inside the two-stream step 19.5 against 16.9 ms and the step +2.2 ms (72.9 against 70.7 ms, alternating): the
+// text stream's kernels wait for CUs the persistent grids of the other streams hold, and 192-576 short workgroups take longer to find
+// them than 12-48.  To build it again: add this file to csrc/build.sh and call egv_gemm6_launch from egv_gemm before egv_gemm2_launch
+// (commit 5a325e7 has the wiring, the switches EGV_GEMM_SMALL_M / EGV_GEMM_SMALL_SPLITK and the tests).
+//
 // Small-grid bf16 NT GEMM for gfx950: C[M,N] = epilogue(A[M,K] B[N,K]^T) for the Linears over the TEXT rows of a step (RobertaLayer's
 // query / key / value, attention outputs, intermediate / output dense and their data gradients: roberta.py:226-236, 338-349, 380-420;
 // M = B * 32 = 256 ... 768 rows).  As 128 x 128 tiles these are 12-48 workgroups that each walk K alone through 24-96 barrier-separated
