@@ -94,6 +94,7 @@ BLOCK_FP8 = 4
 BLOCK_TAIL = 8
 BLOCK_H3_READY = 16
 BLOCK_HEAD = 32
+BLOCK_INFER = 64
 
 
 # name -> (restype, argtypes); every symbol declared in include/egovlp_hip.h

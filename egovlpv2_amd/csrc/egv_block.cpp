@@ -483,6 +483,10 @@ extern "C" int egv_vblock_fwd(const egv_vblock_desc* d) {
     CuLimit fwd_limit(d->fwd_cus > 0 && d->fwd_cus < device_cus() ? d->fwd_cus : 0, 0);   // (exact: the rest of the chip belongs to the other chain)
     static const bool epi_q = egv_cfg_on("EGV_MX_EPI_QUANT", true);
     const bool mlp_chain = epi_q && f8.on && d->wq[VW_FC1] && d->wq_s[VW_FC1] && d->wq[VW_FC2] && d->wq_s[VW_FC2];
+    // EGV_BLOCK_INFER: no backward call follows -- what only the backward pass reads is not written.  That is the MLP's pre-activation
+    // (M x Hd: as large as the activation itself; fc1 then runs the GELU epilogue without the second store).  Not with MX-fp8
+    // operands (their fc1 epilogue is built with the saved pre-activation only).
+    void* const fc1_pre = ((d->flags & EGV_BLOCK_INFER) && !f8.on) ? nullptr : (void*)(sv + L.pre);
     // one Linear over the M video tokens: MX-fp8 when the desc carries the quantised weight, bf16 otherwise
     auto lin = [&](int w, int N, int K, const void* x, void* y, int act, const void* r1, void* pre) -> int {
         if (f8.on && d->wq[w] && d->wq_s[w]) return f8.lin(N, K, x, d->wq[w], d->wq_s[w], d->b[w], y, act, r1, pre, nullptr, 0);
@@ -542,7 +546,7 @@ extern "C" int egv_vblock_fwd(const egv_vblock_desc* d) {
             a1 = sv + L.s; ag = sv + L.pg;
         }
         BCHK(sumln(a1, nullptr, ag, nullptr, sv + L.sr, sv + L.h2, VL_NORM2, (float*)(sv + L.stats2)));
-        BCHK(lin(VW_FC1, Hd, D, sv + L.h2, sv + L.act, mlp_act(dt), nullptr, sv + L.pre));
+        BCHK(lin(VW_FC1, Hd, D, sv + L.h2, sv + L.act, mlp_act(dt), nullptr, fc1_pre));
         BCHK(lin(VW_FC2, D, Hd, sv + L.act, d->out, 0, nullptr, nullptr));                         // the MLP's output, then out = sr + it in place
         // the block's output sum, in fp32 and bf16 -- and, when the caller names the next block's norm3 and save slots, that LayerNorm too
         const bool fold = d->next_h && d->next_g && d->next_b && d->next_stats;
@@ -568,7 +572,7 @@ extern "C" int egv_vblock_fwd(const egv_vblock_desc* d) {
         BCHK(lin_fwd(dt, M, D, D, sv + L.o, d->w[VW_PROJ_I2T], d->b[VW_PROJ_I2T], sv + L.sr, 0, d->alpha, sv + L.s, d->x, sv + L.pg, st));
     }
     // MLP (:226): sr + fc2(gelu(fc1(norm2 sr)))
-    BCHK(ln_lin(VL_NORM2, sv + L.sr, sv + L.h2, (float*)(sv + L.stats2), VW_FC1, Hd, D, sv + L.act, mlp_act(dt), sv + L.pre));
+    BCHK(ln_lin(VL_NORM2, sv + L.sr, sv + L.h2, (float*)(sv + L.stats2), VW_FC1, Hd, D, sv + L.act, mlp_act(dt), fc1_pre));
     if (mlp_chain) BCHK(f8.lin_from_q2(D, Hd, d->wq[VW_FC2], d->wq_s[VW_FC2], d->b[VW_FC2], d->out, sv + L.sr));
     else BCHK(lin(VW_FC2, D, Hd, sv + L.act, d->out, 0, sv + L.sr, nullptr));
     return 0;

@@ -1219,6 +1219,8 @@ class VideoBlockFn(Function):
             out32 = torch.empty(x.shape, dtype=torch.float32, device=x.device)
             d.flags |= L.BLOCK_RES_F32
             d.x32, d.out32 = _p(x32), _p(out32)
+        if len(cfg) > 13 and cfg[13]:
+            d.flags |= L.BLOCK_INFER                     # called under no_grad: no backward call will read this call's save buffer
         nsave = lib.egv_vblock_save_bytes(C.byref(d))
         pre_save, nxt = (cfg[11], cfg[12]) if res32 else (None, None)
         if pre_save is not None and pre_save.numel() == nsave:
@@ -1497,7 +1499,7 @@ def video_block(x, params, B, Fr, N, H, Hd, eps, y=None, y_mask=None, L=0, fp8=F
         if next_ln is not None and not SW.on('EGV_LN_FOLD'):
             next_ln = None
     cfg = (B, Fr, N, H, Hd, float(eps), L if y is not None else 0, _tracks_grad(params), bool(fp8), res32, stream32(x) if res32 else None,
-           pre, next_ln if res32 else None)
+           pre, next_ln if res32 else None, (not torch.is_grad_enabled()) and SW.on('EGV_INFER_LEAN'))
     if not res32:
         return VideoBlockFn.apply(cfg, x, y, y_mask, *params)
     out, out32, nsv = VideoBlockFn.apply(cfg, x, y, y_mask, *params)

@@ -24,6 +24,7 @@ SWITCHES = {
     'EGV_TEXT_RES32': ('1', 'fp32 residual stream of the text tower in the bf16 mode'),
     'EGV_VIDEO_RES32': ('1', 'fp32 residual stream of the video tower in the bf16 mode (sums and LayerNorm inputs in fp32, as under autocast)'),
     'EGV_CLS_TAIL': ('1', 'the last block of a video pass computes its CLS rows only (attn.proj, image-to-text part and MLP on B rows instead of B*S)'),
+    'EGV_INFER_LEAN': ('1', 'video blocks called under torch.no_grad() do not write what only a backward pass would read (the MLP\'s pre-activation): EGV_BLOCK_INFER'),
     'EGV_LN_FOLD': ('1', 'fp32 video stream: a block\'s output pass also writes the next block\'s first LayerNorm (one HBM pass less per block)'),
     'EGV_ITM_RES32': ('1', 'the ITM pass gathers the fp32 value of the shared video prefix with the clips (0: it restarts from the bf16 rows)'),
     'EGV_VIDEO_FP8': ('0', 'MX-fp8 forward / data-gradient GEMMs in the video blocks (configs[4])'),

@@ -834,6 +834,33 @@ def test_layernorm_fold_and_clip_gather_are_bitwise_neutral_bf16(monkeypatch):
         assert torch.equal(g, out['0'][1][n]), n
 
 
+def test_inference_calls_skip_backward_only_stores_bitwise_neutral_bf16(monkeypatch):
+    """round 5: a video block called under torch.no_grad() (infer(), validation, feature extraction) is told so (EGV_BLOCK_INFER) and does
+    not write the MLP's pre-activation -- fc1 runs its GELU epilogue with one store instead of two.  The activation is formed from the
+    same fp32 sums: every output of infer() for the three tasks must be bit-identical with the flag on and off; full token geometry,
+    3 + 3 layers, two fused."""
+    from egovlpv2_amd.config import PathConfig
+    from egovlpv2_amd.synthetic import make_state_dict, make_batch
+    cfg = PathConfig(depth=3, n_fuse=2, frames=4, img=224)
+    sd = make_state_dict(cfg, 11)
+    data, _, _ = make_batch(cfg, 4, 16, 31)
+    cu = _to_cuda(data)
+    out = {}
+    for lean in ('1', '0'):
+        monkeypatch.setenv('EGV_INFER_LEAN', lean)
+        m = _build(cfg, sd, torch.bfloat16).eval()
+        with torch.no_grad():
+            r = {}
+            for task in ('EgoNCE', 'ITM', 'MLM'):
+                r.update({task + '.' + k: v.clone() for k, v in m.infer(cu, task_names=task).items() if torch.is_tensor(v)})
+        torch.cuda.synchronize()
+        out[lean] = r
+    assert set(out['1']) == set(out['0']) and len(out['1']) >= 3
+    for k, v in out['1'].items():
+        assert torch.isfinite(v.float()).all(), k
+        assert torch.equal(v, out['0'][k]), k
+
+
 def test_cls_only_last_block_matches_the_full_block_bf16(monkeypatch):
     """round 5: the last block of a video pass is read at its CLS rows only (video_transformer.py:392-394, model.py:275), so its
     space-attention query, attn.proj, image-to-text part and MLP run on B rows (model.py::_video_block_tail, EGV_CLS_TAIL) and the dead
