@@ -528,7 +528,9 @@ extern "C" int egv_vblock_fwd(const egv_vblock_desc* d) {
         BCHK(lin(VW_TQKV, 3 * D, D, sv + L.h3, sv + L.qkv_t, 0, nullptr, nullptr));
         BCHK(dvt.fwd(sv + L.qkv_t, sv + L.tctx, (float*)(sv + L.lse_t), aws, awb, st));
         BCHK(lin(VW_TPROJ, D, D, sv + L.tctx, sv + L.tr, 0, nullptr, nullptr));                    // the projection, then tr = x + it in place
-        BCHK(sumln(sv + L.tr, nullptr, nullptr, nullptr, sv + L.tr, sv + L.h1, VL_NORM1, (float*)(sv + L.stats1)));
+        // (EGV_BLOCK_INFER: the bf16 roundings of the two inner sums, tr and sr, are read by the backward pass only -- not written)
+        const bool lean = (d->flags & EGV_BLOCK_INFER) != 0;
+        BCHK(sumln(sv + L.tr, nullptr, nullptr, nullptr, lean ? nullptr : sv + L.tr, sv + L.h1, VL_NORM1, (float*)(sv + L.stats1)));
         BCHK(lin(VW_SQKV, 3 * D, D, sv + L.h1, sv + L.qkv_s, 0, nullptr, nullptr));
         if (head) return 0;                                        // the caller goes on with the CLS query alone (model.py: _video_block_tail)
         BCHK(dvs.fwd(sv + L.qkv_s, sv + L.sctx, (float*)(sv + L.lse_s), aws, awb, st));
@@ -545,7 +547,7 @@ extern "C" int egv_vblock_fwd(const egv_vblock_desc* d) {
             BCHK(lin_fwd(dt, M, D, D, sv + L.o, d->w[VW_PROJ_I2T], d->b[VW_PROJ_I2T], sv + L.pg, 0, nullptr, nullptr, nullptr, nullptr, st));
             a1 = sv + L.s; ag = sv + L.pg;
         }
-        BCHK(sumln(a1, nullptr, ag, nullptr, sv + L.sr, sv + L.h2, VL_NORM2, (float*)(sv + L.stats2)));
+        BCHK(sumln(a1, nullptr, ag, nullptr, lean ? nullptr : sv + L.sr, sv + L.h2, VL_NORM2, (float*)(sv + L.stats2)));
         BCHK(lin(VW_FC1, Hd, D, sv + L.h2, sv + L.act, mlp_act(dt), nullptr, fc1_pre));
         BCHK(lin(VW_FC2, D, Hd, sv + L.act, d->out, 0, nullptr, nullptr));                         // the MLP's output, then out = sr + it in place
         // the block's output sum, in fp32 and bf16 -- and, when the caller names the next block's norm3 and save slots, that LayerNorm too

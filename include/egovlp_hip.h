@@ -365,7 +365,8 @@ typedef struct egv_vblock_desc {
                                  the MLP on B rows (model.py: _video_block_tail) instead of on all M: 66 % of the block's matrix work is dead. */
 #define EGV_BLOCK_INFER 64    /* egv_vblock_fwd: no egv_vblock_bwd call will be made on this call's `save` (inference, validation: torch.no_grad()) -- what only
                                  the backward pass reads is not written: the MLP's pre-activation [M, Hd] (fc1 runs its GELU epilogue without the second
-                                 store).  Ignored with EGV_BLOCK_FP8.  Outputs are bitwise those of a call without the flag. */
+                                 store; not with EGV_BLOCK_FP8) and, with EGV_BLOCK_RES_F32, the bf16 roundings of the two inner residual sums.
+                                 Outputs are bitwise those of a call without the flag. */
 #define EGV_BLOCK_H3_READY 16 /* egv_vblock_fwd with EGV_BLOCK_RES_F32: the h3 / stats3 slots of `save` were filled by the previous call (next_h / next_stats) */
 long long egv_vblock_save_bytes(const egv_vblock_desc* d);
 /* byte offsets of the stats3 [M][2] fp32 and h3 [M, D] slots inside a save buffer of this geometry */

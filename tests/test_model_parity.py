@@ -836,7 +836,8 @@ def test_layernorm_fold_and_clip_gather_are_bitwise_neutral_bf16(monkeypatch):
 
 def test_inference_calls_skip_backward_only_stores_bitwise_neutral_bf16(monkeypatch):
     """round 5: a video block called under torch.no_grad() (infer(), validation, feature extraction) is told so (EGV_BLOCK_INFER) and does
-    not write the MLP's pre-activation -- fc1 runs its GELU epilogue with one store instead of two.  The activation is formed from the
+    not write the MLP's pre-activation (fc1 runs its GELU epilogue with one store instead of two) nor the bf16 copies of the two inner
+    residual sums of the fp32 stream.  The activation is formed from the
     same fp32 sums: every output of infer() for the three tasks must be bit-identical with the flag on and off; full token geometry,
     3 + 3 layers, two fused."""
     from egovlpv2_amd.config import PathConfig
@@ -852,7 +853,8 @@ def test_inference_calls_skip_backward_only_stores_bitwise_neutral_bf16(monkeypa
         with torch.no_grad():
             r = {}
             for task in ('EgoNCE', 'ITM', 'MLM'):
-                r.update({task + '.' + k: v.clone() for k, v in m.infer(cu, task_names=task).items() if torch.is_tensor(v)})
+                # (keys with a leading underscore are internal: `_mlm_logits_padded` has never-written padding columns)
+                r.update({task + '.' + k: v.clone() for k, v in m.infer(cu, task_names=task).items() if torch.is_tensor(v) and not k.startswith('_')})
         torch.cuda.synchronize()
         out[lean] = r
     assert set(out['1']) == set(out['0']) and len(out['1']) >= 3
