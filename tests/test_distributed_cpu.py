@@ -153,3 +153,58 @@ def test_bf16_wire_gradient_sum_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _egomcq_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from egovlpv2_amd.trainer.validate import EgoMCQAccumulator
+    g = torch.Generator().manual_seed(7)                      # the same stream on every rank: question (step, r) is row step * world + r
+    steps, b2 = 6, 5
+    vtc = torch.randn(steps * world, b2, generator=g)
+    vtm = torch.rand(steps * world, b2, generator=g)
+    gt = torch.randint(0, b2, (steps * world,), generator=g)
+    ty = torch.randint(1, 3, (steps * world,), generator=g)
+    acc = EgoMCQAccumulator()
+    for s_ in range(steps):
+        i = s_ * world + rank
+        acc.add({'vtc': vtc[i:i + 1], 'vtm': vtm[i:i + 1], 'ensemble': vtc[i:i + 1] + vtm[i:i + 1]}, gt[i:i + 1], ty[i:i + 1])
+    a = acc.arrays()
+    ok = torch.equal(a['gt'], gt) and torch.equal(a['type'], ty) and torch.equal(a['vtm'], vtm) and torch.equal(a['ensemble'], vtc + vtm)
+    m = acc.metrics()
+    from egovlpv2_amd.model.metric import egomcq_accuracy_metrics_ensemble, egomcq_accuracy_metrics_vtm
+    ok = ok and m['egomcq_accuracy_metrics_ensemble'] == egomcq_accuracy_metrics_ensemble(vtc + vtm, gt, ty)
+    ok = ok and m['egomcq_accuracy_metrics_vtm'] == egomcq_accuracy_metrics_vtm(vtm, gt, ty)
+    ok = ok and set(m['egomcq_accuracy_metrics_vtm']) == {'Inter-video', 'Intra-video'}
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_egomcq_validation_gathers_world2():
+    """trainer_egoclip.py:250-291: per batch every rank contributes one question; ground truth, the two score arrays and the question
+    types are all-gathered in rank order and the metrics of the concatenation equal those of a single process over all questions."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29950 + (os.getpid() % 300)
+    procs = [ctx.Process(target=_egomcq_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_egomcq_accumulator_single_process():
+    """without a process group the accumulator keeps the local arrays (the 1-GPU validation run)"""
+    sys.path.insert(0, REPO)
+    from egovlpv2_amd.trainer.validate import EgoMCQAccumulator
+    acc = EgoMCQAccumulator()
+    vtc = torch.tensor([[0.1, 0.9, 0.0, 0.0, 0.0], [0.5, 0.1, 0.1, 0.1, 0.1]])
+    vtm = torch.tensor([[0.2, 0.1, 0.0, 0.0, 0.0], [0.0, 0.0, 0.0, 0.0, 0.9]])
+    acc.add({'vtc': vtc, 'vtm': vtm}, torch.tensor([1, 0]), torch.tensor([1, 2]))
+    m = acc.metrics()
+    assert m['egomcq_accuracy_metrics_ensemble'] == {'Inter-video': 100.0, 'Intra-video': 0.0}
+    assert m['egomcq_accuracy_metrics_vtm'] == {'Inter-video': 0.0, 'Intra-video': 0.0}
