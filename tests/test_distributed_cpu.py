@@ -1,4 +1,4 @@
-"""world_size-2 gloo tests (CPU) of the multi-rank plumbing of the path: AllGather_multi forward/backward semantics
+"""world_size-2 and -4 gloo tests (CPU) of the multi-rank plumbing of the path: AllGather_multi forward/backward semantics
 (reference trainer/trainer_egoclip.py:25-41) and the scalar-gather form of the MLM/ITM loss reductions, which must give
 the same loss and the same local gradients as gathering the logits (reference model.py:411-418)."""
 import os
@@ -47,17 +47,18 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_allgather_and_loss_reduction_world2():
+@pytest.mark.parametrize('world', [2, 4])
+def test_allgather_and_loss_reduction(world):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 300)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29600 + 7 * world + (os.getpid() % 300)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-    assert sorted(res) == [(0, True), (1, True)]
+    assert sorted(res) == [(r, True) for r in range(world)]
 
 
 def _exchange_worker(rank, world, port, q):
@@ -72,6 +73,15 @@ def _exchange_worker(rank, world, port, q):
     ok = True
     # three rounds: both ranks request, only rank 0 requests, nobody requests (a rank that asks for nothing still serves)
     draws = [{0: [0, 5, 2, 7], 1: [4, 1, 6, 1]}, {0: [6, 1, 2, 6], 1: [4, 5, 6, 7]}, {0: [0, 1, 2, 3], 1: [4, 5, 6, 7]}]
+    if world > 2:
+        # more than one peer: a rank fetches from several owners and an owner serves several requesters (two random rounds), only
+        # the last rank requests, nobody requests
+        own = {r: list(range(r * bsz, (r + 1) * bsz)) for r in range(world)}
+        rand = [{r: torch.randint(0, world * bsz, (bsz,), generator=torch.Generator().manual_seed(100 * k + r)).tolist() for r in range(world)}
+                for k in range(2)]
+        last = dict(own)
+        last[world - 1] = [0, bsz, 2 * bsz + 1, 1]
+        draws = rand + [last, own]
     for rnd, dr in enumerate(draws):
         g = torch.Generator().manual_seed(10 * rnd + rank)
         x = torch.randn(bsz * rows, d, generator=g, requires_grad=True)
@@ -104,17 +114,18 @@ def _exchange_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_negative_clip_token_exchange_world2():
+@pytest.mark.parametrize('world', [2, 4])
+def test_negative_clip_token_exchange(world):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29950 + (os.getpid() % 300)
-    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29950 + 7 * world + (os.getpid() % 300)
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-    assert sorted(res) == [(0, True), (1, True)]
+    assert sorted(res) == [(r, True) for r in range(world)]
 
 
 def _wire_worker(rank, world, port, q):
@@ -140,19 +151,20 @@ def _wire_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_bf16_wire_gradient_sum_world2():
+@pytest.mark.parametrize('world', [2, 4])
+def test_bf16_wire_gradient_sum(world):
     """trainer/grad_sync.py::allreduce_bf16_wire (FlatGradSync(wire='bf16'), SURVEY.md 8e): bf16 on the links, fp32 accumulation on
     arrival, identical bits on every rank."""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29300 + (os.getpid() % 250)
-    procs = [ctx.Process(target=_wire_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29300 + 7 * world + (os.getpid() % 250)
+    procs = [ctx.Process(target=_wire_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-    assert sorted(res) == [(0, True), (1, True)]
+    assert sorted(res) == [(r, True) for r in range(world)]
 
 
 def _egomcq_worker(rank, world, port, q):
