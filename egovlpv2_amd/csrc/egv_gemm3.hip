@@ -39,6 +39,14 @@
 #ifndef PP_LD_AUX
 #define PP_LD_AUX 0
 #endif
+// spread epilogue of the plain kinds (round 6): 2 = beside the wave's own MFMAs, 1 = in the load segments; -DPP_EPI2=0 restores round 5's
+// deferred quadrant-pair epilogue for A/B builds
+#ifndef PP_EPI2
+#define PP_EPI2 1
+#endif
+#ifndef PP_E2X
+#define PP_E2X 0
+#endif
 
 namespace egv {
 
@@ -67,26 +75,69 @@ __device__ __forceinline__ PPTile pp_tile(int t, int tiles_n, int bm) {
 // decides the count of the phase's s_waitcnt.
 enum { PP_PLAIN = 0, PP_LAST = 1, PP_FIRST_CHAIN = 2, PP_FIRST_COLD = 3, PP_SECOND_CHAIN = 4, PP_SECOND_COLD = 5 };
 
-// extra vector-memory operations issued in phase p of a K-tile of kind `kind` (NSP0 / NSP1 stores for the quadrant pair of A sub-tile 0 / 1 of a deferred epilogue,
-// 1 bias DMA per tile); with a BULK epilogue (residual / GELU' operand kinds) the tile's NST stores are issued between the
-// last K-tile and the next tile's first one
+// SPREAD epilogue of the plain kinds (round 6, `EPI2`): the finished tile's 16-byte output vectors -- NV = 2 (IM + IM1) per lane, in quadrant
+// order -- are converted and stored a few at a time over consecutive phases around the tile boundary; segment sg carries vectors
+// [sg NV / NSEG, (sg + 1) NV / NSEG).  Quadrant q (0..3 in the order the phases compute them; IM vectors each for 0, 1 and IM1 for 2, 3) is
+// final after the MFMAs of phase q of the last K-tile and re-initialised by the MFMAs of phase q of the next tile's first K-tile.
+//   mode 1 (7 segments): in the LOAD segments of the last K-tile's phases 1..3 and the first K-tile's phases 0..3 (before the phase's unit)
+//   mode 2 (6 segments): in the MFMA segments of the last K-tile's phases 1..3 and the first K-tile's phases 0..2 -- beside the wave's own
+//          MFMAs, which leave the vector ALU and the store path idle (a load segment that carries epilogue work lengthens the phase for
+//          both wave rows: measured +600 cycles per phase in mode 1)
+__host__ __device__ constexpr int pp_e2_nseg(int mode) { return mode == 2 ? 6 : 7; }
+__host__ __device__ constexpr int pp_e2_beg(int sg, int nv, int mode) { return sg * nv / pp_e2_nseg(mode); }
+__host__ __device__ constexpr int pp_e2_cnt(int sg, int nv, int mode) { return (sg + 1) * nv / pp_e2_nseg(mode) - sg * nv / pp_e2_nseg(mode); }
+// segment sg may touch quadrant q only inside [q, q + 3] (mode 1) / [q, q + 2] (mode 2: segment sg >= 3 runs BESIDE the MFMAs that
+// re-initialise quadrant sg - 3)
+__host__ __device__ constexpr bool pp_e2_ok(int im, int im1, int mode) {
+    const int nv = 2 * (im + im1), ns = pp_e2_nseg(mode);
+    for (int sg = 0; sg < ns; ++sg)
+        for (int v = pp_e2_beg(sg, nv, mode); v < pp_e2_beg(sg, nv, mode) + pp_e2_cnt(sg, nv, mode); ++v) {
+            const int qd = v < im ? 0 : v < 2 * im ? 1 : v < 2 * im + im1 ? 2 : 3;
+            if (sg < qd || sg > qd + (mode == 2 ? 2 : 3)) return false;
+        }
+    return pp_e2_beg(ns, nv, mode) == nv;
+}
+// extra vector-memory operations issued in the LOAD segment of phase p of a K-tile of kind `kind`, before the phase's unit (NSP0 / NSP1
+// stores for the quadrant pair of A sub-tile 0 / 1 of a deferred epilogue, 1 bias DMA per tile); with a BULK epilogue (residual / GELU'
+// operand kinds) the tile's NST stores are issued between the last K-tile and the next tile's first one
 // (MX-fp8 form: + the K-tile's scale DMA, issued in phase 3 right BEFORE that phase's unit)
-__host__ __device__ constexpr int pp_extra(int kind, int p, int NSP0, int NSP1, bool bulk, bool mx = false) {
+// e2nv > 0: spread epilogue with e2nv vectors per tile (the bias DMA then rides in phase 0 of a tile's SECOND K-tile)
+__host__ __device__ constexpr int pp_extra(int kind, int p, int NSP0, int NSP1, bool bulk, bool mx = false, int e2nv = 0, int e2m = 0) {
     const int s = (mx && p == 3) ? 1 : 0;
+    if (e2nv > 0) {
+        if (kind == PP_SECOND_CHAIN || kind == PP_SECOND_COLD) return s + (p == 0 ? 1 : 0);
+        if (e2m == 2) return s;
+        if (kind == PP_LAST) return s + (p >= 1 ? pp_e2_cnt(p - 1, e2nv, e2m) : 0);
+        if (kind == PP_FIRST_CHAIN) return s + pp_e2_cnt(3 + p, e2nv, e2m);
+        return s;
+    }
     if (kind == PP_LAST) return s + (p == 1 ? 1 : 0);
     if (kind == PP_FIRST_CHAIN && !bulk) return s + (p == 0 ? NSP0 : p == 2 ? NSP1 : 0);
     return s;
 }
+// ... and in the MFMA segment of phase p (after the phase's unit and its wait): the stores of the spread epilogue in mode 2
+__host__ __device__ constexpr int pp_extra_m(int kind, int p, int e2nv, int e2m) {
+    if (e2nv <= 0 || e2m != 2) return 0;
+    if (kind == PP_LAST) return p >= 1 ? pp_e2_cnt(p - 1, e2nv, e2m) : 0;
+    if (kind == PP_FIRST_CHAIN) return p <= 2 ? pp_e2_cnt(3 + p, e2nv, e2m) : 0;
+    return 0;
+}
 __host__ __device__ constexpr int pp_prev_kind(int kind) {
     return kind == PP_FIRST_CHAIN ? PP_LAST : kind == PP_SECOND_CHAIN ? PP_FIRST_CHAIN : kind == PP_SECOND_COLD ? PP_FIRST_COLD : PP_PLAIN;
 }
-// operations younger than the unit staged 4 phases ago, at the wait of phase p: the DMAs of the last 4 phases + the extras
-__host__ __device__ constexpr int pp_nwait(int kind, int p, int NSP0, int NSP1, bool bulk, bool mx = false) {
+// operations younger than the unit staged 4 phases ago, at the wait of phase p: the DMAs of the last 4 phases + the load-segment extras of
+// those phases (issued BEFORE their unit) + the MFMA-segment extras of phases p - 4 .. p - 1 (issued after their unit).  A count that is too
+// small only waits longer; one that is too large is a race: PLAIN stands for "the K-tile before this one" of PLAIN and LAST, which is
+// SECOND_* when K is 192 or 256 -- whose only extra (spread epilogue: the bias DMA of phase 0) is older than every window that reaches back
+// into it.
+__host__ __device__ constexpr int pp_nwait(int kind, int p, int NSP0, int NSP1, bool bulk, bool mx = false, int e2nv = 0, int e2m = 0) {
     int n = 8;
-    for (int q = 0; q <= p; ++q) n += pp_extra(kind, q, NSP0, NSP1, bulk, mx);
-    if (kind != PP_FIRST_COLD)                      // before a cold first K-tile there is only the prologue (nothing younger)
-        for (int q = p + 1; q < 4; ++q) n += pp_extra(pp_prev_kind(kind), q, NSP0, NSP1, bulk, mx);
-    else if (mx && p < 3) n += 1;                   // ... except the prologue's scale DMA of K-tile 1, issued where a phase 3 would have
+    for (int q = 0; q <= p; ++q) n += pp_extra(kind, q, NSP0, NSP1, bulk, mx, e2nv, e2m);
+    for (int q = 0; q < p; ++q) n += pp_extra_m(kind, q, e2nv, e2m);
+    if (kind != PP_FIRST_COLD) {                    // before a cold first K-tile there is only the prologue (nothing younger)
+        for (int q = p + 1; q < 4; ++q) n += pp_extra(pp_prev_kind(kind), q, NSP0, NSP1, bulk, mx, e2nv, e2m);
+        for (int q = p; q < 4; ++q) n += pp_extra_m(pp_prev_kind(kind), q, e2nv, e2m);
+    } else if (mx && p < 3) n += 1;                 // ... except the prologue's scale DMA of K-tile 1, issued where a phase 3 would have
     if (kind == PP_FIRST_CHAIN && bulk) n += NSP0 + NSP1;  // the previous tile's bulk epilogue (all of its stores) sits between the tiles
     return n;
 }
@@ -141,6 +192,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
     // other wave row idles for a memory latency four times per tile; profiles/round5_experiments.md.)
     // -DPP_PLAIN_BULK=1 (experiment): the plain kinds with the one-piece epilogue too (within 1 % either way).
     constexpr bool BULK = X1K != 0 || PP_PLAIN_BULK;
+    // plain kinds (bias or nothing; every tile height): the spread epilogue above
+    constexpr bool EPI2 = PP_EPI2 && !BULK && !PREK && !ACTK && !MX && !QOUT && EGV_PP_EXP == 0;
+    constexpr int E2M = EPI2 ? PP_EPI2 : 0;                        // 1: load segments, 2: MFMA segments
+    constexpr int NV = 2 * (IM + IM1);                             // 16-byte output vectors per lane and tile
+    constexpr int E2NV = EPI2 ? NV : 0;
+    static_assert(!EPI2 || pp_e2_ok(IM, IM1, E2M), "spread epilogue: a vector outside its quadrant's window");
     constexpr unsigned int OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -185,7 +242,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                 const int ra = ims == 4 ? rho : ims == 3 ? min(wave * 12 + p * 8 + srow, 95) : wave * 8 + srow;
                 const int row = min(tl.m0 + (ra / sms) * WM + roff + (ra % sms), g.M - 1);
                 const unsigned int sch = ((lane & 7) ^ (ra & 7)) * 16;
-                return (ims == 2 && p == 1) ? 0u : (unsigned int)(row * g.lda) * ES + sch;
+                return (ims == 2 && p == 1) ? 0u : __umul24((unsigned int)row, (unsigned int)g.lda * ES) + sch;   // (24-bit factors by the launcher's checks: one v_mad_u32_u24, no 64-bit register pair)
             };
             soff[0][p] = a_off(IM, 0);
             soff[3][p] = a_off(IM1, SM0);
@@ -193,8 +250,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
             const int wcp = rho >> 5, jp = (rho >> 4) & 1, q = rho & 15;
             const int cb0 = min(tl.n0 + wcp * 64 + (q >> 2) * 8 + jp * 4 + (q & 3), g.N - 1);
             const int cb1 = min(tl.n0 + wcp * 64 + 32 + (q >> 2) * 8 + jp * 4 + (q & 3), g.N - 1);
-            soff[1][p] = (unsigned int)(cb0 * g.ldb) * ES + schunk;
-            soff[2][p] = (unsigned int)(cb1 * g.ldb) * ES + schunk;
+            soff[1][p] = __umul24((unsigned int)cb0, (unsigned int)g.ldb * ES) + schunk;
+            soff[2][p] = __umul24((unsigned int)cb1, (unsigned int)g.ldb * ES) + schunk;
         }
     };
     // staging cursor: units are issued in the fixed order U0(kt) U1(kt) U2(kt) U3(kt) U0(kt+1) ... across tiles
@@ -343,8 +400,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
     const bool has_bias = e.bias != nullptr;
     auto load_bias = [&](const PPTile& tb) {
         const unsigned int voff = (unsigned int)min(tb.n0 + lane * 4, g.N - 4) * 4u;
-        glds(has_bias ? (const void*)e.bias : g.B, has_bias ? voff : 0u, __builtin_amdgcn_readfirstlane(bias_lds));
+        if constexpr (EPI2)    // without a bias the slab holds zeros (written once, below) and the DMA -- kept for the counted waits -- lands in the dummy slab
+            glds(has_bias ? (const void*)e.bias : g.B, has_bias ? voff : 0u, __builtin_amdgcn_readfirstlane(has_bias ? bias_lds : dummy_lds));
+        else
+            glds(has_bias ? (const void*)e.bias : g.B, has_bias ? voff : 0u, __builtin_amdgcn_readfirstlane(bias_lds));
     };
+    if constexpr (EPI2) {
+        if (!has_bias) *reinterpret_cast<f32x4_t*>(smem + 2 * PP_BUF + 8192 + wave * 1024 + lane * 16) = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
     f32x4_t acc[IM + IM1][4];                                     // (AOFF(s)+i, t*2+j'); written by the first MFMAs of every tile
     bf16x8_t af[IMX][2], bf0[2][2], bf1[2][2];
     int sc_a0 = 0, sc_a1 = 0, sc_b = 0;                           // MX: block scales of the K-tile (A sub-tiles 0 / 1: byte i; B: byte t*2+j')
@@ -490,6 +553,42 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
         }
     };
 
+    // ---- spread epilogue (EPI2): segment sg of tile `tl`.  A vector = fragment i of quadrant (s, t): row m0 + wr*WM + ROFF(s) + i*16 + fr, columns
+    // n0 + wc*64 + t*32 + fg*8 .. +7 -- the MFMA C layout as it is (16 rows x 64 contiguous bytes per store instruction: the store path takes
+    // the same 32 cycles per instruction as for the 8-rows-x-128-bytes form of the pair-swapped epilogue, tools/probe_store.hip), so a vector
+    // costs 8 adds (bias; + 0.f without one: bit-identical to the other GEMM kernels), 4 packed conversions, one address add and the store --
+    // about 14 instructions against ~50 of the pair-swapped form with its per-fragment bias reads from LDS.
+    const unsigned int lane_c2 = (unsigned int)((wr * WM + fr) * g.ldc + lane_col) * 2u;
+    auto epi2_seg = [&](int sg, const PPTile& tl) {               // sg compile-time at every call site
+        const int vb = pp_e2_beg(sg, NV, E2M), ve = vb + pp_e2_cnt(sg, NV, E2M);
+        const unsigned int col_oob = tl.n0 + wc * 64 < g.N ? 0u : OOB;   // wave-uniform (N % 64 == 0); or-ed in: no branch
+        f32x4_t bA = {0.f, 0.f, 0.f, 0.f}, bB = {0.f, 0.f, 0.f, 0.f};
+        int bt = -1;
+#pragma unroll
+        for (int v = vb; v < ve; ++v) {
+            const int qd = v < IM ? 0 : v < 2 * IM ? 1 : v < 2 * IM + IM1 ? 2 : 3;
+            const int i = v - (qd == 0 ? 0 : qd == 1 ? IM : qd == 2 ? 2 * IM : 2 * IM + IM1);
+            const int s_ = qd >> 1, t_ = (qd == 1 || qd == 2) ? 1 : 0;
+            if (t_ != bt) {                                       // (compile-time after unrolling) the 8 bias values of this lane's columns
+                const float* bp = bias_slab + wc * 64 + fg * 8 + t_ * 32;
+                bA = *reinterpret_cast<const f32x4_t*>(bp);
+                bB = *reinterpret_cast<const f32x4_t*>(bp + 4);
+                bt = t_;
+            }
+            const f32x4_t a0 = acc[PP_AOFF(s_) + i][t_ * 2 + 0], a1 = acc[PP_AOFF(s_) + i][t_ * 2 + 1];
+            const u32x4_t o = {pack_bf16x2(a0[0] + bA[0], a0[1] + bA[1]), pack_bf16x2(a0[2] + bA[2], a0[3] + bA[3]),
+                               pack_bf16x2(a1[0] + bB[0], a1[1] + bB[1]), pack_bf16x2(a1[2] + bB[2], a1[3] + bB[3])};
+            const unsigned int sterm = ((unsigned int)((tl.m0 + PP_ROFF(s_) + i * 16) * g.ldc + tl.n0 + t_ * 32) * 2u) | col_oob;
+#if PP_E2X == 1                                                       /* experiment: conversion without the store */
+            asm volatile("" :: "v"(o), "v"(lane_c2 + sterm));
+#elif PP_E2X == 2                                                     /* experiment: the store without the conversion (raw accumulator bits) */
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, a0), rs_c, lane_c2 + sterm, 0, PP_ST_AUX);
+#else
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs_c, lane_c2 + sterm, 0, PP_ST_AUX);
+#endif
+        }
+    };
+
     // ---- prologue: the first tile's bias (and residual quadrants 0, 1) first, then U0..U3 of K-tile 0 and U0 U1 of K-tile 1
     // (the units the steady-state schedule would have issued before phase 0)
     PPTile cur = pp_tile(first, g.tiles_n, BM);
@@ -514,7 +613,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
     acc[PP_AOFF(S) + (I)][(T) * 2 + (JP)] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                              \
         PP_CAT8(BF[JP]), PP_CAT8(af[I]), (ZERO) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[PP_AOFF(S) + (I)][(T) * 2 + (JP)], 0, 0, \
         (T) * 2 + (JP), sc_b, (I), (S) == 0 ? sc_a0 : sc_a1)
-#define PP_MFMA(S, BF, T, ZERO)                                                                                            \
+#define PP_MFMA(S, BF, T, ZERO, PH)                                                                                         \
     do {                                                                                                                   \
         PP_SETPRIO(1);                                                                                                     \
         if constexpr (MX) {                                                                                                \
@@ -533,6 +632,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
             acc[PP_AOFF(S) + i][(T) * 2 + jp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                   \
                 BF[jp][kh], af[i][kh], ((ZERO) && kh == 0) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[PP_AOFF(S) + i][(T) * 2 + jp], 0, 0, 0); \
         }                                                                                                                  \
+        /* spread epilogue, mode 2: segment PH - 1 of the tile this K-tile finishes / segment 3 + PH of the previous tile, beside the MFMAs above */ \
+        if (LASTK && E2M == 2 && (PH) >= 1) epi2_seg((PH) - 1, cur);                                                       \
+        if (CHAIN && E2M == 2 && (PH) <= 2) epi2_seg(3 + (PH), prev);                                                      \
         PP_SETPRIO(0);                                                                                                     \
     } while (0)
 #define PP_KTILE(KIND, BUFIDX)                                                                                             \
@@ -540,12 +642,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
         constexpr bool FIRSTK = (KIND) == PP_FIRST_CHAIN || (KIND) == PP_FIRST_COLD;                                       \
         constexpr bool CHAIN = (KIND) == PP_FIRST_CHAIN;                                                                   \
         constexpr bool LASTK = (KIND) == PP_LAST;                                                                          \
+        constexpr bool SECONDK = (KIND) == PP_SECOND_CHAIN || (KIND) == PP_SECOND_COLD;                                    \
         const unsigned char* buf = smem + ((BUFIDX) & 1) * PP_BUF;                                                         \
         /* ---------------- phase 0: read A sub 0 (U0) + B sub 0 (U1); stage U2 of kt+1; quadrant 0 = (0,0) */             \
         {                                                                                                                  \
-            if (CHAIN && !BULK) pp_wait_vmcnt<6 + (MX ? 1 : 0)>();   /* the bias DMA of LAST phase 1 (this wave's own slab) landed */ \
-            if (CHAIN && !BULK) pair_epilogue(0, prev);                                                                             \
-            if (CHAIN && !BULK) PP_PIN();                                                                                  \
+            if (CHAIN && !BULK && !EPI2) pp_wait_vmcnt<6 + (MX ? 1 : 0)>();   /* the bias DMA of LAST phase 1 (this wave's own slab) landed */ \
+            if (CHAIN && !BULK && !EPI2) pair_epilogue(0, prev);                                                           \
+            if (CHAIN && !BULK && !EPI2) PP_PIN();                                                                         \
+            if (CHAIN && E2M == 1) epi2_seg(3, prev);                                                                          \
+            if (SECONDK && EPI2) load_bias(cur);        /* this tile's bias: read from LAST phase 1 on (>= 5 phases later) */ \
             const unsigned char* pa = buf + 0 * PP_UNIT + a_base0;                                                         \
             const unsigned char* pb = buf + 1 * PP_UNIT + b_base;                                                          \
             _Pragma("unroll") for (int jp = 0; jp < 2; ++jp) {                                                             \
@@ -561,14 +666,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                 sc_b = sc_read((BUFIDX) & 3, 4 + wc);                                                                      \
             }                                                                                                              \
             stage_unit(2);                                                                                                 \
-            pp_wait_vmcnt<pp_nwait(KIND, 0, NSP0, NSP1, BULK, MX)>();                                                           \
+            pp_wait_vmcnt<pp_nwait(KIND, 0, NSP0, NSP1, BULK, MX, E2NV, E2M)>();                                                           \
             __builtin_amdgcn_s_barrier();                                                                                  \
-            PP_MFMA(0, bf0, 0, FIRSTK);                                                                                 \
+            PP_MFMA(0, bf0, 0, FIRSTK, 0);                                                                                \
             __builtin_amdgcn_s_barrier();                                                                                  \
         }                                                                                                                  \
         /* ---------------- phase 1: read B sub 1 (U2); stage U3 of kt+1; quadrant 1 = (0,1) */                            \
         {                                                                                                                  \
-            if (LASTK) load_bias(cur);                                                                                    \
+            if (LASTK && !EPI2) load_bias(cur);                                                                           \
+            if (LASTK && E2M == 1) epi2_seg(0, cur);                                                                          \
+            if (CHAIN && E2M == 1) epi2_seg(4, prev);                                                                          \
             const unsigned char* pb = buf + 2 * PP_UNIT + b_base;                                                          \
             _Pragma("unroll") for (int jp = 0; jp < 2; ++jp) {                                                             \
                 bf1[jp][0] = *reinterpret_cast<const bf16x8_t*>(pb + jp * 2048 + swz0);                                    \
@@ -576,15 +683,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
             }                                                                                                              \
             stage_unit(3);                                                                                                 \
             advance_cursor();                                                                                              \
-            pp_wait_vmcnt<pp_nwait(KIND, 1, NSP0, NSP1, BULK, MX)>();                                                           \
+            pp_wait_vmcnt<pp_nwait(KIND, 1, NSP0, NSP1, BULK, MX, E2NV, E2M)>();                                                           \
             __builtin_amdgcn_s_barrier();                                                                                  \
-            PP_MFMA(0, bf1, 1, FIRSTK);                                                                                 \
+            PP_MFMA(0, bf1, 1, FIRSTK, 1);                                                                                \
             __builtin_amdgcn_s_barrier();                                                                                  \
         }                                                                                                                  \
         /* ---------------- phase 2: read A sub 1 (U3); stage U0 of kt+2; quadrant 2 = (1,1) */                            \
         {                                                                                                                  \
-            if (CHAIN && !BULK) pair_epilogue(1, prev);                                                                             \
-            if (CHAIN && !BULK) PP_PIN();                                                                                  \
+            if (CHAIN && !BULK && !EPI2) pair_epilogue(1, prev);                                                           \
+            if (CHAIN && !BULK && !EPI2) PP_PIN();                                                                         \
+            if (LASTK && E2M == 1) epi2_seg(1, cur);                                                                          \
+            if (CHAIN && E2M == 1) epi2_seg(5, prev);                                                                          \
             const unsigned char* pa = buf + 3 * PP_UNIT + a_base1;                                                         \
             _Pragma("unroll") for (int i = 0; i < IM1; ++i) {                                                              \
                 af[i][0] = *reinterpret_cast<const bf16x8_t*>(pa + i * 2048 + swz0);                                       \
@@ -592,18 +701,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
             }                                                                                                              \
             if constexpr (MX) sc_a1 = sc_read((BUFIDX) & 3, wr * 2 + 1);                                                   \
             stage_unit(0);                                                                                                 \
-            pp_wait_vmcnt<pp_nwait(KIND, 2, NSP0, NSP1, BULK, MX)>();                                                           \
+            pp_wait_vmcnt<pp_nwait(KIND, 2, NSP0, NSP1, BULK, MX, E2NV, E2M)>();                                                           \
             __builtin_amdgcn_s_barrier();                                                                                  \
-            PP_MFMA(1, bf1, 1, FIRSTK);                                                                                 \
+            PP_MFMA(1, bf1, 1, FIRSTK, 2);                                                                                \
             __builtin_amdgcn_s_barrier();                                                                                  \
         }                                                                                                                  \
         /* ---------------- phase 3: no reads; stage U1 of kt+2; quadrant 3 = (1,0) */                                     \
         {                                                                                                                  \
+            if (LASTK && E2M == 1) epi2_seg(2, cur);                                                                          \
+            if (CHAIN && E2M == 1) epi2_seg(6, prev);                                                                          \
             stage_scales();                                                                                                \
             stage_unit(1);                                                                                                 \
-            pp_wait_vmcnt<pp_nwait(KIND, 3, NSP0, NSP1, BULK, MX)>();                                                           \
+            pp_wait_vmcnt<pp_nwait(KIND, 3, NSP0, NSP1, BULK, MX, E2NV, E2M)>();                                                           \
             __builtin_amdgcn_s_barrier();                                                                                  \
-            PP_MFMA(1, bf0, 0, FIRSTK);                                                                                 \
+            PP_MFMA(1, bf0, 0, FIRSTK, 3);                                                                                \
             __builtin_amdgcn_s_barrier();                                                                                  \
         }                                                                                                                  \
     } while (0)
@@ -680,7 +791,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
 #undef PP_STAMP
     // ---- the last tile's epilogue
     pp_wait_vmcnt<0>();                                           // its bias slab (and the dummy DMAs)
-    if (!BULK) {
+    if constexpr (EPI2) {                                         // the quadrants the last K-tile's segments did not reach
+        epi2_seg(3, prev); epi2_seg(4, prev); epi2_seg(5, prev);
+        if constexpr (E2M == 1) epi2_seg(6, prev);
+    } else if (!BULK) {
         pair_epilogue(0, prev);
         pair_epilogue(1, prev);
     }
@@ -717,6 +831,7 @@ int egv_gemm3_launch(const GemmArgs& gin, hipStream_t st) {
     if ((g.ldc % 8) || (e.ldr % 8) || !al16(g.C) || !al16(e.res1) || !al16(e.pre) || !al16(e.aux) || (e.bias && !al16(e.bias))) return 0;
     if ((long long)g.M * g.lda >= (1LL << 30) || (long long)g.N * g.ldb >= (1LL << 30)) return 0;   // 32-bit byte offsets
     if ((long long)g.M * g.ldc >= (1LL << 30) || (long long)g.M * e.ldr >= (1LL << 30)) return 0;
+    if (g.M >= (1 << 24) || g.N >= (1 << 24) || g.lda >= (1 << 23) || g.ldb >= (1 << 23)) return 0;   // 24-bit factors of the staging offsets
     if (e.scale != 1.0f) return 0;                                // the bias rides in as the accumulators' initial value
     if ((e.act && e.act != 1 && e.act != 4) || (e.dact && (e.dact != 1 || e.bias))) return 0;   // epilogues are built for GELU / GELU' (a data gradient: no bias) only
     if (e.res2 && (!e.res1 || e.dact || e.act)) return 0;             // gated two-residual form; e.pre = the saved pre-gate value
@@ -849,6 +964,7 @@ extern "C" int egv_gemm_mx(int M, int N, int K, const void* Aq, const void* Asca
               (reinterpret_cast<uintptr_t>(Bscales) & 3) == 0 && (ldc % 8) == 0 && (ldr % 8) == 0, "egv_gemm_mx: 16-byte aligned operands and ldc, ldr %% 8 == 0 required");
     EGV_CHECK((long long)M * K < (1LL << 31) && (long long)N * K < (1LL << 31) && (long long)M * ldc < (1LL << 30) && (long long)M * ldr < (1LL << 30),
               "egv_gemm_mx: operand beyond 32-bit byte offsets");
+    EGV_CHECK(M < (1 << 24) && N < (1 << 24) && K < (1 << 23), "egv_gemm_mx: M, N < 2^24 and K < 2^23 required");
     EGV_CHECK(!(res1 && (dact || act || pre)) && !(dact && (act || pre)) && !(pre && !act), "egv_gemm_mx: epilogue combination not built");
     EGV_CHECK(!dact || aux, "egv_gemm_mx: dact without aux");
     EGV_CHECK((act == 0 || act == 1 || act == 4) && (dact == 0 || (dact == 1 && !bias)), "egv_gemm_mx: epilogues are built for GELU / GELU' (without bias) only");
