@@ -65,55 +65,86 @@ def skipped_flops_per_pair(cfg, L, workload, world, tail=True):
     return (vblock + i2t) + shared * prefix + tails + patch
 
 
-def _cpu_sample(frames, L, workload, threads):
-    """one fwd+bwd of the CPU oracle at B=1 on `frames` x 224^2 frames; returns seconds"""
+def _cpu_sample(frames, L, workload, thread_choices, budget_s):
+    """CPU oracle timing (runs in a subprocess): SURVEY.md section 8(d) procedure -- one warm-up step, then >= 2 timed fwd+bwd steps
+    at B = 1 on the workload's own shapes.  Thread count: the best of `thread_choices` on a 4-frame probe (one warm-up + one timed
+    step each).  If warm-up + 2 timed steps of the full shape do not fit what is left of `budget_s`, the 4-frame shape is the sample
+    and the caller scales it by the FLOP ratio.  Returns a dict."""
     from oracle import ref_model as O
     from egovlpv2_amd.synthetic import make_state_dict, make_batch
     from egovlpv2_amd.config import PathConfig, tiny_config
     tasks = 'EgoNCE' if workload == 'dual' else 'EgoNCE_MLM_ITM'
-    torch.set_num_threads(threads)
+    t_start = time.time()
 
-    def one(c, B, Lx):
-        sd = make_state_dict(c, 0)
+    def one(c, B, Lx, sd=None):
+        if sd is None:
+            sd = make_state_dict(c, 0)
+            for v in sd.values():
+                if v.is_floating_point():
+                    v.requires_grad_(True)
         for v in sd.values():
-            if v.is_floating_point():
-                v.requires_grad_(True)
+            v.grad = None
         data, noun, verb = make_batch(c, B, Lx, 99)
         t0 = time.time()
         loss, _, _ = O.forward_losses(sd, data, noun, verb, O.make_cfg(**c.as_dict()), tasks)
         loss.backward()
-        return time.time() - t0
+        return time.time() - t0, sd
+    torch.set_num_threads(thread_choices[0])
     one(tiny_config(), 2, 16)                       # page the libraries in
-    return one(PathConfig(frames=frames), 1, L)
+    probe_frames = min(4, frames)
+    c4 = PathConfig(frames=probe_frames)
+    tried, sd4 = {}, None
+    for th in thread_choices:
+        torch.set_num_threads(th)
+        _, sd4 = one(c4, 1, L, sd4)                 # warm-up at this thread count (first touch of the thread pool / buffers)
+        tried[th], sd4 = one(c4, 1, L, sd4)
+    best = min(tried, key=tried.get)
+    torch.set_num_threads(best)
+    del sd4
+    cf = PathConfig(frames=frames)
+    ratio = flops_per_pair(cf, L, workload) / flops_per_pair(c4, L, workload)
+    est = tried[best] * ratio
+    left = budget_s - (time.time() - t_start)
+    if frames > probe_frames and 3.3 * est <= left:
+        _, sdf = one(cf, 1, L)
+        t1, sdf = one(cf, 1, L, sdf)
+        t2, sdf = one(cf, 1, L, sdf)
+        return {"frames": frames, "threads": best, "tried": tried, "steps_s": [t1, t2], "seconds": 0.5 * (t1 + t2), "ratio": 1.0}
+    t1, sd4 = one(c4, 1, L)
+    t2, sd4 = one(c4, 1, L, sd4)
+    t3, sd4 = one(c4, 1, L, sd4)
+    return {"frames": probe_frames, "threads": best, "tried": tried, "steps_s": [t2, t3], "seconds": 0.5 * (t2 + t3),
+            "ratio": ratio if frames > probe_frames else 1.0}
 
 
-def cpu_baseline(cfg, L, workload, timeout_s=300):
+def cpu_baseline(cfg, L, workload, timeout_s=330, budget_s=240):
     """The CPU oracle (oracle/ref_model.py, kind 'port': a restatement of the reference's fp32 CPU path, pinned to the
-    reference by tests/golden) timed on this box's host cores on a BOUNDED sample of the same workload: the same model and
-    shapes (16 x 224^2 frames, 32 tokens, all three losses) at B=1, one fwd+bwd step on all physical cores, in a subprocess
-    with a timeout."""
+    reference by tests/golden) timed on this box's host cores on a BOUNDED sample of the same workload, as SURVEY.md 8(d)
+    prescribes: the same model and shapes (16 x 224^2 frames, 32 tokens, all three losses) at B = 1, one warm-up step and two
+    timed fwd+bwd steps, at the better of 64 / 128 torch threads (probed on the 4-frame shape); when three full-shape steps do
+    not fit the budget the 4-frame shape is timed instead and scaled by the FLOP ratio.  Runs in a subprocess with a timeout."""
     import subprocess
     cores = os.cpu_count() or 1
-    threads = max(1, cores // 2) if cores > 16 else cores       # physical cores (SMT siblings add nothing to fp32 GEMMs)
-    frames = cfg.frames                                       # the workload's own shapes at B = 1 (SURVEY.md 8d)
+    choices = sorted({t for t in (64, 128) if t <= cores} or {max(1, cores // 2) if cores > 16 else cores})
     code = (f"import sys, json; sys.path.insert(0, {REPO!r}); import bench; "
-            f"print(json.dumps(bench._cpu_sample({frames}, {L}, {workload!r}, {threads})))")
+            f"print(json.dumps(bench._cpu_sample({cfg.frames}, {L}, {workload!r}, {choices!r}, {budget_s})))")
     try:
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=timeout_s, cwd=REPO)
-        dt = float(json.loads(r.stdout.strip().splitlines()[-1]))
+        d = json.loads(r.stdout.strip().splitlines()[-1])
     except Exception as e:                              # never let the baseline leg take the bench down
-        return {"value": None, "unit": "pairs/s", "cores": threads, "kind": "port", "sample": f"failed: {type(e).__name__}"}
-    f4 = flops_per_pair(type(cfg)(frames=frames), L, workload)
-    f16 = flops_per_pair(cfg, L, workload)
+        return {"value": None, "unit": "pairs/s", "cores": choices[-1], "kind": "port", "sample": f"failed: {type(e).__name__}"}
     try:
         model_name = [ln.split(':', 1)[1].strip() for ln in open('/proc/cpuinfo') if ln.startswith('model name')][0]
     except Exception:
         model_name = 'unknown CPU'
-    return {"value": round(1.0 / dt, 5), "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": f"oracle fp32 fwd+bwd, B=1, {frames}x{cfg.img}^2 frames, {L} tokens, {'EgoNCE' if workload == 'dual' else 'EgoNCE+MLM+ITM'}, "
-                      f"{threads} torch threads of {cores} logical CPUs ({model_name}); 1 step = {dt:.1f} s",
-            "seconds": round(dt, 2), "flops_ratio_workload_over_sample": round(f16 / f4, 3),
-            "value_scaled_to_workload": round(1.0 / dt * f4 / f16, 5)}
+    dt, ratio = float(d['seconds']), float(d['ratio'])
+    return {"value": round(1.0 / (dt * ratio), 5), "unit": "pairs/s", "cores": int(d['threads']), "kind": "port",
+            "sample": f"oracle fp32 fwd+bwd, B=1, {d['frames']}x{cfg.img}^2 frames, {L} tokens, {'EgoNCE' if workload == 'dual' else 'EgoNCE+MLM+ITM'}, "
+                      f"1 warm-up + 2 timed steps ({d['steps_s'][0]:.1f} s, {d['steps_s'][1]:.1f} s) at {d['threads']} torch threads of {cores} logical CPUs "
+                      f"({model_name})" + (f"; scaled to {cfg.frames} frames by the FLOP ratio {ratio:.2f}" if ratio != 1.0 else ""),
+            "seconds_per_step": round(dt, 2), "steps_s": [round(x, 2) for x in d['steps_s']],
+            "threads_tried_s_on_4_frames": {str(k): round(float(v), 2) for k, v in d['tried'].items()},
+            "flops_ratio_workload_over_sample": round(ratio, 3)}
 
 
 def main():

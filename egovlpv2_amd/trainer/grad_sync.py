@@ -27,19 +27,34 @@ from .. import hipops as ops
 from .. import switches as SW
 
 
+_wire_bufs = {}          # (device, world * per) -> (send, recv): staging of allreduce_bf16_wire, reused call after call
+
+
+def _wire_staging(device, n):
+    """Two bf16 staging buffers of n elements.  One pair per size and device for the life of the process: the ~50 calls of a step run
+    one after another on ONE stream (FlatGradSync's side stream, or the calling stream on CPU / in tests), so reuse is ordered by that
+    stream -- no allocator traffic and no record_stream bookkeeping on a path that runs beside the backward pass."""
+    key = (str(device), int(n))
+    b = _wire_bufs.get(key)
+    if b is None:
+        b = _wire_bufs[key] = (torch.zeros(n, dtype=torch.bfloat16, device=device), torch.empty(n, dtype=torch.bfloat16, device=device))
+    return b
+
+
 def allreduce_bf16_wire(flat, group=None):
     """Sum over the ranks of an fp32 buffer, in place, MOVED as bf16 and ACCUMULATED in fp32 on arrival (half the bytes of the fp32
     all-reduce on the per-link-bound xGMI ring): every rank sends shard q of its buffer, rounded to bf16, to rank q (all-to-all); rank q
     adds the `world` copies of its shard in fp32, in rank order, rounds the sum once and all-gathers it.  Every rank ends with the
     same bits (the shard's owner forms the sum; nobody else does), so replicas do not drift apart.  Error: two bf16 roundings per
     element (2^-9 relative each) instead of none -- an OPTION (FlatGradSync(wire='bf16')); fp32 stays the default until a node has
-    measured both."""
+    measured both.  Callers on a GPU must issue every call on the same stream (the staging buffers are reused)."""
     world = dist.get_world_size(group)
     n = flat.numel()
     per = -(-n // world)
-    send = torch.zeros(world * per, dtype=torch.bfloat16, device=flat.device)
+    send, recv = _wire_staging(flat.device, world * per)
     send[:n].copy_(flat)
-    recv = torch.empty_like(send)
+    if world * per > n:
+        send[n:].zero_()
     dist.all_to_all_single(recv, send, group=group)
     part = recv.view(world, per).float().sum(0).to(torch.bfloat16)
     dist.all_gather_into_tensor(send, part, group=group)
@@ -71,8 +86,12 @@ class FlatGradSync:
         if self.comm:
             self._reduce(flat)
 
+    # bf16 wire: buffers below this size (the tensors outside the blocks: embeddings' position / type tables, LayerNorms, head biases, gates)
+    # keep the exact fp32 all-reduce -- their bytes do not matter on the links and two bf16 roundings do matter on a LayerNorm gain
+    WIRE_MIN_NUMEL = 1 << 20
+
     def _reduce(self, t):
-        if self.wire == 'fp32':
+        if self.wire == 'fp32' or t.numel() < self.WIRE_MIN_NUMEL:
             self._works.append(dist.all_reduce(t, group=self.group, async_op=True))
         elif t.is_cuda:
             # cast / exchange / sum / gather on a side stream ordered after the stream the buffer is complete on; the calling stream

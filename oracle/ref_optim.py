@@ -5,8 +5,11 @@ set_optim_schedule.py:8-13,108,114-127.  transformers 4.30.0 is a third-party de
 is not installed here (the installed 5.x removed ``AdamW``), so this part of the oracle is pinned differently:
   * the parameter GROUPING is the reference's own code: oracle/gen_golden_optim.py imports set_optim_schedule.py with a
     recording stub in place of the missing AdamW and stores the six name lists (tests/golden/optim_groups.json);
-  * the update arithmetic below is the published algorithm of that release ("parity unpinned" by reference tests; the HIP
-    kernel is checked against this restatement bit-for-bit-close in fp32).
+  * the update arithmetic below is the published algorithm of that release -- no reference test or fixture exists for it ("parity
+    unpinned" against the absent dependency itself); it is pinned instead against torch.optim.Adam (the identical update at
+    weight_decay = 0, eps = 0) and one hand-computed decay-after-update vector
+    (tests/test_optimizer.py::test_oracle_adamw_is_pinned_to_torch_adam_and_a_hand_computed_vector); the HIP kernel is checked against
+    this restatement bit-for-bit-close in fp32.
 """
 import math
 

@@ -166,3 +166,49 @@ def test_switch_tables_are_the_only_readers_of_the_environment_and_defaults_are_
     for f in glob.glob(os.path.join(REPO, 'egovlpv2_amd', '**', '*.py'), recursive=True):
         used_py |= set(re.findall(r"SW\.(?:on|value)\('(EGV_[A-Z0-9_]+)'\)", open(f).read())) | set(re.findall(r"_sw\.value\('(EGV_[A-Z0-9_]+)'\)", open(f).read()))
     assert used_py == set(switches.SWITCHES), (used_py ^ set(switches.SWITCHES))
+
+
+def test_dropin_registers_the_reference_module_names(tmp_path):
+    """with egovlpv2_amd.dropin.install() the reference launcher's own import lines (multinode_train_egoclip.py:23-26)
+    bind the HIP implementation -- `import model.model as module_arch`, `import model.loss as module_loss` -- while the rest of the
+    reference tree (here a stand-in tree: a `model` package with another module, a trainer module, utils.util) keeps importing from
+    the tree, with AllGather_multi / state_dict_data_parallel_fix patched in place.  Runs in a subprocess (sys.modules is global)."""
+    import subprocess
+    import sys
+    import textwrap
+    tree = tmp_path / 'reftree'
+    (tree / 'model').mkdir(parents=True)
+    (tree / 'trainer').mkdir()
+    (tree / 'utils').mkdir()
+    (tree / 'model' / '__init__.py').write_text('')
+    (tree / 'model' / 'model.py').write_text('raise ImportError("the reference model.model must not be imported after install()")\n')
+    (tree / 'model' / 'loss.py').write_text('raise ImportError("the reference model.loss must not be imported after install()")\n')
+    (tree / 'model' / 'metric.py').write_text('MARK = "reference metric module"\n')
+    (tree / 'trainer' / '__init__.py').write_text('from .trainer_egoclip import *\n')
+    (tree / 'trainer' / 'trainer_egoclip.py').write_text('class AllGather_multi: pass\nclass Multi_Trainer_dist: pass\n')
+    (tree / 'utils' / '__init__.py').write_text('')
+    (tree / 'utils' / 'util.py').write_text('def state_dict_data_parallel_fix(a, b): raise RuntimeError("reference")\ndef other(): return 7\n')
+    code = textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {str(tree)!r}); sys.path.insert(1, {REPO!r})
+        import egovlpv2_amd.dropin
+        egovlpv2_amd.dropin.install()
+        import model.metric as module_metric
+        import model.loss as module_loss
+        import model.model as module_arch
+        from trainer import Multi_Trainer_dist
+        import trainer.trainer_egoclip as T
+        import utils.util as U
+        import egovlpv2_amd.model.model as ours, egovlpv2_amd.model.loss as ours_loss
+        import egovlpv2_amd.trainer.trainer_egoclip as ours_T, egovlpv2_amd.utils.util as ours_U
+        assert module_arch is ours and module_loss is ours_loss
+        assert getattr(module_arch, 'FrozenInTime') is ours.FrozenInTime and module_loss.EgoNCE is ours_loss.EgoNCE
+        assert module_metric.MARK == 'reference metric module'
+        assert T.AllGather_multi is ours_T.AllGather_multi and T.Multi_Trainer_dist is Multi_Trainer_dist
+        assert U.state_dict_data_parallel_fix is ours_U.state_dict_data_parallel_fix and U.other() == 7
+        egovlpv2_amd.dropin.uninstall()
+        assert 'model.model' not in sys.modules
+        print('dropin ok')
+    """)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'dropin ok' in r.stdout, r.stderr[-2000:]

@@ -19,12 +19,14 @@ class _HostGather(torch.autograd.Function):
     """AllGather_multi semantics (trainer_egoclip.py:25-41) staged through the host so that it works on gloo with device
     tensors: forward = concatenation over ranks, backward = the local slice of the incoming gradient."""
 
+    group = None            # gloo group of the host staging (None: the default group of the one-GPU rehearsal)
+
     @staticmethod
     def forward(ctx, t, n_gpu, args):
         ctx.rank, ctx.b = args.rank, t.shape[0]
         c = t.detach().cpu().contiguous()
         out = [torch.empty_like(c) for _ in range(args.world_size)]
-        dist.all_gather(out, c)
+        dist.all_gather(out, c, group=_HostGather.group)
         return torch.cat(out, 0).to(t.device)
 
     @staticmethod
@@ -32,7 +34,7 @@ class _HostGather(torch.autograd.Function):
         return g[ctx.b * ctx.rank: ctx.b * (ctx.rank + 1)], None, None
 
 
-def _worker(rank, world, port, q, steps, overlap, gsync='ddp'):
+def _worker(rank, world, port, q, steps, overlap, gsync='ddp', backend='gloo'):
     try:
         if not overlap:
             os.environ['EGV_NO_OVERLAP'] = '1'
@@ -40,14 +42,27 @@ def _worker(rank, world, port, q, steps, overlap, gsync='ddp'):
         sys.path.insert(0, os.path.join(REPO, 'tests'))
         os.environ['MASTER_ADDR'] = '127.0.0.1'
         os.environ['MASTER_PORT'] = str(port)
-        dist.init_process_group('gloo', rank=rank, world_size=world)
+        # backend 'gloo': both ranks on cuda:0 (the one-GPU rehearsal; collectives staged through the host).  backend 'nccl': one GPU per
+        # rank on RCCL -- the product transport: AllGather_multi itself, DDP / FlatGradSync over xGMI -- with a gloo group beside it
+        # for the CPU oracle's gathers
+        rccl = backend == 'nccl'
+        dev_index = rank if rccl else 0
+        host_group = None
+        if rccl:
+            os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+            torch.cuda.set_device(dev_index)
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', dev_index))
+            host_group = dist.new_group(backend='gloo')
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        _HostGather.group = host_group
         import types
         from helpers import load_golden, oracle_setup
         from oracle import ref_model as O
         from egovlpv2_amd.model.model import FrozenInTime
         from egovlpv2_amd.model.loss import EgoNCE
         from egovlpv2_amd.synthetic import make_batch
-        torch.cuda.set_device(0)
+        torch.cuda.set_device(dev_index)
         _, cfg, B, L, wseed, _ = load_golden('tiny')
         B = 4                                              # 2 negatives per rank and step
         sd, _, _, _, oc = oracle_setup(cfg, B, L, wseed, 0, requires_grad=True)
@@ -59,7 +74,7 @@ def _worker(rank, world, port, q, steps, overlap, gsync='ddp'):
         flat = None
         if gsync == 'ddp':
             from torch.nn.parallel import DistributedDataParallel as DDP
-            net = DDP(m, device_ids=[0], static_graph=True, gradient_as_bucket_view=True, find_unused_parameters=False)
+            net = DDP(m, device_ids=[dev_index], static_graph=True, gradient_as_bucket_view=True, find_unused_parameters=False)
         else:                                              # trainer/grad_sync.py: all-reduce of the flat per-block gradient buffers
             from egovlpv2_amd.trainer.grad_sync import FlatGradSync
             net, flat = m, FlatGradSync(m)
@@ -73,8 +88,10 @@ def _worker(rank, world, port, q, steps, overlap, gsync='ddp'):
             np.random.seed(40 + step + rank)
             torch.manual_seed(40 + step + rank)
             net.zero_grad(set_to_none=True)
-            loss, ld, ret = net(dev, noun.cuda(), verb.cuda(), _HostGather.apply, world, args, {'loss': {'type': 'EgoNCE'}},
-                                EgoNCE(), 0, task_names='EgoNCE_MLM_ITM')
+            if rccl:
+                from egovlpv2_amd.trainer.trainer_egoclip import AllGather_multi
+            loss, ld, ret = net(dev, noun.cuda(), verb.cuda(), AllGather_multi.apply if rccl else _HostGather.apply, world, args,
+                                {'loss': {'type': 'EgoNCE'}}, EgoNCE(), dev_index, task_names='EgoNCE_MLM_ITM')
             if flat is not None:
                 flat.backward(loss)
             else:
@@ -99,7 +116,7 @@ def _worker(rank, world, port, q, steps, overlap, gsync='ddp'):
             for n in names:
                 g = sd[n].grad
                 g = torch.zeros_like(sd[n]) if g is None else g.detach().clone()
-                dist.all_reduce(g)
+                dist.all_reduce(g, group=host_group)
                 g /= world
                 a = dict(m.named_parameters())[n].grad.double().cpu().reshape(-1)
                 r = g.double().reshape(-1)
@@ -138,6 +155,35 @@ def test_world2_full_step_vs_oracle(overlap, gsync):
     assert sum(info['remote'] for _, _, info in res) > 0, res
 
 
+needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="first contact with RCCL at N > 1: needs two GPUs (the build and test boxes have one)")
+
+
+@needs_two_gpus
+@pytest.mark.parametrize('gsync', ['flat', 'ddp'])
+def test_world2_full_step_vs_oracle_on_rccl(gsync):
+    """The world-size-2 step of test_world2_full_step_vs_oracle on the PRODUCT transport: one GPU per rank, backend 'nccl' (RCCL over
+    xGMI), AllGather_multi for the EgoNCE embeddings, the device request gather + point-to-point token exchange for the other rank's
+    hard negatives, FlatGradSync's in-place all-reduces issued from the weight-gradient stream / DDP's buckets -- against the CPU oracle
+    under a gloo group of the same ranks.  Skipped on a one-GPU box: the first N > 1 execution on RCCL is this parity test, not the
+    scaling bench."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29300 + (os.getpid() % 90) + (200 if gsync == 'flat' else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, 2, True, gsync, 'nccl')) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+    for rank, status, info in res:
+        assert status == 'ok', info
+        assert info['loss'] < 1e-3, info
+        assert info['grad'] < 5e-3, info
+    assert sum(info['remote'] for _, _, info in res) > 0, res
+
+
 def _run_bench(nproc, extra, env_extra, port):
     """bench.py as the driver launches it (torch.distributed.run for nproc > 1); returns rank 0's JSON line"""
     import json
@@ -170,6 +216,24 @@ def test_bench_two_ranks_flat_grad_sync_rehearsal():
     singles = [_run_bench(1, common + ['--seed-offset', str(r)], {}, 29641 + r) for r in range(2)]
     cnt = two['losses']['mlm_labels_per_rank']
     assert len(cnt) == 2 and [s['losses']['mlm_labels_per_rank'][0] for s in singles] == cnt
+    want = sum(s['losses']['loss_mlm'] * c for s, c in zip(singles, cnt)) / sum(cnt)
+    assert abs(two['losses']['loss_mlm'] - want) <= 2e-3 * abs(want), (two['losses'], [s['losses'] for s in singles])
+    for k in ('EgoNCE', 'loss_itm', 'loss_total'):
+        assert np.isfinite(two['losses'][k]) and 0 < two['losses'][k] < 50, two['losses']
+
+
+@needs_two_gpus
+@pytest.mark.parametrize('wire', ['fp32', 'bf16'])
+def test_bench_two_ranks_on_rccl(wire):
+    """`bench.py --gpus 2` exactly as the driver launches it, one GPU per rank on RCCL (no rehearsal switch): the one-JSON-line contract
+    and the MLM loss against the label-count-weighted mean of two 1-rank runs on the same batches, with the fp32 and the bf16 wire
+    format of the flat gradient sync.  Skipped on a one-GPU box."""
+    common = ['--batch', '4', '--frames', '4', '--drop-rate', '0']
+    two = _run_bench(2, common + ['--grad-sync', 'flat', '--grad-wire', wire], {}, 29661 + (7 if wire == 'bf16' else 0))
+    assert two['n_gpus'] == 2 and two['steps'] == 2 and two['scaling'] == 'weak' and two['value'] > 0
+    assert two['config']['global_batch'] == 8
+    singles = [_run_bench(1, common + ['--seed-offset', str(r)], {}, 29671 + r) for r in range(2)]
+    cnt = two['losses']['mlm_labels_per_rank']
     want = sum(s['losses']['loss_mlm'] * c for s, c in zip(singles, cnt)) / sum(cnt)
     assert abs(two['losses']['loss_mlm'] - want) <= 2e-3 * abs(want), (two['losses'], [s['losses'] for s in singles])
     for k in ('EgoNCE', 'loss_itm', 'loss_total'):

@@ -150,3 +150,105 @@ def test_checkpoint_resume_continues_fused_adamw(tmp_path):
     torch.cuda.synchronize()
     for a, b in zip(m1.parameters(), m2.parameters()):
         assert torch.equal(a, b)
+
+
+def test_oracle_adamw_is_pinned_to_torch_adam_and_a_hand_computed_vector():
+    """oracle/ref_optim.adamw_step (the restatement of transformers-4.30 AdamW that the fused HIP kernel is tested against) pinned two ways:
+    (a) at weight_decay = 0 and eps = 0 the HF update lr sqrt(1 - b2^t) / (1 - b1^t) m / sqrt(v) IS torch.optim.Adam's
+    lr (m / (1 - b1^t)) / sqrt(v / (1 - b2^t)) -- five steps on random gradients against torch's own implementation; (b) one step with
+    eps and DECOUPLED decay applied AFTER the Adam update with the plain learning rate (p -= lr wd p: the HF order, not torch.optim.AdamW's
+    decay-first), against arithmetic written out by hand."""
+    import math
+    from oracle.ref_optim import adamw_step
+    torch.manual_seed(3)
+    p0 = torch.randn(257, dtype=torch.float64)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=3e-3, betas=(0.9, 0.98), eps=0.0, weight_decay=0.0)
+    p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    for t in range(1, 6):
+        g = torch.randn(257, dtype=torch.float64) + 0.1
+        ref.grad = g.clone()
+        opt.step()
+        adamw_step(p, g, m, v, t, 3e-3, betas=(0.9, 0.98), eps=0.0, weight_decay=0.0)
+        assert torch.allclose(p, ref.detach(), rtol=1e-12, atol=1e-14), t
+    # (b) by hand: p = 1, g = 0.5, lr = 0.1, betas (0.9, 0.98), eps = 1e-8, wd = 0.01, first step
+    m1 = 0.1 * 0.5
+    v1 = 0.02 * 0.25
+    step_size = 0.1 * math.sqrt(1.0 - 0.98) / (1.0 - 0.9)
+    p1 = 1.0 - step_size * m1 / (math.sqrt(v1) + 1e-8)
+    p1 = p1 - 0.1 * 0.01 * p1
+    pt, mt, vt = torch.tensor([1.0], dtype=torch.float64), torch.zeros(1, dtype=torch.float64), torch.zeros(1, dtype=torch.float64)
+    adamw_step(pt, torch.tensor([0.5], dtype=torch.float64), mt, vt, 1, 0.1, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01)
+    assert abs(float(pt) - p1) < 1e-15 and abs(p1 - 0.8991000141) < 1e-9, (float(pt), p1)
+    assert abs(float(mt) - m1) < 1e-15 and abs(float(vt) - v1) < 1e-15
+
+
+@pytest.mark.gpu
+def test_grad_scaler_around_fused_adamw_on_flat_block_gradients():
+    """The reference's AMP step (trainer/trainer_egoclip.py:143-149, base/base_trainer.py:334): scaler.scale(loss).backward();
+    scaler.step(optimizer); scaler.update() -- around the fused AdamW, on gradients that are VIEWS of the block executor's flat buffers.
+    (bf16 needs no loss scaling; the wrap must still behave: the reference's trainer always has it.)  (a) a scaled step equals the
+    unscaled step (unscale_ divides the flat views in place; scale 2^10 is exact in fp32); (b) an inf in one gradient skips the step --
+    parameters and optimiser state untouched -- and halves the scale."""
+    import types
+    import numpy as np
+    from egovlpv2_amd.config import tiny_config
+    from egovlpv2_amd.synthetic import make_state_dict, make_batch
+    from egovlpv2_amd.model.model import FrozenInTime
+    from egovlpv2_amd.model.loss import EgoNCE
+    from egovlpv2_amd.trainer.trainer_egoclip import AllGather_multi
+    from egovlpv2_amd.set_optim_schedule import set_schedule
+    cfg = tiny_config()
+    data, noun, verb = make_batch(cfg, 2, 16, 77)
+    dev = {'video': data['video'].cuda(), 'text': {k: v.cuda() for k, v in data['text'].items()},
+           'text_mlm_ids': data['text_mlm_ids'].cuda(), 'text_mlm_labels': data['text_mlm_labels'].cuda()}
+    args = types.SimpleNamespace(world_size=1, rank=0)
+    ocfg = {"optimizer": {"type": "AdamW", "args": {"lr": 1e-3, "weight_decay": 0.01, "lr_mult_head": 4, "lr_mult_cross_modal": 4}}}
+
+    def build():
+        m = FrozenInTime({'model': 'SpaceTimeTransformer', 'num_frames': cfg.frames, 'pretrained': True},
+                         {'model': 'roberta-base', 'pretrained': True, 'input': 'text'}, path_config=cfg,
+                         task_names='EgoNCE_MLM_ITM', compute_dtype=torch.float32)
+        m.load_state_dict(make_state_dict(cfg, 0), strict=True)
+        m = m.cuda()
+        opt, _ = set_schedule(m, ocfg, {"decay_power": "cosine", "end_lr": 1e-7}, 20, 3)
+        return m, opt
+
+    def fwd(m):
+        np.random.seed(5)
+        torch.manual_seed(5)
+        loss, _, _ = m(dev, noun.cuda(), verb.cuda(), AllGather_multi.apply, 1, args, {'loss': {'type': 'EgoNCE'}}, EgoNCE(), 0,
+                       task_names='EgoNCE_MLM_ITM')
+        return loss
+
+    m0, o0 = build()
+    o0.zero_grad(set_to_none=True)
+    fwd(m0).backward()
+    o0.step()
+    m1, o1 = build()
+    scaler = torch.amp.GradScaler('cuda', init_scale=2.0 ** 10, growth_interval=1000)
+    o1.zero_grad(set_to_none=True)
+    scaler.scale(fwd(m1)).backward()
+    scaler.step(o1)
+    scaler.update()
+    torch.cuda.synchronize()
+    worst = 0.0
+    for (n, a), (_, b) in zip(m0.named_parameters(), m1.named_parameters()):
+        worst = max(worst, ((a - b).norm() / (a.norm() + 1e-12)).item())
+    assert worst < 1e-6, worst                      # (not bitwise: a scaled loss moves the roundings inside backward by a few ulp)
+    assert scaler.get_scale() == 2.0 ** 10
+    # (b) inf-skip
+    before = {n: p.detach().clone() for n, p in m1.named_parameters()}
+    steps_before = {n: int(o1.state[p]['step']) for n, p in m1.named_parameters() if p in o1.state and 'step' in o1.state[p]}
+    o1.zero_grad(set_to_none=True)
+    scaler.scale(fwd(m1)).backward()
+    victim = dict(m1.named_parameters())['video_model.blocks.0.mlp.fc1.weight']
+    victim.grad.view(-1)[7] = float('inf')           # a view of the block's flat gradient buffer
+    scaler.step(o1)
+    scaler.update()
+    torch.cuda.synchronize()
+    for n, p in m1.named_parameters():
+        assert torch.equal(p.detach(), before[n]), n
+        if n in steps_before:
+            assert int(o1.state[p]['step']) == steps_before[n], n
+    assert scaler.get_scale() == 2.0 ** 9

@@ -54,6 +54,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=4)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--dump', action='store_true', help='chronological list of the calls of the last step (both streams)')
     a = ap.parse_args()
     dev = torch.device('cuda', 0)
     cfg = PathConfig(frames=16, drop_rate=0.1)
@@ -134,6 +135,10 @@ def main():
     print("largest single gaps:")
     for g, p, q, at in sorted(big, reverse=True)[:15]:
         print(f"  {g:8.3f} ms after {p} before {q} at t={at:.2f} ms")
+    if a.dump:
+        print("calls of the last step (start, end, duration in ms; M = calling stream, S = companion):")
+        for tag, st, b, e in sorted(cur, key=lambda r: r[2]):
+            print(f"  {'M' if st == main_st else 'S'} {b - t0:8.3f} {e - t0:8.3f} {e - b:7.3f}  {tag}")
     for tag in ('fwd_end', 'bwd_end'):
         for r in cur:
             if r[0] == tag:
