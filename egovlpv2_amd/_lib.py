@@ -17,7 +17,7 @@ from . import switches as _sw  # noqa: E402
 
 LIB_PATH = _sw.value('EGV_LIB_PATH') or os.path.join(_HERE, 'libegovlp_hip.so')
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 EGV_F32, EGV_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH, ACT_GELU_D = 0, 1, 2, 3, 4
 
@@ -61,6 +61,7 @@ class VBlockDesc(C.Structure):
         ('x32', vp), ('out32', vp),
         ('next_g', vp), ('next_b', vp), ('next_h', vp), ('next_stats', vp),
         ('fwd_cus', i32),
+        ('acc_mask', C.c_uint),
     ]
 
 
@@ -80,12 +81,13 @@ class TLayerDesc(C.Structure):
         ('stream', vp), ('stream2', vp),
         ('flags', i32),
         ('w_qkv', vp), ('wt_qkv', vp), ('b_qkv', vp), ('w_ckv', vp), ('wt_ckv', vp), ('b_ckv', vp),
+        ('acc_mask', C.c_uint),
     ]
 
 
 class WgradProblem(C.Structure):
     """struct egv_wgrad_problem (include/egovlp_hip.h)"""
-    _fields_ = [('dy', vp), ('ldy', i32), ('x', vp), ('ldx', i32), ('dw', vp), ('db', vp), ('gate', vp), ('N', i32), ('K', i32)]
+    _fields_ = [('dy', vp), ('ldy', i32), ('x', vp), ('ldx', i32), ('dw', vp), ('db', vp), ('gate', vp), ('N', i32), ('K', i32), ('accumulate', i32)]
 
 
 BLOCK_NO_JOIN = 1
@@ -170,10 +172,12 @@ PROTOTYPES = {
     'egv_vblock_fwd': (i32, [C.POINTER(VBlockDesc)]),
     'egv_vblock_bwd': (i32, [C.POINTER(VBlockDesc)]),
     'egv_vblock_bwd_defers': (i32, [C.POINTER(VBlockDesc)]),
+    'egv_vblock_bwd_groups': (C.c_uint, [C.POINTER(VBlockDesc)]),
     'egv_tlayer_save_bytes': (i64, [C.POINTER(TLayerDesc)]),
     'egv_tlayer_ws_bytes': (i64, [C.POINTER(TLayerDesc), i32]),
     'egv_tlayer_fwd': (i32, [C.POINTER(TLayerDesc)]),
     'egv_tlayer_bwd': (i32, [C.POINTER(TLayerDesc)]),
+    'egv_tlayer_bwd_groups': (C.c_uint, [C.POINTER(TLayerDesc)]),
     'egv_prof_enable': (i32, [i32]),
     'egv_prof_reset': (i32, []),
     'egv_prof_collect': (i32, [C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int), i32]),

@@ -17,7 +17,7 @@ void egv_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int egv_abi_version(void) { return 5; }
+extern "C" int egv_abi_version(void) { return 6; }
 
 // ---- switches --------------------------------------------------------------------------------------------------------------
 // Every run-time switch of the library in ONE table (name, default, what it does).  The defaults are the configuration that is

@@ -587,6 +587,16 @@ extern "C" int egv_vblock_bwd_defers(const egv_vblock_desc* d) {
     return (vgroup_ok(d) && vdefer_ok(d) && d->stream2 && d->stream2 != d->stream && M >= 4096) ? 1 : 0;
 }
 
+// Linear slots whose weight gradients egv_vblock_bwd(d) forms in its grouped launch (those over the M video tokens) -- the slots a caller
+// may ask to ACCUMULATE (acc_mask); 0 when the call would take the one-launch-per-gradient form
+extern "C" unsigned int egv_vblock_bwd_groups(const egv_vblock_desc* d) {
+    if (!vgroup_ok(d)) return 0u;
+    if (d->flags & EGV_BLOCK_HEAD) return (1u << VW_TQKV) | (1u << VW_TPROJ) | (1u << VW_SQKV);
+    unsigned int m = (1u << VW_TQKV) | (1u << VW_TPROJ) | (1u << VW_SQKV) | (1u << VW_SPROJ) | (1u << VW_FC1) | (1u << VW_FC2);
+    if (d->L > 0) m |= (1u << VW_Q_I2T) | (1u << VW_PROJ_I2T);
+    return m;
+}
+
 extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
     const int dt = d->dtype;
     const size_t es = esz(dt);
@@ -674,8 +684,10 @@ extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
         if (group && rows == M) {
             egv_wgrad_problem& q = grp[ngrp++];
             q.dy = dz; q.ldy = N; q.x = x; q.ldx = K; q.dw = d->dw[w]; q.db = d->db[w]; q.gate = gate; q.N = N; q.K = K;
+            q.accumulate = (d->acc_mask >> w) & 1;
             return 0;
         }
+        if ((d->acc_mask >> w) & 1) { egv_set_error("egv_vblock_bwd: acc_mask bit %d set for a weight gradient outside the grouped launch", w); return -1; }
         return lin_wgrad(dt, rows, N, K, dz, N, x, d->dw[w], d->db[w], gate, wgw, wgb, fk.begin());
     };
 
@@ -940,6 +952,14 @@ extern "C" int egv_tlayer_fwd(const egv_tlayer_desc* d) {
     return 0;
 }
 
+// as egv_vblock_bwd_groups: the gradients over the B*L text rows (a merged q | k | v gradient is slot TW_Q's problem: bits 1, 2 follow bit 0)
+extern "C" unsigned int egv_tlayer_bwd_groups(const egv_tlayer_desc* d) {
+    if (!tgroup(d)) return 0u;
+    unsigned int m = (1u << TW_Q) | (1u << TW_K) | (1u << TW_V) | (1u << TW_AO) | (1u << TW_FC1) | (1u << TW_FC2);
+    if (d->S > 0) m |= (1u << TW_CQ) | (1u << TW_CO);
+    return m;
+}
+
 extern "C" int egv_tlayer_bwd(const egv_tlayer_desc* d) {
     const int dt = d->dtype;
     const size_t es = esz(dt);
@@ -1002,8 +1022,10 @@ extern "C" int egv_tlayer_bwd(const egv_tlayer_desc* d) {
         if (grp_on && rows == BL) {
             egv_wgrad_problem& q = grp[ngrp++];
             q.dy = dz; q.ldy = ldz; q.x = x; q.ldx = K; q.dw = d->dw[w]; q.db = d->db[w]; q.gate = gate; q.N = N; q.K = K;
+            q.accumulate = (d->acc_mask >> w) & 1;
             return 0;
         }
+        if ((d->acc_mask >> w) & 1) { egv_set_error("egv_tlayer_bwd: acc_mask bit %d set for a weight gradient outside the grouped launch", w); return -1; }
         return lin_wgrad(dt, rows, N, K, dz, ldz, x, d->dw[w], d->db[w], gate, wgw, wgb, fk.begin());
     };
     auto wgrad = [&](int rows, int N, int K, const void* dz, const void* x, int w, const float* gate) -> int {

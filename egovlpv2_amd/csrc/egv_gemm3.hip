@@ -575,9 +575,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                 bB = *reinterpret_cast<const f32x4_t*>(bp + 4);
                 bt = t_;
             }
-            const f32x4_t a0 = acc[PP_AOFF(s_) + i][t_ * 2 + 0], a1 = acc[PP_AOFF(s_) + i][t_ * 2 + 1];
-            const u32x4_t o = {pack_bf16x2(a0[0] + bA[0], a0[1] + bA[1]), pack_bf16x2(a0[2] + bA[2], a0[3] + bA[3]),
-                               pack_bf16x2(a1[0] + bB[0], a1[1] + bB[1]), pack_bf16x2(a1[2] + bB[2], a1[3] + bB[3])};
+            f32x4_t a0 = acc[PP_AOFF(s_) + i][t_ * 2 + 0] + bA, a1 = acc[PP_AOFF(s_) + i][t_ * 2 + 1] + bB;
+            if (has_gate) {                                       // (wave-uniform; the gated data gradient of proj_i2t: the product is rounded on its own, as in every GEMM kernel)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { a0[k] *= gate; a1[k] *= gate; }
+            }
+            const u32x4_t o = {pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[0], a1[1]), pack_bf16x2(a1[2], a1[3])};
             const unsigned int sterm = ((unsigned int)((tl.m0 + PP_ROFF(s_) + i * 16) * g.ldc + tl.n0 + t_ * 32) * 2u) | col_oob;
 #if PP_E2X == 1                                                       /* experiment: conversion without the store */
             asm volatile("" :: "v"(o), "v"(lane_c2 + sterm));

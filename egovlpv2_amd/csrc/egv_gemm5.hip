@@ -38,6 +38,7 @@ struct WgProb {
     int lda, ldb, ldc;
     int tiles_m, tiles_n;   // row (N_p / 256) and column (K_p / 256) tiles
     int tile0;              // first global tile index of this problem
+    int accumulate;         // 1: C += ..., db += ... (a later use of a block adds into the first use's buffer)
 };
 constexpr int WG_MAXPH = 8;
 struct WgPhase {
@@ -171,7 +172,9 @@ __global__ __launch_bounds__(512) void gemm_wgrad_group_kernel(const WgGroup g) 
                     }
                     v[0] = v[0] * sc + poison; v[1] = v[1] * sc + poison; v[2] = v[2] * sc + poison; v[3] = v[3] * sc + poison;
                     const int col = n0 + w4_col(wc, t, jp) + fg * 4;
-                    *reinterpret_cast<f32x4_t*>(P.C + (size_t)row * P.ldc + col) = v;
+                    f32x4_t* dst = reinterpret_cast<f32x4_t*>(P.C + (size_t)row * P.ldc + col);
+                    if (P.accumulate) v = *dst + v;                 // (written by an earlier launch on this stream; this tile's only writer now)
+                    *dst = v;
                 }
         }
     if (has_db && fg == 0) {
@@ -184,7 +187,8 @@ __global__ __launch_bounds__(512) void gemm_wgrad_group_kernel(const WgGroup g) 
                 for (int z = 1; z < nsplit; ++z) sum += z == split ? v : tile_slabs[(size_t)z * WG_SLAB_FLOATS + 256 * 256 + rl];
                 v = sum;
             }
-            P.db[m0 + rl] = v * sc + poison;
+            v = v * sc + poison;
+            P.db[m0 + rl] = P.accumulate ? P.db[m0 + rl] + v : v;
         }
     }
     }   // phases
@@ -350,9 +354,10 @@ extern "C" int egv_gemm_wgrad_grouped(int dtype, int M, int nprob, const egv_wgr
         g.p[i].tiles_m = q.N / 256;
         g.p[i].tiles_n = q.K / 256;
         g.p[i].tile0 = t0;
+        g.p[i].accumulate = q.accumulate != 0;
         t0 += (q.N / 256) * (q.K / 256);
         flops += 2.0 * M * q.N * q.K;
-        bytes += 2.0 * ((double)M * q.N + (double)M * q.K) + 4.0 * q.N * q.K;
+        bytes += 2.0 * ((double)M * q.N + (double)M * q.K) + 4.0 * q.N * q.K * (q.accumulate ? 2 : 1);
     }
     g.slabs = (float*)workspace;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -13,8 +13,23 @@
 // Units of a K-tile (64 tokens x 128 columns = 16 KB each): U0 = dY columns read in phase 0 (sub-tile 0 of both wave rows: tile rows
 // 0..127), U1 = X columns of phase 0 (sub-tile 0 of every wave column: tile columns 0..127), U2 = X columns of phase 1 (128..255),
 // U3 = dY columns of phase 2 (128..255).
+//
+// Round 6 (W4_TWO_PHASE, default): TWO phases per K-tile instead of four.  The measured loop time fits  2 x sum_p max(load segment p,
+// MFMA segment) + ~42 cycles per barrier pair  (complete 1.42 us, no fragment reads 1.26, no DMAs 1.18, no MFMAs 1.04 per unit of
+// 256 x 256 x 64): with four phases the load segments carry 24 / 8 / 16 / 0 transposing reads + 2 DMA pieces each, so the first and the
+// third outlast their 16-MFMA segments and every K-tile pays eight barrier pairs.  Two phases -- {A sub 0, B sub 0, B sub 1: 32 reads, 4
+// pieces | 34 MFMAs} and {A sub 1: 16 reads, 4 pieces | 34 MFMAs} -- keep the same 64 fragment registers, halve the barrier pairs and
+// put each load segment beside an MFMA segment of its own length.  Staging order is unchanged (U2 U3 of kt+1, then U0 U1 of kt+2), two
+// units per phase; a unit's slot is restaged ONE phase after its last read, which is legal because every phase retires its LDS reads
+// (s_waitcnt lgkmcnt(0), free: they were issued ahead of four DMA pieces) before its first barrier (cdna_hip_programming.md, WAR rule);
+// the waits are vmcnt(8) in the first phase (A sub 1 of this K-tile, staged two phases ago) and vmcnt(6) in the second (U0 U1 of the next
+// K-tile, staged two phases ago, and its U2 -- the B operand, i.e. a bf16 activation panel every tile of a row re-reads -- staged in the
+// previous phase; its U3 may still be in flight).
 #pragma once
 #include "egv_gemm.h"
+#ifndef W4_TWO_PHASE
+#define W4_TWO_PHASE 1
+#endif
 
 namespace egv {
 
@@ -121,7 +136,7 @@ __device__ __forceinline__ void w4_mainloop(const void* A, const void* B, int ld
     stage_unit(0); stage_unit(1); stage_unit(2); stage_unit(3);
     ++s_kt;
     stage_unit(0); stage_unit(1);
-    w4_wait_vmcnt<8>();
+    w4_wait_vmcnt<W4_TWO_PHASE ? 6 : 8>();                        // U0 U1 (two phases: and U2) of K-tile 0 have landed
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();                    // the second wave row runs one barrier behind the first
 
@@ -150,6 +165,62 @@ __device__ __forceinline__ void w4_mainloop(const void* A, const void* B, int ld
 #endif
 #define W4_RD(first) (W4_EXP != 1 || (first))
 #define W4_STAGE(u) do { if (W4_EXP != 2) stage_unit(u); } while (0)
+#if W4_TWO_PHASE
+    for (int kt = 0; kt < KT; ++kt) {
+        const unsigned char* buf = smem + (kt & 1) * W4_BUF;
+        const bool first = kt == 0;
+        // ---- phase A: A sub 0 (U0), B sub 0 (U1), B sub 1 (U2); stage U2 U3 of kt+1; quadrants (0,0) (0,1)
+        {
+            const unsigned char* pa = buf + 0 * W4_UNIT;
+            const unsigned char* pb0 = buf + 1 * W4_UNIT;
+            const unsigned char* pb1 = buf + 2 * W4_UNIT;
+            if (W4_RD(first)) {
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    bf0[jp][0] = w4_frag(pb0, wc * 32 + jp * 16, fr, fg);
+                    bf0[jp][1] = w4_frag(pb0 + 8192, wc * 32 + jp * 16, fr, fg);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    af[i][0] = w4_frag(pa, wr * 64 + (i ^ wc) * 16, fr, fg);
+                    af[i][1] = w4_frag(pa + 8192, wr * 64 + (i ^ wc) * 16, fr, fg);
+                }
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    bf1[jp][0] = w4_frag(pb1, wc * 32 + jp * 16, fr, fg);
+                    bf1[jp][1] = w4_frag(pb1 + 8192, wc * 32 + jp * 16, fr, fg);
+                }
+            }
+            W4_STAGE(2);
+            W4_STAGE(3);
+            ++s_kt;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this phase's reads are retired before its first barrier: their slots are restaged next phase
+            w4_wait_vmcnt<8>();
+            __builtin_amdgcn_s_barrier();
+            if (first) { W4_MFMA(0, bf0, 0, kh == 0, true); W4_MFMA(0, bf1, 1, kh == 0, false); }
+            else { W4_MFMA(0, bf0, 0, false, true); W4_MFMA(0, bf1, 1, false, false); }
+            __builtin_amdgcn_s_barrier();
+        }
+        // ---- phase B: A sub 1 (U3); stage U0 U1 of kt+2; quadrants (1,1) (1,0)
+        {
+            const unsigned char* pa = buf + 3 * W4_UNIT;
+            if (W4_RD(first))
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i][0] = w4_frag(pa, wr * 64 + (i ^ wc) * 16, fr, fg);
+                af[i][1] = w4_frag(pa + 8192, wr * 64 + (i ^ wc) * 16, fr, fg);
+            }
+            W4_STAGE(0);
+            W4_STAGE(1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            w4_wait_vmcnt<6>();
+            __builtin_amdgcn_s_barrier();
+            if (first) { W4_MFMA(1, bf1, 1, kh == 0, true); W4_MFMA(1, bf0, 0, kh == 0, false); }
+            else { W4_MFMA(1, bf1, 1, false, true); W4_MFMA(1, bf0, 0, false, false); }
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+#else
     for (int kt = 0; kt < KT; ++kt) {
         const unsigned char* buf = smem + (kt & 1) * W4_BUF;
         const bool first = kt == 0;
@@ -215,6 +286,7 @@ __device__ __forceinline__ void w4_mainloop(const void* A, const void* B, int ld
             __builtin_amdgcn_s_barrier();
         }
     }
+#endif
 #undef W4_MFMA
 #undef W4_RD
 #undef W4_STAGE

@@ -972,15 +972,24 @@ def _fill_weights(d, weights, dtype):
 class _GradPack:
     """one flat fp32 buffer holding the gradients of every parameter of a block call; views are handed to autograd"""
 
-    def __init__(self, params, device, order=None):
+    def __init__(self, params, device, order=None, reuse=None):
         """order: the parameter indices in the order they are laid out in the flat buffer (default: as listed) -- weights whose
-        gradients one GEMM writes as one matrix (merged query / key / value) are made adjacent this way; views stay in list order"""
+        gradients one GEMM writes as one matrix (merged query / key / value) are made adjacent this way; views stay in list order.
+        reuse: {parameter index: view of an EARLIER call's buffer} -- those gradients are accumulated into that view by the grouped
+        weight-gradient launch itself (egv_wgrad_problem::accumulate) and get no storage here; `flat` then holds the others only."""
         sizes = [p.numel() for p in params]
-        self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+        reuse = reuse or {}
+        self.layout = list(order if order is not None else range(len(params)))
+        self.flat = torch.empty(sum(sizes[i] for i in self.layout if i not in reuse), dtype=torch.float32, device=device)
         self.views = [None] * len(params)
+        self.offset = {}                                   # parameter index -> element offset inside self.flat
         off = 0
-        for i in (order if order is not None else range(len(params))):
+        for i in self.layout:
+            if i in reuse:
+                self.views[i] = reuse[i]
+                continue
             self.views[i] = self.flat[off:off + sizes[i]].view(params[i].shape)
+            self.offset[i] = off
             off += sizes[i]
 
 
@@ -1020,7 +1029,7 @@ def _acc_forward(key, track, fused):
     needs_input_grad is True for parameters even under torch.no_grad())."""
     if track:
         for k in ((key, 0), (key, 1)) if fused else ((key, 0),):
-            e = _acc.setdefault(k, {'uses': 0, 'done': 0, 'flat': None, 'views': None, 'params': None, 'side': None, 'stream': None, 'event': None})
+            e = _acc.setdefault(k, {'uses': 0, 'done': 0, 'flat': None, 'views': None, 'params': None, 'side': None, 'stream': None, 'event': None, 'small0': None})
             e['uses'] += 1
 
 
@@ -1063,16 +1072,35 @@ def _queue_done():
         torch.autograd.Variable._execution_engine.queue_callback(_backward_done)
 
 
-def _acc_part(k, flat, views, params, side=None):
-    """side: (companion stream, calling stream) when this call's weight gradients are still running on the companion"""
+def _acc_part(k, flat, views, params, side=None, tail_only=False, small0=None):
+    """side: (companion stream, calling stream) when this call's weight gradients are still running on the companion.
+    small0 (first use): (element offset inside `flat` where the gradients that no grouped launch writes begin, the parameter indices before
+    it), or None when this call had no grouped launch / another layout.
+    tail_only (a later use under _acc_reuse): `flat` holds only that tail -- the launch has already added the rest into the first
+    use's buffer."""
     e = _acc.get(k)
     if e is None:                                             # no bookkeeping for this use (earlier pass flushed it): plain path
+        assert not tail_only
         if side is not None:                                  # nothing may touch the views before the join: join now
             side[1].wait_stream(side[0])
         return views
     cur = torch.cuda.current_stream()
     if e['flat'] is None:
-        e['flat'], e['views'], e['params'], e['side'] = flat, views, params, side
+        assert not tail_only
+        e['flat'], e['views'], e['params'], e['side'], e['small0'] = flat, views, params, side, small0
+    elif tail_only:
+        dst = e['flat'][e['small0'][0]:]
+        assert dst.numel() == flat.numel(), (dst.numel(), flat.numel())
+        sd = side or e['side']
+        if flat.numel():
+            if sd is not None:                                # (the text projections of a fused video block write their gradients on the companion)
+                sd[0].wait_stream(cur)
+                with torch.cuda.stream(sd[0]):
+                    dst.add_(flat)
+                flat.record_stream(sd[0])
+            else:
+                dst.add_(flat)
+        e['side'] = sd
     else:
         if e['stream'] != cur.cuda_stream:
             # the uses of one block ran on different streams (the model keeps a tower on one stream, so this is the exception):
@@ -1111,11 +1139,59 @@ def _acc_part(k, flat, views, params, side=None):
     return [None] * len(params)
 
 
-def _acc_backward(key, pack, params, nshared, side=None):
-    ns = sum(p.numel() for p in params[:nshared])
-    out = list(_acc_part((key, 0), pack.flat[:ns], pack.views[:nshared], params[:nshared], side))
-    if len(params) > nshared:
-        out += list(_acc_part((key, 1), pack.flat[ns:], pack.views[nshared:], params[nshared:], side))
+def _acc_reuse(key, params, nshared, layout, acc_params, side):
+    """beta = 1 plan of a backward call (EGV_WGRAD_ACC): for each part of the block's parameters (0: those every use of the block has,
+    1: the fusion extras) whose FIRST use of this step has already run on this stream, the gradients the grouped weight-gradient launch
+    forms (`acc_params`: parameter indices) are accumulated into that use's buffer inside the launch -- no second 20-57 MB buffer, no
+    flat add over it.  Returns ({parameter index: first use's view}, [part is accumulating]).  What the launch does not write
+    (LayerNorm / gate gradients, the projections over the other modality's rows: < 1 % of the bytes unfused) must be the TAIL of the
+    part's layout, so that one small add covers it; a part whose layout does not have that form is left on the flat-add path."""
+    reuse, on = {}, [False, False]
+    if not acc_params or not SW.on('EGV_WGRAD_ACC'):
+        return reuse, on
+    cur = torch.cuda.current_stream().cuda_stream
+    for part, (lo, hi) in enumerate(((0, nshared), (nshared, len(params)))):
+        e = _acc.get((key, part))
+        if hi <= lo or e is None or e['flat'] is None or e['stream'] != cur or e.get('small0') is None:
+            continue
+        if e['small0'][1] != frozenset(i for i in acc_params if lo <= i < hi):
+            continue                                        # the first use formed other gradients in its launch (another batch size: another form)
+        es, ss = e['side'], side
+        if (es is None) != (ss is None) or (es is not None and es[0].cuda_stream != ss[0].cuda_stream):
+            continue                                        # both launches must sit on ONE stream (the companion, or the calling stream)
+        reuse.update({i: e['views'][i - lo] for i in range(lo, hi) if i in acc_params})
+        on[part] = True
+    return reuse, on
+
+
+def _part_small0(layout, lo, hi, acc_params):
+    """number of accumulating parameters at the head of a part's layout if the others form its tail, else None"""
+    idx = [i for i in layout if lo <= i < hi]
+    n = 0
+    while n < len(idx) and idx[n] in acc_params:
+        n += 1
+    return n if all(i not in acc_params for i in idx[n:]) else None
+
+
+def _acc_backward(key, pack, params, nshared, side=None, acc_params=(), acc_on=(False, False)):
+    out = []
+    for part, (lo, hi) in enumerate(((0, nshared), (nshared, len(params)))):
+        if hi <= lo:
+            continue
+        pp, vv = params[lo:hi], pack.views[lo:hi]
+        idx = [i for i in pack.layout if lo <= i < hi]
+        n0 = _part_small0(pack.layout, lo, hi, acc_params)
+        if acc_on[part]:
+            # the launch added the big gradients into the first use's buffer; what is left of this call is the tail of small ones
+            small = [i for i in idx if i not in acc_params]
+            a = pack.offset[small[0]] if small else 0
+            b = (pack.offset[small[-1]] + params[small[-1]].numel()) if small else 0
+            out += list(_acc_part((key, part), pack.flat[a:b], vv, pp, side, tail_only=True))
+        else:
+            a = pack.offset[idx[0]]
+            b = pack.offset[idx[-1]] + params[idx[-1]].numel()
+            small0 = None if (n0 is None or n0 == 0) else (sum(params[i].numel() for i in idx[:n0]), frozenset(idx[:n0]))
+            out += list(_acc_part((key, part), pack.flat[a:b], vv, pp, side, small0=small0))
     return out
 
 
@@ -1175,6 +1251,11 @@ class VideoBlockFn(Function):
     """SpaceTimeBlock.forward (video_transformer.py:214-228).  params = [W, b] x 6 (timeattn.qkv, timeattn.proj, attn.qkv,
     attn.proj, mlp.fc1, mlp.fc2), [gamma, beta] x 3 (norm3, norm1, norm2) and, for a fused block, [W, b] x 3 (qkv_text_i2t,
     qkv_i2t, proj_i2t), norm_i2t_i gamma / beta, alpha_i2t."""
+
+    # flat gradient layout of a fused block: in each part (the 18 shared parameters | the fusion extras) what the grouped weight-gradient
+    # launch writes comes first and the rest -- LayerNorm pairs; in the extras the text projection qkv_text_i2t, norm_i2t_i and the gate --
+    # is the part's tail (one small add when a later use of the block accumulates: _acc_reuse)
+    ORDER_FUSED = list(range(18)) + [20, 21, 22, 23, 18, 19, 24, 25, 26]
 
     @staticmethod
     def _desc(cfg, x, y, y_mask, params):
@@ -1269,8 +1350,21 @@ class VideoBlockFn(Function):
         d = VideoBlockFn._desc(cfg, x, y, y_mask, params)
         dx = torch.empty_like(x)
         dy = torch.empty_like(y) if (fused and ctx.needs_input_grad[2]) else None
+        d.stream2 = _side_stream_ptr()
+        side = _defer_side(params) if (d.stream2 and lib.egv_vblock_bwd_defers(C.byref(d))) else None
+        # beta = 1: a later use of this block in the step adds the gradients of its grouped weight-gradient launch into the first use's
+        # buffer inside the launch (only in the deferred-group form: that is where the launch exists)
+        gmask = int(lib.egv_vblock_bwd_groups(C.byref(d))) if side is not None else 0
+        acc_params = set()
+        for w in range(9 if fused else 6):
+            if (gmask >> w) & 1:
+                acc_params.update((2 * w, 2 * w + 1) if w < 6 else (18 + 2 * (w - 6), 19 + 2 * (w - 6)))
+        order = VideoBlockFn.ORDER_FUSED if fused else None
+        reuse, acc_on = _acc_reuse(ctx.key, params, 18, order or range(len(params)), acc_params, side)
+        for i in reuse:
+            d.acc_mask |= 1 << (i // 2 if i < 12 else 6 + (i - 18) // 2)
         # LayerNorm gradients live as [gamma ; beta] pairs (one reduction launch per LayerNorm): params are ordered that way
-        gp = _GradPack(params, x.device)
+        gp = _GradPack(params, x.device, order, reuse)
         nwsb = lib.egv_vblock_ws_bytes(C.byref(d), 1)
         ws = torch.empty(nwsb, dtype=torch.uint8, device=x.device)
         d.save, d.save_bytes, d.ws, d.ws_bytes = _p(save), save.numel(), _p(ws), nwsb
@@ -1285,8 +1379,6 @@ class VideoBlockFn(Function):
                 d.dw[6 + i], d.db[6 + i] = _p(g[18 + 2 * i]), _p(g[19 + 2 * i])
             d.dln_g[3], d.dln_b[3] = _p(g[24]), _p(g[25])
             d.dalpha = _p(g[26])
-        d.stream2 = _side_stream_ptr()
-        side = _defer_side(params) if (d.stream2 and lib.egv_vblock_bwd_defers(C.byref(d))) else None
         if side is not None:
             # the grouped weight-gradient launch of this call keeps running on the companion stream after the call returns:
             # everything it reads or writes must outlive it in the caching allocator, and the calling stream is joined at the
@@ -1298,7 +1390,7 @@ class VideoBlockFn(Function):
             _deferred['sides'][side[0].cuda_stream] = side
             _queue_done()
         check(lib.egv_vblock_bwd(C.byref(d)), 'egv_vblock_bwd')
-        return (None, dx, dy, None, *_acc_backward(ctx.key, gp, params, 18, side))
+        return (None, dx, dy, None, *_acc_backward(ctx.key, gp, params, 18, side, acc_params, acc_on))
 
 
 class VideoHeadFn(Function):
@@ -1549,8 +1641,10 @@ class TextLayerFn(Function):
 
     # flat gradient layout: [Wq Wk Wv | bq bk bv | ...] and, in the fused extras, [Wcq bcq | Wck Wcv | bck bcv | ...]: the merged
     # projections write their weight / bias gradients as one matrix / one vector
+    # (in each part the gradients of the grouped launch first, the rest -- LayerNorms; key | value of text-to-image over the video rows and
+    # the gate -- as the tail: _acc_reuse)
     ORDER = [0, 2, 4, 1, 3, 5] + list(range(6, 16))
-    ORDER_FUSED = ORDER + [16, 17, 18, 20, 19, 21, 22, 23, 24]
+    ORDER_FUSED = ORDER + [16, 17, 22, 23, 18, 20, 19, 21, 24]
 
     @staticmethod
     def forward(ctx, cfg, hid, mask, enc, *params):
@@ -1580,7 +1674,16 @@ class TextLayerFn(Function):
         denc = torch.empty_like(enc) if (fused and ctx.needs_input_grad[3]) else None
         if cfg[9] and dout.dtype != torch.float32:
             dout = dout.float()
-        gp = _GradPack(params, hid.device, TextLayerFn.ORDER_FUSED if fused else TextLayerFn.ORDER)
+        gmask = int(lib.egv_tlayer_bwd_groups(C.byref(d)))
+        acc_params = set()
+        for w in range(10 if fused else 6):
+            if (gmask >> w) & 1:
+                acc_params.update((2 * w, 2 * w + 1) if w < 6 else (16 + 2 * (w - 6), 17 + 2 * (w - 6)))
+        order = TextLayerFn.ORDER_FUSED if fused else TextLayerFn.ORDER
+        reuse, acc_on = _acc_reuse(ctx.key, params, 16, order, acc_params, None)
+        for i in reuse:
+            d.acc_mask |= 1 << (i // 2 if i < 12 else 6 + (i - 16) // 2)
+        gp = _GradPack(params, hid.device, order, reuse)
         nwsb = lib.egv_tlayer_ws_bytes(C.byref(d), 1)
         ws = torch.empty(nwsb, dtype=torch.uint8, device=hid.device)
         d.save, d.save_bytes, d.ws, d.ws_bytes = _p(save), save.numel(), _p(ws), nwsb
@@ -1596,7 +1699,7 @@ class TextLayerFn(Function):
             d.dalpha = _p(g[24])
         d.stream2 = _side_stream_ptr()
         check(lib.egv_tlayer_bwd(C.byref(d)), 'egv_tlayer_bwd')
-        return (None, dhid, None, denc, *_acc_backward(ctx.key, gp, params, 16))
+        return (None, dhid, None, denc, *_acc_backward(ctx.key, gp, params, 16, None, acc_params, acc_on))
 
 
 def text_layer(hid, mask, params, B, Lt, H, Hd, eps, enc=None, S=0, drop_p=0.0, seeds=(0, 0, 0, 0, 0, 0), res32=False):

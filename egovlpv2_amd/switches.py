@@ -17,6 +17,7 @@ SWITCHES = {
     'EGV_TEXT_STREAM': ('1', 'text tower on its companion stream'),
     'EGV_TAIL_STREAM': ('1', 'MLM head + cross entropy and the EgoNCE tail on the text stream'),
     'EGV_WGRAD_DEFER': ('1', 'a video block backward returns while its grouped weight-gradient launch is still running'),
+    'EGV_WGRAD_ACC': ('1', 'later uses of a block add their grouped weight gradients into the first use\'s buffer inside the launch (beta = 1)'),
     'EGV_WGRAD_TAIL': ('1', 'the last block of a backward pass gives its weight gradients 7/8 of the chip'),
     'EGV_ATTN_FUSED_BWD': ('1', 'per-op attention: one-launch backward where a kernel covers the shape'),
     'EGV_ATTN_FUSED_CLS': ('1', 'per-op attention: the group launches also serve the CLS row'),

@@ -87,6 +87,9 @@ typedef struct egv_wgrad_problem {
     float* dw; float* db;
     const float* gate;
     int N, K;
+    int accumulate;                     /* 1: dw += ..., db += ... (beta = 1: a block used several times per step adds a later use's gradient
+                                           into the first use's buffer inside the launch -- existing + (sum of the splits, gated): the bits of
+                                           a separate fp32 add of two buffers); 0: overwrite */
 } egv_wgrad_problem;
 long long egv_gemm_wgrad_grouped_workspace_bytes(int M, int nprob, const egv_wgrad_problem* problems, int cus);   /* -1: group not supported */
 int egv_gemm_wgrad_grouped(int dtype, int M, int nprob, const egv_wgrad_problem* problems, int cus, void* workspace,
@@ -355,6 +358,9 @@ typedef struct egv_vblock_desc {
      * chains on two streams lets each chain's GEMMs take a share of the chip, so that the other chain's HBM-bound kernels
      * (LayerNorm, attention) find free CUs beside them instead of queueing behind a grid that owns every CU. */
     int fwd_cus;
+    /* egv_vblock_bwd: bit w set = the weight / bias gradient of Linear slot w is ADDED to dw[w] / db[w] (egv_wgrad_problem::accumulate) -- honoured by
+     * the grouped weight-gradient launch only (egv_vblock_bwd_groups(d) == 1); a caller must not set bits otherwise. */
+    unsigned int acc_mask;
 } egv_vblock_desc;
 #define EGV_BLOCK_HEAD 32     /* egv_vblock_fwd / _bwd (EGV_BLOCK_RES_F32 form): only the part of the block every output row depends on -- norm3, the
                                  time attention with its projection and residual, norm1 and the space attention's qkv projection
@@ -377,6 +383,8 @@ int egv_vblock_fwd(const egv_vblock_desc* d);
 int egv_vblock_bwd(const egv_vblock_desc* d);
 /* 1 if egv_vblock_bwd(d) with EGV_BLOCK_NO_JOIN would return with weight-gradient work still running on d->stream2 */
 int egv_vblock_bwd_defers(const egv_vblock_desc* d);
+/* bit mask of the Linear slots whose weight gradients egv_vblock_bwd(d) would form in ONE grouped launch (and may therefore accumulate: acc_mask); 0: none */
+unsigned int egv_vblock_bwd_groups(const egv_vblock_desc* d);
 
 /* RobertaLayer.forward (roberta.py:444-505) on hid[B*L, D]: self attention (:257-327, separate q/k/v Linears, additive key
  * mask, probability dropout), RobertaSelfOutput (:335-345), optional text-to-image cross attention over enc[B*S, D] (video
@@ -409,11 +417,13 @@ typedef struct egv_tlayer_desc {
      * must follow dw[0] contiguously ([3D, D] fp32) and db[1], db[2] follow db[0]; with w_ckv set, dw[8] follows dw[7] and db[8] db[7]. */
     const void* w_qkv; const void* wt_qkv; const float* b_qkv;
     const void* w_ckv; const void* wt_ckv; const float* b_ckv;
+    unsigned int acc_mask;                          /* egv_tlayer_bwd: as egv_vblock_desc::acc_mask (slots 0..9; a merged q | k | v gradient follows bit 0, k | v of t2i bit 7) */
 } egv_tlayer_desc;
 long long egv_tlayer_save_bytes(const egv_tlayer_desc* d);
 long long egv_tlayer_ws_bytes(const egv_tlayer_desc* d, int backward);
 int egv_tlayer_fwd(const egv_tlayer_desc* d);
 int egv_tlayer_bwd(const egv_tlayer_desc* d);
+unsigned int egv_tlayer_bwd_groups(const egv_tlayer_desc* d);   /* as egv_vblock_bwd_groups */
 
 /* ---- instrumentation: HIP-event timing of the GEMM launches on their own stream (bench.py roofline) ---- */
 int egv_prof_enable(int on);

@@ -745,6 +745,29 @@ def test_persistent_gemm_bitwise_equals_ring_gemm(ops, N, K, kind):
     assert _rel(big[rows.cuda()], ref) < 6e-3
 
 
+@pytest.mark.parametrize('N,K,bias', [(768, 768, False), (2304, 768, False), (768, 768, True)])
+def test_persistent_gemm_gated_plain_kind_bitwise_equals_ring_gemm(ops, N, K, bias):
+    """The gate WITHOUT a residual or a saved pre-gate value -- egv_block.cpp's data gradient of the gated image-to-text projection,
+    d_o = alpha (d_sr W_proj_i2t) -- takes the persistent kernel's plain kind (192- and 256-row tiles), whose spread epilogue (round 6)
+    has to apply it: bitwise against the ring kernel on a slice of the rows, fp64 on the ragged last rows.  (Round 6's first spread
+    epilogue dropped the factor; no per-op test saw it -- the end-to-end gradient check of test_base_f16_vs_golden did.)"""
+    M, m = FULL_M, 1024
+    x = _rnd((M, K), torch.bfloat16, 1.0, 31).cuda()
+    w = _rnd((N, K), torch.float32, 0.05, 32).to(torch.bfloat16).cuda()
+    b = _rnd((N,), torch.float32, 0.5, 33).cuda() if bias else None
+    gate = torch.tensor([0.37], device='cuda')
+    big = torch.empty(M, N, dtype=torch.bfloat16, device='cuda')
+    small = torch.empty(m, N, dtype=torch.bfloat16, device='cuda')
+    ops.gemm(x, w, big, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=b, gate=gate)
+    ops.gemm(x[:m].contiguous(), w, small, M=m, N=N, K=K, lda=K, ldb=K, ldc=N, bias=b, gate=gate)
+    assert torch.equal(big[:m], small)
+    rows = torch.arange(M - 8, M)
+    z = x[rows.cuda()].double().cpu() @ w.double().cpu().t()
+    if b is not None:
+        z = z + b.double().cpu()
+    assert _rel(big[rows.cuda()], 0.37 * z) < 6e-3
+
+
 def test_cls_only_attention_vs_fp64(ops):
     """ops.cls_attention: the CLS query of a divided space attention over ALL S keys, straight from the fused qkv matrix (the last block
     of a video pass, model.py::_video_block_tail): output and the whole dqkv (dK | dV of every row, dQ of the CLS rows, zeros elsewhere)

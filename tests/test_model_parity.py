@@ -834,6 +834,33 @@ def test_layernorm_fold_and_clip_gather_are_bitwise_neutral_bf16(monkeypatch):
         assert torch.equal(g, out['0'][1][n]), n
 
 
+def test_weight_gradient_accumulation_inside_the_grouped_launch_is_bitwise_neutral_bf16(monkeypatch):
+    """round 6 (beta = 1): a block used by several passes of a step (EgoNCE / MLM / ITM) has its later uses ADD their weight and bias
+    gradients into the first use's flat buffer inside the grouped weight-gradient launch (egv_wgrad_problem::accumulate; the LayerNorm /
+    gate / other-modality tail of the buffer by one small add) instead of writing a second 20-57 MB buffer and adding the two --
+    existing + (sum of the splits): the bits of the separate add.  Losses and every gradient of the three-loss step with the switch on
+    and off; full token geometry and enough rows (M = 4710 video tokens, 96 text rows) for the grouped launches, 3 layers, two fused."""
+    from egovlpv2_amd.config import PathConfig
+    from egovlpv2_amd.synthetic import make_state_dict, make_batch
+    cfg = PathConfig(depth=3, n_fuse=2, frames=4, img=224)
+    sd = make_state_dict(cfg, 9)
+    data, noun, verb = make_batch(cfg, 6, 16, 29)
+    out = {}
+    for acc in ('1', '0'):
+        monkeypatch.setenv('EGV_WGRAD_ACC', acc)
+        m = _build(cfg, sd, torch.bfloat16)
+        np.random.seed(3)
+        torch.manual_seed(3)
+        loss, ld, ret = _forward(m, data, noun, verb, 'EgoNCE_MLM_ITM')
+        loss.backward()
+        torch.cuda.synchronize()
+        out[acc] = ({k: float(v) for k, v in ld.items()}, {n: p.grad.clone() for n, p in m.named_parameters()})
+    assert out['1'][0] == out['0'][0], (out['1'][0], out['0'][0])
+    for n, g in out['1'][1].items():
+        assert torch.isfinite(g).all(), n
+        assert torch.equal(g, out['0'][1][n]), n
+
+
 def test_inference_calls_skip_backward_only_stores_bitwise_neutral_bf16(monkeypatch):
     """round 5: a video block called under torch.no_grad() (infer(), validation, feature extraction) is told so (EGV_BLOCK_INFER) and does
     not write the MLP's pre-activation (fc1 runs its GELU epilogue with one store instead of two) nor the bf16 copies of the two inner
