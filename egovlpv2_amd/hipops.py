@@ -956,10 +956,21 @@ def _side_stream_ptr():
         return None
     cur = torch.cuda.current_stream()
     key = (cur.device.index, cur.cuda_stream)
+    if any(k[0] == key[0] and v.cuda_stream == key[1] for k, v in _wg_streams.items()):
+        return None                                         # the current stream IS a companion (work forked onto it): no companion of a companion
     st = _wg_streams.get(key)
     if st is None:
         st = _wg_streams[key] = companion_stream(cur.device)
     return st.cuda_stream
+
+
+def weight_gradient_stream_of(stream):
+    """the weight-gradient companion of `stream` (created on first use) -- model.py forks the MLM pass's top onto the text stream's"""
+    key = (stream.device.index, stream.cuda_stream)
+    st = _wg_streams.get(key)
+    if st is None:
+        st = _wg_streams[key] = companion_stream(stream.device)
+    return st
 
 
 def _fill_weights(d, weights, dtype):

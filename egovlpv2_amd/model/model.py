@@ -275,6 +275,7 @@ class FrozenInTime(nn.Module):
         or backward) are still queued.  Returns (out, join); join() orders the calling stream after fn's work only."""
         if not self._overlap() or not SW.on('EGV_TEXT_STREAM') or (kind == 'tail' and not SW.on('EGV_TAIL_STREAM')):
             return fn(), (lambda: None)
+        aux = kind == 'aux' and SW.on('EGV_MLM_TOP_AUX')
         kind = 'text'                                          # the loss tails follow the text tower on its stream
         main = torch.cuda.current_stream()
         sides = self.__dict__.setdefault('_sides', {})
@@ -290,6 +291,10 @@ class FrozenInTime(nn.Module):
             if warn_off is not None:
                 warn_off(False)
         side = sides[kind]
+        if aux:
+            # kind 'aux': the text stream's own weight-gradient companion -- a fourth stream that exists anyway and is idle at both ends of
+            # a step (every further HIP stream would share a hardware queue with one of the four: measured + 9 ms with two queues)
+            side = ops.weight_gradient_stream_of(side)
         if after is None:
             side.wait_stream(main)
         else:
@@ -611,14 +616,17 @@ class FrozenInTime(nn.Module):
             t = self._text_layer(t, mask, i, B, L)
         return t, mask
 
-    def _fused_stack(self, video, input_ids, attention_mask, need_video_out=True, video_prefix=None, text_prefix=None):
+    def _fused_stack(self, video, input_ids, attention_mask, need_video_out=True, video_prefix=None, text_prefix=None, defer_top=False):
         """model.py:211-271 / :295-357: model-level cls_token, unfused prefix, then fused steps where both sides read the
         other modality's state from BEFORE the step.  With need_video_out=False (MLM branch) the last video block, whose
         output the reference computes and discards, is skipped.  video_prefix: the already computed
         output of _video_prefix for these clips (video is then ignored); text_prefix: ((hidden, mask), join) of a
         _text_prefix already forked by the caller.
         Both halves of a fused step depend only on the previous step, so the text layer runs on the side stream while the
-        video block runs on the calling stream (events both ways per step)."""
+        video block runs on the calling stream (events both ways per step).
+        defer_top (need_video_out=False only): the LAST fused text layer -- which has no video block beside it -- is not issued; the
+        third result is a callable that issues it (on the text stream) and returns its output.  The caller may create it AFTER other
+        graph parts: the autograd engine then runs its backward BEFORE theirs."""
         c = self.cfg
         B, L = input_ids.shape
         n_plain = c.depth - c.n_fuse
@@ -634,6 +642,11 @@ class FrozenInTime(nn.Module):
             if overlap:
                 ev = torch.cuda.Event()
                 ev.record()                                                   # v (and t, joined above) are ready here
+            if last and defer_top and not need_video_out:
+                def top(t=t, v=v, ev=ev, i=i):
+                    t_top, join_top = self._fork_text(lambda: self._text_layer(t, mask, i, B, L, enc=v), uses=(v, mask, t), after=ev, kind='aux')
+                    return t_top, join_top
+                return None, t, top
             t_new, join = self._fork_text(lambda: self._text_layer(t, mask, i, B, L, enc=v), uses=(v, mask, t), after=ev)
             tail = last and need_video_out and self._tail_ok(v)             # (the result is read at the CLS rows only: model.py:275)
             nxt = None if (i + 1 == c.depth or (i + 2 == c.depth and not need_video_out)) else (i + 1, 0 if (i + 2 == c.depth and self._tail_ok(v)) else L)
@@ -645,7 +658,7 @@ class FrozenInTime(nn.Module):
                 v_new = self._video_block(v, i, B, y=self._text_operand(t), y_mask=mask, L=L, next_block=nxt)
             join()
             v, t = v_new, t_new
-        return v, t
+        return (v, t, None) if defer_top else (v, t)
 
     def infer(self, data, video_only=False, return_embeds=True, task_names=None, ret=None):
         """model.py:189-367.  (The reference's mutable default ``ret={}`` is replaced by a fresh dict.)"""
@@ -944,8 +957,26 @@ class FrozenInTime(nn.Module):
             # the ITM pass's backward instead of after it (2.2 ms of calling-stream idle time per step)
             self._prepare_weights()
             self.task_names = 'MLM'
-            _, t_mlm = self._fused_stack(data_mlm['video'], data['text_mlm_ids'], data['text']['attention_mask'], need_video_out=False,
-                                         video_prefix=data_mlm.get('_video_prefix'), text_prefix=data_mlm.get('_text_prefix'))
+            # EGV_MLM_TOP_LATE (round 6): the pass's top -- its last fused text layer (no video block beside it), the head and the cross
+            # entropy, ~1 ms of small launches on the text stream in each direction -- is CREATED after the ITM pass.  The engine runs
+            # backward nodes in reverse creation order: the top's backward is then the first thing the text stream runs, beside the
+            # B-row chain of the ITM pass's CLS-only last block on the calling stream (1.1 ms with the chip idle), instead of after the ITM
+            # pass's text layers, where the first MLM video block's backward waited for it (1.2 ms hole at the ITM -> MLM boundary).
+            late = ('ITM' in task_names and not SW.on('EGV_ITM_FIRST') and SW.on('EGV_MLM_TOP_LATE') and self._overlap() and SW.on('EGV_TEXT_STREAM'))
+            out = self._fused_stack(data_mlm['video'], data['text_mlm_ids'], data['text']['attention_mask'], need_video_out=False,
+                                    video_prefix=data_mlm.get('_video_prefix'), text_prefix=data_mlm.get('_text_prefix'), defer_top=late)
+            if late and out[2] is not None:
+                top = out[2]
+
+                def finish():
+                    t_top, join_top = top()
+                    joins.append(join_top)
+                    mlm_head(t_top, kind='aux')           # (same stream as the layer: in order behind it, no event)
+                mlm_late.append(finish)
+                return
+            mlm_head(out[1])
+
+        def mlm_head(t_mlm, kind='tail'):
             labels = data['text_mlm_labels'].reshape(-1)
 
             def mlm_tail():
@@ -959,7 +990,7 @@ class FrozenInTime(nn.Module):
                 # two per-rank scalars gives the identical loss and, through AllGather_multi.backward, identical gradients.
                 tot = gather(torch.stack([ce_sum, cnt]).reshape(1, 2))
                 return logits, tot[:, 0].sum() / tot[:, 1].sum()
-            (logits, loss_mlm), join_mlm = self._fork_text(mlm_tail, uses=(t_mlm, labels), kind='tail')
+            (logits, loss_mlm), join_mlm = self._fork_text(mlm_tail, uses=(t_mlm, labels), kind=kind)
             joins.append(join_mlm)
             Bm, Lm = data['text_mlm_ids'].shape
             ret.update({'cross_attn_mlm_logits': logits.reshape(Bm, Lm, -1)[..., :c.vocab]})
@@ -1015,9 +1046,12 @@ class FrozenInTime(nn.Module):
             loss_dict['loss_mlm'] = None
         if 'ITM' in task_names:
             loss_dict['loss_itm'] = None
+        mlm_late = []
         for name, fn in ((('ITM', run_itm), ('MLM', run_mlm)) if SW.on('EGV_ITM_FIRST') else (('MLM', run_mlm), ('ITM', run_itm))):
             if name in task_names:
                 fn()
+        for fn in mlm_late:
+            fn()
         for key in ('mlm', 'itm'):
             if key in terms:
                 loss_terms.append(terms[key])

@@ -37,6 +37,8 @@ SWITCHES = {
     'EGV_EGONCE_TAIL_LATE': ('1', 'differentiable EgoNCE tail created after both text prefixes'),
     'EGV_ITM_DRAW_EARLY': ('1', 'ITM negatives drawn before the MLM pass is enqueued'),
     'EGV_ITM_FIRST': ('0', 'create the ITM pass before the MLM pass (default: the reference order)'),
+    'EGV_MLM_TOP_AUX': ('1', 'the late MLM top runs on the text stream\'s weight-gradient companion instead of the text stream'),
+    'EGV_MLM_TOP_LATE': ('1', 'the MLM pass\'s last fused text layer + head + cross entropy are created after the ITM pass (their backward then runs first, beside the ITM tail)'),
     'EGV_EXCHANGE_HOST_TABLE': ('0', 'exchange the ITM request table through a host (gloo) all-gather also on RCCL'),
     'EGV_SYNC_WIRE': ('fp32', 'flat gradient sync: fp32 = in-place all-reduce, bf16 = bf16 on the links with fp32 accumulation on arrival (grad_sync.allreduce_bf16_wire)'),
     'EGV_SYNC_FORCE': ('0', 'run the flat gradient all-reduces at world size 1 (test aid)'),
