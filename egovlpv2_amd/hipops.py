@@ -1341,6 +1341,12 @@ class VideoBlockFn(Function):
         if cfg[7]:
             _first_vblock[0] = False
         _acc_forward(ctx.key, cfg[7], cfg[6] > 0)
+        ctx.recompute = None
+        if len(cfg) > 14 and cfg[14]:
+            # activation checkpointing: this call ran with EGV_BLOCK_INFER (what only a backward call reads was not even written) and its
+            # save buffer dies here; the backward call re-runs the forward from the inputs (x and, with the fp32 stream, its fp32 value)
+            ctx.recompute = (res32, x32)
+            save = torch.empty(0, dtype=torch.uint8, device=x.device)
         ctx.save_for_backward(x, y, y_mask, save, *params)
         if res32:
             if next_save is None:
@@ -1358,6 +1364,21 @@ class VideoBlockFn(Function):
             dout = torch.zeros_like(x)
         fused = cfg[6] > 0
         dout = dout.contiguous()
+        if ctx.recompute is not None:
+            res32, x32 = ctx.recompute
+            df = VideoBlockFn._desc(cfg, x, y, y_mask, params)
+            out_r = torch.empty_like(x)
+            out32_r = None
+            if res32:
+                out32_r = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+                df.flags |= L.BLOCK_RES_F32
+                df.x32, df.out32 = _p(x32), _p(out32_r)
+            nsave = lib.egv_vblock_save_bytes(C.byref(df))
+            save = torch.empty(nsave, dtype=torch.uint8, device=x.device)
+            wsf = workspace(lib.egv_vblock_ws_bytes(C.byref(df), 0), x.device, slot=2)
+            df.out, df.save, df.save_bytes, df.ws, df.ws_bytes = _p(out_r), _p(save), nsave, _p(wsf), wsf.numel()
+            check(lib.egv_vblock_fwd(C.byref(df)), 'egv_vblock_fwd(recompute)')
+            del out_r, out32_r
         d = VideoBlockFn._desc(cfg, x, y, y_mask, params)
         dx = torch.empty_like(x)
         dy = torch.empty_like(y) if (fused and ctx.needs_input_grad[2]) else None
@@ -1585,24 +1606,32 @@ def stream32(x):
     return getattr(x, '_res32', None)
 
 
-def video_block(x, params, B, Fr, N, H, Hd, eps, y=None, y_mask=None, L=0, fp8=False, next_ln=None):
+def video_block(x, params, B, Fr, N, H, Hd, eps, y=None, y_mask=None, L=0, fp8=False, next_ln=None, recompute=False):
     """fp8: the forward / dgrad GEMMs over the video tokens on MX-fp8 operands (bf16 mode only; BASELINE.json configs[4]).
     With EGV_VIDEO_RES32 (bf16 mode) the residual stream is fp32, as under the reference's autocast (trainer_egoclip.py:143): the
     returned bf16 tensor -- the one autograd sees, GEMMs read and the backward pass uses -- carries its fp32 value as `._res32`,
     which the next block (and the final LayerNorm) picks up.
     next_ln = (gamma, beta, L_next) of the block that will consume the result (its norm3, and whether it is a fused block over L_next
     text tokens): this call's output pass then also writes that LayerNorm into the save buffer of the next call, which travels with
-    the result as `._pre_save` and is taken by the FIRST video_block call on it (EGV_LN_FOLD; a second consumer normalises itself)."""
+    the result as `._pre_save` and is taken by the FIRST video_block call on it (EGV_LN_FOLD; a second consumer normalises itself).
+    recompute: activation checkpointing (the reference's yml `use_checkpoint`, model.py:239-266,326: torch.utils.checkpoint around every
+    block) -- the call keeps its inputs only; its backward call first re-runs the forward into a fresh save buffer (bitwise the first
+    run: same kernels, same inputs, no dropout in a video block), then runs the backward.  0.85 GB less per block call at configs[2],
+    one more forward per block."""
     res32 = video_res32(x, fp8)
+    recompute = bool(recompute) and _tracks_grad(params) and not fp8
     pre = None
-    if res32:
+    if recompute:
+        x.__dict__.pop('_pre_save', None)                    # (a save buffer that is dropped after the forward: nothing to fold into)
+        next_ln = None
+    elif res32:
         ps = x.__dict__.pop('_pre_save', None)
         if ps is not None and ps[1] == id(params[12]):
             pre = ps[0]
         if next_ln is not None and not SW.on('EGV_LN_FOLD'):
             next_ln = None
     cfg = (B, Fr, N, H, Hd, float(eps), L if y is not None else 0, _tracks_grad(params), bool(fp8), res32, stream32(x) if res32 else None,
-           pre, next_ln if res32 else None, (not torch.is_grad_enabled()) and SW.on('EGV_INFER_LEAN'))
+           pre, next_ln if res32 else None, ((not torch.is_grad_enabled()) and SW.on('EGV_INFER_LEAN')) or recompute, recompute)
     if not res32:
         return VideoBlockFn.apply(cfg, x, y, y_mask, *params)
     out, out32, nsv = VideoBlockFn.apply(cfg, x, y, y_mask, *params)

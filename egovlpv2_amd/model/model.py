@@ -131,7 +131,7 @@ class FrozenInTime(nn.Module):
     def __init__(self, video_params, text_params, projection_dim=4096, load_checkpoint=None, projection='minimal',
                  load_temporal_fix='bilinear', config=config, task_names='EgoNCE_ITM_MLM', norm_layer=None, embed_dim=768,
                  compute_dtype=torch.bfloat16, path_config: PathConfig | None = None, init_seed: int = 0, text_fp32: bool = False,
-                 video_fp8: bool = False):
+                 video_fp8: bool = False, activation_checkpointing: bool | None = None):
         super().__init__()
         self.video_params = video_params
         self.text_params = text_params
@@ -169,6 +169,14 @@ class FrozenInTime(nn.Module):
         # torch.autocast (trainer/trainer_egoclip.py:143); EGV_TEXT_RES32=0 stores it in bf16 like the video tower's
         self.text_res32 = compute_dtype == torch.bfloat16 and SW.on('EGV_TEXT_RES32')
         self.patches_per_frame = self.cfg.n_patches
+        # Activation checkpointing of the video blocks (the reference: yml `use_checkpoint`, torch.utils.checkpoint around every block,
+        # model.py:239-266,326 -- on by default there, for 40 GB parts).  Here it is an OPTION: at configs[2] every saved activation fits
+        # (34.6 GB of 288 GB) and recomputing costs a forward per block, so the default keeps everything.  activation_checkpointing=True,
+        # or EGV_ACT_CHECKPOINT=1, or EGV_ACT_CHECKPOINT=yml (then the yml's use_checkpoint decides, as in the reference).
+        if activation_checkpointing is None:
+            v = SW.value('EGV_ACT_CHECKPOINT')
+            activation_checkpointing = v == '1' or (v == 'yml' and bool(self.config.get('use_checkpoint')))
+        self.act_checkpoint = bool(activation_checkpointing)
 
         gen = torch.Generator().manual_seed(init_seed)
         for name, shape in param_shapes(self.cfg, task_names).items():
@@ -420,7 +428,8 @@ class FrozenInTime(nn.Module):
             pn = self._block_params('video', next_block[0], next_block[1] > 0)
             next_ln = (pn[12], pn[13], next_block[1])                       # norm3 weight / bias of the next block
         return ops.video_block(x, self._block_params('video', i, y is not None), B, c.frames, c.n_patches, c.heads, c.dim * c.mlp_ratio,
-                               c.eps_video, y=y, y_mask=y_mask, L=L, fp8=bool(self.__dict__.get('_mx_weights')), next_ln=next_ln)
+                               c.eps_video, y=y, y_mask=y_mask, L=L, fp8=bool(self.__dict__.get('_mx_weights')), next_ln=next_ln,
+                               recompute=self.act_checkpoint)
 
     def _tail_ok(self, x):
         """may the LAST block of a video pass run in its CLS-only form (_video_block_tail)?  bf16 storage with the fp32 residual stream,

@@ -42,6 +42,7 @@ SWITCHES = {
     'EGV_EXCHANGE_HOST_TABLE': ('0', 'exchange the ITM request table through a host (gloo) all-gather also on RCCL'),
     'EGV_SYNC_WIRE': ('fp32', 'flat gradient sync: fp32 = in-place all-reduce, bf16 = bf16 on the links with fp32 accumulation on arrival (grad_sync.allreduce_bf16_wire)'),
     'EGV_SYNC_FORCE': ('0', 'run the flat gradient all-reduces at world size 1 (test aid)'),
+    'EGV_ACT_CHECKPOINT': ('0', 'activation checkpointing of the video blocks: 1 = on, yml = as the yml use_checkpoint says (reference behaviour), 0 = keep every activation'),
     'EGV_ALLOW_UNSAFE_CHECKPOINT': ('0', 'allow full unpickling of a checkpoint whose safe load fails'),
 }
 
