@@ -15,6 +15,7 @@ SWITCHES = {
     'EGV_SIDE_PRIORITY': ('1', 'HIP priority of the companion streams (1 = low: they take the CUs the calling stream leaves free)'),
     'EGV_TEXT_PRIORITY': ('', 'priority of the text stream when it should differ from EGV_SIDE_PRIORITY'),
     'EGV_TEXT_STREAM': ('1', 'text tower on its companion stream'),
+    'EGV_TAIL_REST_AUX': ('0', 'the B-row chain of the EgoNCE tower\'s CLS-only last block runs on the text stream\'s weight-gradient companion'),
     'EGV_TAIL_STREAM': ('1', 'MLM head + cross entropy and the EgoNCE tail on the text stream'),
     'EGV_WGRAD_DEFER': ('1', 'a video block backward returns while its grouped weight-gradient launch is still running'),
     'EGV_WGRAD_ACC': ('1', 'later uses of a block add their grouped weight gradients into the first use\'s buffer inside the launch (beta = 1)'),
