@@ -355,7 +355,7 @@ def main():
         # tools/pmc_instep.py into a committed file; `source` says which
         traffic = mfma_busy = launches_per_step = trace_avg_us = None
         pmc_file = None
-        for cand in ('round5_pmc_instep.json', 'round4_pmc_instep.json', 'round3_pmc_instep.json', 'round2_pmc_instep.json'):
+        for cand in ('round6_pmc_instep.json', 'round5_pmc_instep.json', 'round4_pmc_instep.json', 'round3_pmc_instep.json', 'round2_pmc_instep.json'):
             if os.path.exists(os.path.join(REPO, 'profiles', cand)):
                 pmc_file = cand
                 break
