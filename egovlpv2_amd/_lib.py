@@ -167,7 +167,6 @@ PROTOTYPES = {
     'egv_vblock_qkv_s_offset': (i64, [C.POINTER(VBlockDesc)]),
     'egv_vblock_next_slots': (i32, [C.POINTER(VBlockDesc), C.POINTER(i64), C.POINTER(i64)]),
     'egv_vblock_save_bytes': (i64, [C.POINTER(VBlockDesc)]),
-    'egv_vblock_next_slots': (i32, [C.POINTER(VBlockDesc), C.POINTER(i64), C.POINTER(i64)]),
     'egv_vblock_ws_bytes': (i64, [C.POINTER(VBlockDesc), i32]),
     'egv_vblock_fwd': (i32, [C.POINTER(VBlockDesc)]),
     'egv_vblock_bwd': (i32, [C.POINTER(VBlockDesc)]),

@@ -292,7 +292,12 @@ VLayout vlayout(const egv_vblock_desc* d) {
     const size_t S = 1 + (size_t)d->F * d->N, M = (size_t)d->B * S, D = d->D, Hd = d->Hd, H = d->H;
     auto T = [&](size_t n) { return b.take_off(n); };
     L.stats3 = T(M * 8); L.h3 = T(M * D * es); L.qkv_t = T(M * 3 * D * es); L.tctx = T(M * D * es); L.lse_t = T(M * H * 4);
-    L.tr = T(M * D * es); L.stats1 = T(M * 8); L.h1 = T(M * D * es); L.qkv_s = T(M * 3 * D * es); L.sctx = T(M * D * es);
+    L.tr = T(M * D * es); L.stats1 = T(M * 8); L.h1 = T(M * D * es); L.qkv_s = T(M * 3 * D * es);
+    if (d->flags & EGV_BLOCK_HEAD) {                     // the head form stops at the space attention's qkv: the MLP / context slots (0.3 GB at configs[2]) are never written or read
+        L.total = al(b.off);
+        return L;
+    }
+    L.sctx = T(M * D * es);
     L.lse_s = T(M * H * 4); L.sr = T(M * D * es); L.stats2 = T(M * 8); L.h2 = T(M * D * es); L.pre = T(M * Hd * es); L.act = T(M * Hd * es);
     if (d->L > 0) {
         const size_t BL = (size_t)d->B * d->L;

@@ -1324,9 +1324,11 @@ class VideoBlockFn(Function):
         next_save = None
         if nxt is not None:
             # fold the NEXT block's first LayerNorm into this call's output pass: it is written into the save buffer the next call will use
-            g_n, b_n, L_n = nxt
+            g_n, b_n, L_n = nxt[:3]
             dn = L.VBlockDesc()
             dn.dtype, dn.B, dn.F, dn.N, dn.H, dn.D, dn.Hd, dn.L, dn.eps = d.dtype, d.B, d.F, d.N, d.H, d.D, d.Hd, L_n, d.eps
+            if len(nxt) > 3 and nxt[3]:
+                dn.flags = L.BLOCK_RES_F32 | L.BLOCK_HEAD        # the consumer is the CLS-only last block's head call: its (shorter) save layout
             so, ho = L.i64(0), L.i64(0)
             check(lib.egv_vblock_next_slots(C.byref(dn), C.byref(so), C.byref(ho)), 'egv_vblock_next_slots')
             next_save = torch.empty(lib.egv_vblock_save_bytes(C.byref(dn)), dtype=torch.uint8, device=x.device)
@@ -1513,15 +1515,15 @@ def video_block_head(x, params, B, Fr, N, H, Hd, eps):
     Returns (qkv_s [M, 3D] bf16, the fp32 CLS rows of x [B, D])."""
     pre = None
     ps = x.__dict__.pop('_pre_save', None)
-    if ps is not None and ps[1] == id(params[6]):
+    if ps is not None and ps[1] is params[6] and ps[2]:          # (the producer's token: the norm3 weight tensor itself, and the head-form layout)
         pre = ps[0]
     return VideoHeadFn.apply((B, Fr, N, H, Hd, float(eps), stream32(x), pre, _tracks_grad(params)), x, *params)
 
 
 class ClsAttnFn(Function):
     """The CLS query of a divided space attention alone: softmax(q_cls K^T / 8) V over ALL S keys of its sample (video_transformer.py:129),
-    straight from the fused qkv matrix [B*S, 3D] -> [B, D].  Forward / backward are the text -> image attention's launches (one query row
-    per sample instead of 32; delta from the fp32 output, egv_attn_desc::O32); the backward writes the whole dqkv matrix: dK | dV of
+    straight from the fused qkv matrix [B*S, 3D] -> [B, D].  Forward / backward are the split (few queries, many keys) launches of the generic
+    attention entry point with one query row per sample (workspace sized by _split_ws; delta from the fp32 output, egv_attn_desc::O32); the backward writes the whole dqkv matrix: dK | dV of
     every row, dQ of the CLS rows, zeros in the other rows' dQ."""
 
     @staticmethod
@@ -1626,7 +1628,7 @@ def video_block(x, params, B, Fr, N, H, Hd, eps, y=None, y_mask=None, L=0, fp8=F
         next_ln = None
     elif res32:
         ps = x.__dict__.pop('_pre_save', None)
-        if ps is not None and ps[1] == id(params[12]):
+        if ps is not None and ps[1] is params[12] and not ps[2]:   # (identity of the norm3 weight the producer normalised with -- not id(): ids are recycled)
             pre = ps[0]
         if next_ln is not None and not SW.on('EGV_LN_FOLD'):
             next_ln = None
@@ -1637,7 +1639,7 @@ def video_block(x, params, B, Fr, N, H, Hd, eps, y=None, y_mask=None, L=0, fp8=F
     out, out32, nsv = VideoBlockFn.apply(cfg, x, y, y_mask, *params)
     out._res32 = out32
     if nsv.numel():
-        out._pre_save = (nsv, id(next_ln[0]))
+        out._pre_save = (nsv, next_ln[0], bool(len(next_ln) > 3 and next_ln[3]))
     return out
 
 

@@ -430,7 +430,8 @@ class FrozenInTime(nn.Module):
         next_ln = None
         if next_block is not None and next_block[0] < c.depth:
             pn = self._block_params('video', next_block[0], next_block[1] > 0)
-            next_ln = (pn[12], pn[13], next_block[1])                       # norm3 weight / bias of the next block
+            # norm3 weight / bias of the next block, its text length, and whether it runs as the CLS-only head call (a shorter save layout)
+            next_ln = (pn[12], pn[13], next_block[1], bool(len(next_block) > 2 and next_block[2]))
         return ops.video_block(x, self._block_params('video', i, y is not None), B, c.frames, c.n_patches, c.heads, c.dim * c.mlp_ratio,
                                c.eps_video, y=y, y_mask=y_mask, L=L, fp8=bool(self.__dict__.get('_mx_weights')), next_ln=next_ln,
                                recompute=self.act_checkpoint)
@@ -606,7 +607,7 @@ class FrozenInTime(nn.Module):
         x = self._patch_tokens(video_data, 'video_model.cls_token')
         last = self.cfg.depth - 1
         for i in range(last):
-            x = self._video_block(x, i, B, next_block=(i + 1, 0))
+            x = self._video_block(x, i, B, next_block=(i + 1, 0, i + 1 == last and self._tail_ok(x)))
         if fork_rest and self._tail_ok(x) and SW.on('EGV_TAIL_REST_AUX'):
             head = self._video_tail_head(x, last, B)
             return self._fork_text(lambda: self._video_out_norm(self._video_tail_rest(head, last, B), B, 'video_model.norm', self.cfg.eps_video),
@@ -672,7 +673,8 @@ class FrozenInTime(nn.Module):
                 return None, t, top
             t_new, join = self._fork_text(lambda: self._text_layer(t, mask, i, B, L, enc=v), uses=(v, mask, t), after=ev)
             tail = last and need_video_out and self._tail_ok(v)             # (the result is read at the CLS rows only: model.py:275)
-            nxt = None if (i + 1 == c.depth or (i + 2 == c.depth and not need_video_out)) else (i + 1, 0 if (i + 2 == c.depth and self._tail_ok(v)) else L)
+            to_tail = i + 2 == c.depth and need_video_out and self._tail_ok(v)     # the next block is the stack's last and runs as the CLS-only tail
+            nxt = None if (i + 1 == c.depth or (i + 2 == c.depth and not need_video_out)) else (i + 1, 0 if to_tail else L, to_tail)
             if last and not need_video_out:
                 v_new = None
             elif tail:

@@ -9,6 +9,8 @@ if REPO not in sys.path:
 
 
 def pytest_configure(config):
+    import torch
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), 64)))       # the CPU oracle inside the tests: see tests/helpers.py
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long CPU test (full-depth oracle)")
 

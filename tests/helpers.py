@@ -10,6 +10,11 @@ from oracle import ref_model as O
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
+# The CPU oracle runs inside the parity tests (and inside their spawned workers, which import this module): on a many-core host torch's
+# default -- one thread per logical CPU -- oversubscribes its GEMMs (EPYC 9575F, 256 logical CPUs: the oracle's full-size step takes 18 s on
+# 64 threads and 3 x that on 128; tests/test_model_parity.py::test_base_f16_vs_golden[bf16] 230 s against 17 s).  64 at most.
+torch.set_num_threads(max(1, min(torch.get_num_threads(), 64)))
+
 
 def load_golden(name):
     g = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
