@@ -161,6 +161,29 @@ __device__ __forceinline__ void gelu_pair_fast_f(float x, float& g, float& d) {
     d = fmaf(x * 0.39894228040143267794f, e, cdf);
 }
 
+// The same three functions on TWO values at a time: the polynomial, the products and the sums as packed fp32 operations (v_pk_fma_f32 /
+// v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per lane and issue slot -- the bits of the scalar forms above), the transcendentals
+// per value.  5 + 2 issue slots per value instead of 8 + 2: the GELU epilogues of the persistent GEMM are bound by VALU issue.
+typedef float gelu_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gelu_f32x2_t phi_fast_f2(gelu_f32x2_t x) {
+    const gelu_f32x2_t a = {fabsf(x[0]), fabsf(x[1])};
+    auto c = [](float v) { return gelu_f32x2_t{v, v}; };
+    gelu_f32x2_t p = __builtin_elementwise_fma(c(-0.0004328800132498145f), a, c(0.005315648391842842f));
+    p = __builtin_elementwise_fma(p, a, c(-0.014343290589749813f));
+    p = __builtin_elementwise_fma(p, a, c(-0.08734285086393356f));
+    p = __builtin_elementwise_fma(p, a, c(-0.00952006783336401f));
+    p = __builtin_elementwise_fma(p, a, c(-2.300459146499634f));
+    const gelu_f32x2_t z = x * p;
+    const gelu_f32x2_t d = c(1.0f) + gelu_f32x2_t{__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};
+    return gelu_f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
+__device__ __forceinline__ gelu_f32x2_t gelu_fast_f2(gelu_f32x2_t x) { return x * phi_fast_f2(x); }
+__device__ __forceinline__ gelu_f32x2_t dgelu_fast_f2(gelu_f32x2_t x) {
+    const gelu_f32x2_t z = x * x * gelu_f32x2_t{-0.72134752044448170368f, -0.72134752044448170368f};
+    const gelu_f32x2_t e = {__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};
+    return __builtin_elementwise_fma(x * gelu_f32x2_t{0.39894228040143267794f, 0.39894228040143267794f}, e, phi_fast_f2(x));
+}
+
 #endif
 
 // priority of a wave inside its MFMA segment (ping-pong GEMM kernels).  -DPP_SETPRIO_OFF: experiment hook

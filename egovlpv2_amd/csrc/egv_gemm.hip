@@ -470,8 +470,18 @@ __global__ __launch_bounds__(256) void wgrad_small_m_kernel(const bf16_t* __rest
     const int n = (int)(idx / k4n), k = (int)(idx % k4n) * 4;
     const float sc = scale * (gate ? *gate : 1.0f);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, sb = 0.f;
+    // diagnostic builds (tools/variant_build.sh): which cache holds the stale line?  3 = plain loads behind an invalidate of the CU's vector L1,
+    // 4 = behind an agent-scope invalidate (vector L1 + the non-coherent lines of this XCD's L2), 5 = plain loads after a delay
+#if SMALLM_DIAG == 3
+    asm volatile("buffer_inv sc0\n\ts_waitcnt vmcnt(0)" ::: "memory");
+#elif SMALLM_DIAG == 4
+    asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+#elif SMALLM_DIAG == 5   // plain loads ~25 us after the wave's start: does a producer that is still finishing explain the stale line?
+    for (int i = 0; i < 6; ++i) __builtin_amdgcn_s_sleep(127);
+    asm volatile("" ::: "memory");
+#endif
     for (int m = 0; m < M; ++m) {
-#if SMALLM_DIAG == 2    // plain cached loads (the form that read stale lines)
+#if SMALLM_DIAG >= 2    // plain cached loads (the form that read stale lines)
         const float d = bf2f(dY[(size_t)m * ldy + n].v);
         const u32x2_t xv = *reinterpret_cast<const u32x2_t*>(X + (size_t)m * ldx + k);
 #else

@@ -47,6 +47,14 @@
 #ifndef PP_E2X
 #define PP_E2X 0
 #endif
+// GELU / GELU' of the epilogues two values at a time (packed fp32 operations; -DPP_GELU_PK=0: the scalar forms, for A/B builds)
+#ifdef EGV_GELU_OLD
+#undef PP_GELU_PK
+#define PP_GELU_PK 0
+#endif
+#ifndef PP_GELU_PK
+#define PP_GELU_PK 1
+#endif
 
 namespace egv {
 
@@ -472,8 +480,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                     v[4 + k] = acc[PP_AOFF(s) + i][t * 2 + 1][k] + b8[4 + k];
                 }
                 if (ACTK) {                                       // GELU only (the launcher sends other activations to the ring kernels)
+#if PP_GELU_PK
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {                 // two values per packed-fp32 operation: the bits of gelu_fast_f
+                        const gelu_f32x2_t r2 = gelu_fast_f2(gelu_f32x2_t{v[2 * k], v[2 * k + 1]});
+                        v[2 * k] = r2[0]; v[2 * k + 1] = r2[1];
+                    }
+#else
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] = gelu_fast_f(v[k]);
+#endif
                 }
                 if (X1K == 3 || has_gate) {                       // (x * 1.0f is x: skipping the multiply changes no bit)
 #pragma unroll
@@ -493,8 +509,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs g, int ntil
                     const u32x4_t r = xop[s][i][t];                 // GELU' only (other derivatives: ring kernels)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
+#if PP_GELU_PK
+                        const gelu_f32x2_t d2 = dgelu_fast_f2(gelu_f32x2_t{__uint_as_float(r[k] << 16), __uint_as_float(r[k] & 0xffff0000u)});
+                        v[2 * k] *= d2[0];
+                        v[2 * k + 1] *= d2[1];
+#else
                         v[2 * k] *= dgelu_fast_f(__uint_as_float(r[k] << 16));
                         v[2 * k + 1] *= dgelu_fast_f(__uint_as_float(r[k] & 0xffff0000u));
+#endif
                     }
                 }
                 o[t] = u32x4_t{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
