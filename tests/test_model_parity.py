@@ -183,7 +183,7 @@ def _bf16_gradients_vs_reference_under_autocast(name, cfg, B, L, wseed, bseed, m
                           errors <= 1.25 x the reference's class RMS -- a well-averaged statistic (measured <= 1.12 x for the weight
                           matrices; classes of tensors below 4096 elements -- column sums over B = 2 samples -- are measured against
                           max(class RMS, whole-gradient error) of the reference: 1.6 x their own class RMS occurs on base_f16);
-      every tensor        relative error <= 2 x max(its own reference error, its class RMS) + 5e-3; tensors below 4096 elements
+      every tensor        relative error <= 1.5 x max(its own reference error, its class RMS) + 5e-3 (round 6: was 2 x); tensors below 4096 elements
                           (biases, LayerNorm terms: sums over B = 2 samples that partly cancel) also get the whole-gradient reference
                           error as a floor inside the max.  A single tensor is ONE realisation of the rounding noise -- the
                           reference's own realised errors scatter by 2-3 x from tensor to tensor of one class -- so 1.25 x cannot
@@ -233,7 +233,7 @@ def _bf16_gradients_vs_reference_under_autocast(name, cfg, B, L, wseed, bseed, m
         if numel == 1:
             continue
         lim = max(ra / (gn + 1e-30), crms[c], rtot if numel < 4096 else 0.0)
-        if ea / (gn + 1e-30) > 2.0 * lim + 5e-3:
+        if ea / (gn + 1e-30) > 1.5 * lim + 5e-3:                      # (measured: <= 1.06 x / 1.12 x of `lim` on base_f4 / base_f16, tools/bf16_bound_probe.py)
             bad.append(('tensor', n, ea / (gn + 1e-30), lim))
     assert not bad, bad[:12]
 
@@ -617,7 +617,7 @@ def test_text_fp32_option_inside_the_bf16_model():
 
 
 def test_training_step_is_bitwise_reproducible():
-    """Three runs of the same three-loss step (same weights, batch, RNG seeds, dropout stream) at the benchmark's batch size on the
+    """Eight runs of the same three-loss step (same weights, batch, RNG seeds, dropout stream) at the benchmark's batch size on the
     full 16 x 224^2 geometry give bit-identical losses and gradients.  By design, not by luck: there is no atomic add on the path
     (the embedding-table gradients -- where <s>, </s>, the padding position and repeated words receive many contributions -- are
     summed by one owner wave per table row in token order; the grouped weight-gradient launch adds its reduction splits in split
@@ -636,24 +636,24 @@ def test_training_step_is_bitwise_reproducible():
     ids[1::2, 9] = ids[0, 4]
     data['text_mlm_ids'][:, 7] = data['text_mlm_ids'][0, 3]
     m = _build(cfg, sd, torch.bfloat16).train()
-    runs = []
-    for _ in range(3):
-        m.zero_grad(set_to_none=True)
+    first = None
+    for run in range(8):                                   # (eight runs: the one non-reproducible read this path has shown -- a broadcast-read
+        m.zero_grad(set_to_none=True)                      # small operand through plain loads, profiles/round6_experiments.md section 10 -- hit one step in ~12)
         m.seed_dropout(123)
         np.random.seed(3)
         torch.manual_seed(3)
         loss, ld, _ = _forward(m, data, noun, verb, 'EgoNCE_MLM_ITM')
         loss.backward()
         torch.cuda.synchronize()
-        runs.append((float(loss.detach()), {n: p.grad.clone() for n, p in m.named_parameters()}))
-    for r in runs[1:]:
-        assert runs[0][0] == r[0]
-        for n in ('text_model.embeddings.word_embeddings.weight', 'text_model.embeddings.position_embeddings.weight',
-                  'text_model.embeddings.token_type_embeddings.weight'):
-            assert torch.equal(runs[0][1][n], r[1][n]), n
-            assert runs[0][1][n].abs().sum() > 0, n
-        for n in runs[0][1]:
-            assert torch.equal(runs[0][1][n], r[1][n]), n
+        if first is None:
+            first = (float(loss.detach()), {n: p.grad.clone() for n, p in m.named_parameters()})
+            for n in ('text_model.embeddings.word_embeddings.weight', 'text_model.embeddings.position_embeddings.weight',
+                      'text_model.embeddings.token_type_embeddings.weight'):
+                assert first[1][n].abs().sum() > 0, n
+            continue
+        assert first[0] == float(loss.detach()), run
+        for n, p in m.named_parameters():
+            assert torch.equal(first[1][n], p.grad), (run, n)
 
 
 def test_long_clip_full_size_properties_bf16():
