@@ -54,10 +54,12 @@ const Switch g_switches[] = {
     {"EGV_PP_TRIM", 1, "grid trimmed to the smallest size that keeps the round count"},
     {"EGV_PP_RES_MINK", 1536, "shortest K for which a residual-epilogue GEMM takes the persistent kernel on 256-row tiles"},
     {"EGV_LN_BLOCKS", 512, "workgroup cap of the LayerNorm backward"},
+    {"EGV_LN_DEFER", 1, "video block backward: the LayerNorm parameter-gradient partials of the call's passes are summed by one launch at its end"},
     {"EGV_LN_PACKED", 1, "packed four-rows-per-wave LayerNorm backward (bf16, D = 768 / 1024)"},
     {"EGV_GELU_DERIV", 0, "video MLP saves gelu'(x) instead of x in the bf16 mode (EGV_ACT_GELU_D; measured slower, off)"},
     {"EGV_WGRAD_GROUP", 1, "all weight gradients of a video block call as one persistent grouped launch"},
     {"EGV_WGRAD_CUS", 0, "CU grant of the grouped weight-gradient launch (0: 2/3 CU per output tile)"},
+    {"EGV_WGRAD_TAIL_CUS", 0, "CU grant of the LAST grouped weight-gradient launch of a backward pass (EGV_BLOCK_TAIL; 0: 7/8 of the CUs)"},
     {"EGV_WGRAD_CUS_FUSED", 0, "CU grant of a fused block's grouped launch (0: as EGV_WGRAD_CUS / 2/3 CU per output tile)"},
     {"EGV_FUSED_LIMIT_LIFT", 1, "fused block backward: the GEMMs after the image-to-text part plan for the whole chip"},
     {"EGV_WGRAD_DEFER_MAXTILES", 192, "largest group whose launch is left running beside the next block call"},

@@ -21,6 +21,8 @@ int egv_cfg_int(const char* name, int def);          // run-time switches: the o
 bool egv_cfg_on(const char* name, bool def);
 void egv_gemm_set_cu_limit(int n);                  // egv_gemm3.hip: CUs the persistent forward / dgrad grids of this thread plan for
 void egv_gemm_set_cu_slack(int n);                  // ... and how many CUs beyond that plan a grid may take to save a round (-1: EGV_PP_LIMIT_SLACK)
+void egv_ln_bwd_defer_begin(void* ws, long long bytes);     // egv_norm.hip: the LayerNorm parameter-gradient partials of a call summed by ONE launch
+int egv_ln_bwd_defer_flush(void* stream);
 extern "C" int egv_layernorm_bwd2(int dtype, const void* dy, const void* x, const float* stats, const float* gamma,
                                   const void* add, const void* add2, void* dx, float* dgamma, float* dbeta, int M, int D,
                                   void* workspace, void* stream);
@@ -47,6 +49,15 @@ struct Bump {
         return r;
     }
     bool ok() const { return off <= cap; }
+};
+
+// four partial buffers of a LayerNorm backward (egv_layernorm_bwd_workspace_bytes each, 256-byte aligned slices)
+size_t ln_defer_bytes(int M, int D) { return 4 * (al((size_t)egv_layernorm_bwd_workspace_bytes(M, D)) + 256); }
+struct LnDeferScope {                               // egv_ln_bwd_defer_begin ... flush; an early return of the call ends the deferral
+    bool open;
+    LnDeferScope(void* ws, long long bytes) : open(true) { egv_ln_bwd_defer_begin(ws, bytes); }
+    int flush(void* stream) { open = false; return egv_ln_bwd_defer_flush(stream); }
+    ~LnDeferScope() { if (open) egv_ln_bwd_defer_begin(nullptr, 0); }
 };
 
 // ---- event ring (stream fork / join inside one call) ----
@@ -414,7 +425,11 @@ long long vgroup_ws_bytes(const egv_vblock_desc* d) {
         if (d->L > 0) { add(D, D); add(D, D); }
     }
     const long long b = egv_gemm_wgrad_grouped_workspace_bytes(M, n, pr, vgroup_cus(d));
-    const long long b0 = egv_gemm_wgrad_grouped_workspace_bytes(M, n, pr, (device_cus() * 7) / 8);     // single-stream mode
+    long long b0 = egv_gemm_wgrad_grouped_workspace_bytes(M, n, pr, (device_cus() * 7) / 8);     // single-stream mode
+    if (const int tc = egv_cfg_int("EGV_WGRAD_TAIL_CUS", 0)) {                                    // the tail launch's own grant
+        const long long b1 = egv_gemm_wgrad_grouped_workspace_bytes(M, n, pr, tc);
+        if (b1 > b0) b0 = b1;
+    }
     return b > b0 ? b : (b0 > 0 ? b0 : 0);
 }
 
@@ -452,7 +467,7 @@ extern "C" long long egv_vblock_ws_bytes(const egv_vblock_desc* d, int backward)
         mx(egv_gemm_wgrad_workspace_bytes((int)Hd, (int)D, (int)M)); mx(egv_gemm_wgrad_workspace_bytes((int)D, (int)Hd, (int)M));
         if (d->L > 0) mx(egv_gemm_wgrad_workspace_bytes(2 * (int)D, (int)D, d->B * d->L));
         mx(vgroup_ws_bytes(d));
-        tot += al((size_t)wg) + al((size_t)egv_layernorm_bwd_workspace_bytes((int)M, (int)D));
+        tot += al((size_t)wg) + al((size_t)egv_layernorm_bwd_workspace_bytes((int)M, (int)D)) + al(ln_defer_bytes((int)M, (int)D));
         tot += al(M * Hd * es) + 8 * al(M * D * es) + 2 * al(M * 3 * D * es) + 3 * al(M * H * 4) + 4096;
         if (d->L > 0) tot += 4 * al(M * D * es) + al((size_t)d->B * d->L * 2 * D * es) + 4096;
     }
@@ -629,6 +644,9 @@ extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
     }
     void* wgw = ws.take((size_t)wgb);                       // weight-gradient slabs: the side stream runs them one after another
     void* lnw = ws.take((size_t)egv_layernorm_bwd_workspace_bytes(M, D));
+    // the call's three (fused: four) LayerNorm backward passes keep their parameter-gradient partials until ONE reduction launch at the end
+    // of the call (nothing in the call reads dgamma / dbeta): two or three dependent 6-us launches less on the calling stream per call
+    LnDeferScope ln_defer(ws.take(ln_defer_bytes(M, D)), (long long)ln_defer_bytes(M, D));
     void* dpre = ws.take((size_t)M * Hd * es);
     void* dh2 = ws.take((size_t)M * D * es);
     void* d_sr = ws.take((size_t)M * D * es);
@@ -753,8 +771,11 @@ extern "C" int egv_vblock_bwd(const egv_vblock_desc* d) {
     // (EGV_BLOCK_HEAD: the space residual's gradient reaches x through the caller's own graph, not through this call)
     BCHK(egv_layernorm_bwd2(dt, dh3, d->x, (const float*)(sv + L.stats3), d->ln_g[VL_NORM3], head ? nullptr : d_sr, d_tr, d->dx, d->dln_g[VL_NORM3],
                             d->dln_b[VL_NORM3], M, D, lnw, st));
+    BCHK(ln_defer.flush(st));
     const bool tail = side_group && (d->flags & EGV_BLOCK_TAIL);      // no data-gradient chain follows: the launch may have the chip
-    if (ngrp) BCHK(egv_gemm_wgrad_grouped(dt, M, ngrp, grp, (side_group && !tail) ? vgroup_cus(d) : (device_cus() * 7) / 8, wgw, wgb, fk.begin()));
+    static const int tail_cus = egv_cfg_int("EGV_WGRAD_TAIL_CUS", 0);  // grant of the tail launch (0: 7/8 of the CUs)
+    const int free_cus = (tail && tail_cus > 0) ? tail_cus : (device_cus() * 7) / 8;
+    if (ngrp) BCHK(egv_gemm_wgrad_grouped(dt, M, ngrp, grp, (side_group && !tail) ? vgroup_cus(d) : free_cus, wgw, wgb, fk.begin()));
     if (!side_group) fk.join();
     return 0;
 }

@@ -483,6 +483,47 @@ __global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __re
     }
 }
 
+// The same sum for up to eight partial buffers in ONE launch (blockIdx.y = buffer): the LayerNorm parameter gradients of a block's backward
+// call, whose three or four reductions are otherwise dependent 6-us launches on the calling stream although nothing in the call reads
+// their results.  Per buffer the code, the row split and the order of the sums are those of colsum_partials_kernel: the same bits.
+struct ColsumBatch {
+    const float* partial[8];
+    float* out[8];            // [dgamma ; dbeta] contiguous (out2 == nullptr) or dgamma
+    float* out2[8];           // dbeta when it is not out + D
+    int P[8];
+    int D, n;
+};
+__global__ __launch_bounds__(1024) void colsum_partials_batch_kernel(const ColsumBatch b) {
+    __shared__ float red[16][64];
+    const int e = blockIdx.y;
+    const float* __restrict__ partial = b.partial[e];
+    const int P = b.P[e], ncol = 2 * b.D, stride = 2 * b.D;
+    const int lane = threadIdx.x & 63, w = wave_id();
+    const int c = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (c < ncol) {
+        int p = w;
+        for (; p + 7 * 16 < P; p += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(p + u * 16) * stride + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; p < P; p += 16) s += partial[(size_t)p * stride + c];
+    }
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && c < ncol) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][lane];
+        t = t * 1.0f;
+        if (b.out2[e] && c >= b.D) b.out2[e][c - b.D] = t;
+        else b.out[e][c] = t;
+    }
+}
+
 // partial column sums of X[M,N]: grid (ceil(N/256), chunks); each lane owns 4 columns, waves split rows.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, float* __restrict__ partial, int M, int N, int ld,
@@ -686,6 +727,49 @@ static inline int ln_bwd_blocks(int M) {
 
 extern "C" long long egv_layernorm_bwd_workspace_bytes(int M, int D) { return (long long)ln_bwd_blocks(M) * 2 * D * 4; }
 
+// ---- deferred reduction of the LayerNorm parameter-gradient partials (block executor, egv_block.cpp) -------------------------------
+// Between egv_ln_bwd_defer_begin(ws, bytes) and egv_ln_bwd_defer_flush(stream) every egv_layernorm_bwd2 call of this host thread (bf16 / fp32
+// forms of this file with the [nb][2][D] partial layout) writes its partials into its own slice of `ws` and does NOT launch its
+// reduction; the flush sums all of them in one launch.  A call that does not fit (more than eight, slice too small) reduces at once as before.
+namespace {
+struct LnDefer {
+    bool on = false;
+    char* base = nullptr;
+    size_t cap = 0, off = 0;
+    egv::ColsumBatch b{};
+};
+thread_local LnDefer g_ln_defer;
+}  // namespace
+void egv_ln_bwd_defer_begin(void* ws, long long bytes) {
+    static const bool enabled = egv_cfg_on("EGV_LN_DEFER", true);
+    LnDefer& d = g_ln_defer;
+    d.on = enabled && ws && bytes > 0;
+    d.base = (char*)ws; d.cap = (size_t)(bytes > 0 ? bytes : 0); d.off = 0;
+    d.b = egv::ColsumBatch{};
+}
+int egv_ln_bwd_defer_flush(void* stream) {
+    LnDefer& d = g_ln_defer;
+    d.on = false;
+    if (d.b.n == 0) return 0;
+    hipLaunchKernelGGL(colsum_partials_batch_kernel, dim3((2 * d.b.D + 63) / 64, d.b.n), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), d.b);
+    d.b.n = 0;
+    EGV_LAUNCH_CHECK();
+    return 0;
+}
+// a slice for nb2 partial rows of 2 D floats, or nullptr (-> immediate reduction)
+static float* ln_defer_slot(int nb2, int D, float* dgamma, float* dbeta) {
+    LnDefer& d = g_ln_defer;
+    if (!d.on || d.b.n >= 8 || (d.b.n > 0 && d.b.D != D)) return nullptr;
+    const size_t need = (size_t)nb2 * 2 * D * 4;
+    const size_t off = (d.off + 255) & ~(size_t)255;
+    if (off + need > d.cap) return nullptr;
+    float* p = (float*)(d.base + off);
+    d.off = off + need;
+    const int e = d.b.n++;
+    d.b.partial[e] = p; d.b.out[e] = dgamma; d.b.out2[e] = (dbeta == dgamma + D) ? nullptr : dbeta; d.b.P[e] = nb2; d.b.D = D;
+    return p;
+}
+
 extern "C" int egv_layernorm_bwd2(int dtype, const void* dy, const void* x, const float* stats, const float* gamma,
                                   const void* add, const void* add2, void* dx, float* dgamma, float* dbeta, int M, int D,
                                   void* workspace, void* stream);
@@ -706,6 +790,8 @@ extern "C" int egv_layernorm_bwd2(int dtype, const void* dy, const void* x, cons
     const int rpb = (M + nb - 1) / nb;
     const int nb2 = (M + rpb - 1) / rpb;
     float* partial = (float*)workspace;
+    float* const slot = ln_defer_slot(nb2, D, dgamma, dbeta);        // block executor: the reduction waits for the call's flush
+    if (slot) partial = slot;
     static const int packed = egv_cfg_int("EGV_LN_PACKED", 1);
     if (dtype == EGV_BF16 && packed && D == 1024) {                  // ViT-L / RoBERTa-large width: two packed rows per wave
         const bf16_t *pdy = (const bf16_t*)dy, *pxx = (const bf16_t*)x, *pa = (const bf16_t*)add, *pb = (const bf16_t*)add2;
@@ -728,6 +814,7 @@ extern "C" int egv_layernorm_bwd2(int dtype, const void* dy, const void* x, cons
         hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(nb2), dim3(256), 0, st, (const float*)dy, (const float*)x, stats, gamma,
                            (const float*)add, (const float*)add2, (float*)dx, partial, M, D, rpb);
     EGV_LAUNCH_CHECK();
+    if (slot) return 0;
     // partial layout [nb2][2][D]: columns 0..D-1 = dgamma, D..2D-1 = dbeta
     if (dbeta == dgamma + D) {                  // caller keeps [dgamma ; dbeta] in one buffer: one reduction over 2D columns
         hipLaunchKernelGGL(colsum_partials_kernel, dim3((2 * D + 63) / 64), dim3(1024), 0, st, (const float*)partial, dgamma, nb2,

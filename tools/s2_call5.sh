@@ -1,0 +1,13 @@
+#!/bin/bash
+O=gpurun_out/s2c5; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+timeout 900 python -m pytest tests/test_hip_ops.py tests/test_model_parity.py -q -x -m gpu -k "block or layernorm or tiny or base_f4 or reproducible or checkpoint" > $O/tests.log 2>&1; tail -2 $O/tests.log
+bash tools/ab_multi.sh 4 "EGV_LN_DEFER=0" "EGV_LN_DEFER=1" "EGV_WGRAD_TAIL_CUS=144" "EGV_LN_DEFER=0 EGV_WGRAD_TAIL_CUS=144" 2>&1 | tee $O/ab.txt
+cd /tmp; export TMPDIR=/tmp
+timeout -s KILL 400 rocprofv3 --kernel-trace -d $O/tr -o p -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-gemm-events > $O/tr.log 2>&1
+cd $R
+python tools/trace_dump.py $(find $O/tr -name "*.db" | head -1) $O/step.csv 1 | tail -1
+find $O -name "*.db" -delete; rm -rf $O/tr
+wc -l $O/step.csv

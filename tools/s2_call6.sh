@@ -1,0 +1,12 @@
+#!/bin/bash
+O=gpurun_out/s2c6; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+bash tools/ab_stats.sh 4 30 "EGV_NOP=0" "EGV_WGRAD_TAIL_CUS=144" "EGV_LN_DEFER=0" 2>&1 | tee $O/ab.txt
+cd /tmp; export TMPDIR=/tmp
+timeout -s KILL 400 rocprofv3 --kernel-trace --stats -d $O/tr -o p -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-gemm-events > $O/tr.log 2>&1
+cd $R
+python tools/trace_dump.py $(find $O/tr -name "*.db" | head -1) $O/step.csv 1 | tail -1
+find $O -name "*.db" -delete; rm -rf $O/tr
+wc -l $O/step.csv
