@@ -245,8 +245,12 @@ __global__ __launch_bounds__(64 * SNW) void attn_space_fwd_kernel(const SpaceArg
 // ---------------------------------------------------------------------------------------------------------------------------
 // backward: dQ, dK, dV of the group's rows, delta of its queries, and (a.ws set) the group's share of the CLS row's three gradients
 // as fp32 partials ws[sample * G + group][head][3][64] (dQ, dK, dV: attn_cls_reduce_kernel(self_term = 0) sums them)
+// (-DSPACE_BWD_WPE=n: experiment hook -- waves per SIMD the backward kernel is compiled for; 4 = 128 registers = two workgroups per CU)
+#ifndef SPACE_BWD_WPE
+#define SPACE_BWD_WPE 4
+#endif
 template <int NT, bool EXACT>
-__global__ __launch_bounds__(64 * SNW, (NT <= 14 ? 4 : 2)) void attn_space_bwd_kernel(const SpaceArgs a) {
+__global__ __launch_bounds__(64 * SNW, (NT <= 14 ? SPACE_BWD_WPE : 2)) void attn_space_bwd_kernel(const SpaceArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int IMG = NT * 16 * RB;
     constexpr int NP = (NT + 1) / 2;
